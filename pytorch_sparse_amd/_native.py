@@ -1,0 +1,145 @@
+"""ctypes binding of the C-ABI in ``include/tsamd.h`` (``lib/libtsamd.so``).
+
+This is the thin layer that hands torch device pointers, sizes and the current
+HIP stream to the hand-written kernels.  There is no CPU implementation behind
+it: a missing library, a CPU tensor or a non-zero status raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtsamd.so')
+
+# Every symbol include/tsamd.h declares (tests check that all of them resolve).
+SYMBOLS = [
+    'tsamd_hip_version', 'tsamd_last_hip_error', 'tsamd_status_string',
+    'tsamd_spmm_workspace_bytes', 'tsamd_spmm',
+    'tsamd_spmm_value_bw',
+    'tsamd_spmm_minmax_bw_workspace_bytes', 'tsamd_spmm_minmax_bw',
+    'tsamd_ind2ptr', 'tsamd_ptr2ind',
+]
+
+DTYPES = {
+    torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3,
+    torch.int32: 4, torch.int64: 5,
+}
+REDUCES = {'sum': 0, 'add': 0, 'mean': 1, 'min': 2, 'max': 3}
+
+_lib = None
+
+
+class TsamdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtsamd.so once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                'pytorch_sparse_amd: %s is missing. Build it with '
+                '`python -m pytorch_sparse_amd.build` (needs hipcc, targets gfx950). '
+                'There is no CPU fallback.' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.tsamd_hip_version.restype = ctypes.c_int64
+        L.tsamd_status_string.restype = ctypes.c_char_p
+        L.tsamd_spmm_workspace_bytes.restype = ctypes.c_size_t
+        if hasattr(L, 'tsamd_spmm_minmax_bw_workspace_bytes'):
+            L.tsamd_spmm_minmax_bw_workspace_bytes.restype = ctypes.c_size_t
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        L = lib()
+        msg = L.tsamd_status_string(int(status)).decode()
+        if status == 3:
+            msg += ' (hipError_t %d)' % L.tsamd_last_hip_error()
+        raise TsamdError('%s failed: %s' % (what, msg))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _i64(x):
+    return ctypes.c_int64(int(x))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise TsamdError(
+                'pytorch_sparse_amd runs on MI355X (HIP) tensors only; got a %s tensor. '
+                'There is no CPU implementation in this package.' % t.device.type)
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dtype_code(dtype):
+    try:
+        return DTYPES[dtype]
+    except KeyError:
+        raise TsamdError('unsupported dtype %s (supported: %s)' % (dtype, sorted(map(str, DTYPES))))
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def spmm(rowptr, col, value, mat, reduce):
+    """C-ABI ``tsamd_spmm``: returns (out, arg_out or None).  mat: [..., N, K] contiguous."""
+    require_gpu(rowptr, col, value, mat)
+    red = REDUCES[reduce]
+    dt = dtype_code(mat.dtype)
+    if value is not None and value.dtype != mat.dtype:
+        raise TsamdError('expected scalar type %s but found %s' % (mat.dtype, value.dtype))
+    if mat.dim() < 2:
+        raise TsamdError('Input mismatch: mat.dim() >= 2 required')
+    mat = mat.contiguous()
+    M, E = rowptr.numel() - 1, col.numel()
+    N, K = mat.size(-2), mat.size(-1)
+    B = mat.numel() // max(N * K, 1) if N * K > 0 else 1
+    for s in mat.shape[:-2]:
+        pass
+    sizes = list(mat.shape)
+    sizes[-2] = M
+    out = torch.empty(sizes, dtype=mat.dtype, device=mat.device)
+    arg = None
+    if red >= 2:
+        arg = torch.empty(sizes, dtype=torch.int64, device=mat.device)
+    L = lib()
+    nb = L.tsamd_spmm_workspace_bytes(dt, red, _i64(B), _i64(M), _i64(K), _i64(E))
+    ws = workspace(nb, mat.device)
+    with torch.cuda.device(mat.device):
+        st = L.tsamd_spmm(dt, red, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(out),
+                          _ptr(arg), _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
+                          ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
+    check(st, 'tsamd_spmm')
+    return out, arg
+
+
+def ind2ptr(ind, M):
+    require_gpu(ind)
+    out = torch.empty(M + 1, dtype=torch.int64, device=ind.device)
+    with torch.cuda.device(ind.device):
+        st = lib().tsamd_ind2ptr(_ptr(ind), _i64(M), _i64(ind.numel()), _ptr(out),
+                                 stream_ptr(ind.device))
+    check(st, 'tsamd_ind2ptr')
+    return out
+
+
+def ptr2ind(ptr, E):
+    require_gpu(ptr)
+    out = torch.empty(E, dtype=torch.int64, device=ptr.device)
+    with torch.cuda.device(ptr.device):
+        st = lib().tsamd_ptr2ind(_ptr(ptr), _i64(ptr.numel() - 1), _i64(E), _ptr(out),
+                                 stream_ptr(ptr.device))
+    check(st, 'tsamd_ptr2ind')
+    return out

@@ -1,0 +1,210 @@
+// Shared device/host helpers for the gfx950 kernels (wave64 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <limits>
+
+#include "tsamd.h"
+
+namespace tsamd {
+
+// --------------------------------------------------------------------------
+// error plumbing
+// --------------------------------------------------------------------------
+extern thread_local int g_last_hip_error;
+
+#define TSAMD_HIP_TRY(expr)                       \
+  do {                                            \
+    hipError_t _e = (expr);                       \
+    if (_e != hipSuccess) {                       \
+      ::tsamd::g_last_hip_error = (int)_e;        \
+      return TSAMD_ERR_HIP;                       \
+    }                                             \
+  } while (0)
+
+#define TSAMD_LAUNCH_CHECK() TSAMD_HIP_TRY(hipGetLastError())
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int kWave = 64;
+
+// --------------------------------------------------------------------------
+// element types.  bf16 is carried as raw bits; f16 uses the native _Float16.
+// --------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t bits;
+};
+using f16_t = _Float16;
+
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+  union {
+    uint32_t u;
+    float f;
+  } c;
+  c.u = ((uint32_t)h.bits) << 16;
+  return c.f;
+}
+
+// round-to-nearest-even, NaN -> quiet NaN (same rule as c10::BFloat16)
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+  union {
+    uint32_t u;
+    float f;
+  } c;
+  c.f = f;
+  bf16_t r;
+  if (f != f) {
+    r.bits = 0x7FC0;
+  } else {
+    uint32_t bias = 0x7FFFu + ((c.u >> 16) & 1u);
+    r.bits = (uint16_t)((c.u + bias) >> 16);
+  }
+  return r;
+}
+
+// Traits<T>: accumulator type, conversions, and the reducer's init values
+// (csrc/cpu/reducer.h:43-52 of the reference: max() for MIN, lowest() for MAX).
+template <typename T>
+struct Traits;
+
+template <>
+struct Traits<float> {
+  using acc_t = float;
+  static constexpr bool kNarrow = false;
+  __device__ static inline acc_t to_acc(float x) { return x; }
+  __device__ static inline float from_acc(acc_t a) { return a; }
+  __device__ static inline acc_t round_acc(acc_t a) { return a; }
+  __device__ static inline acc_t max_init() { return 3.402823466e+38f; }
+  __device__ static inline acc_t lowest_init() { return -3.402823466e+38f; }
+};
+
+template <>
+struct Traits<double> {
+  using acc_t = double;
+  static constexpr bool kNarrow = false;
+  __device__ static inline acc_t to_acc(double x) { return x; }
+  __device__ static inline double from_acc(acc_t a) { return a; }
+  __device__ static inline acc_t round_acc(acc_t a) { return a; }
+  __device__ static inline acc_t max_init() { return 1.7976931348623157e+308; }
+  __device__ static inline acc_t lowest_init() { return -1.7976931348623157e+308; }
+};
+
+template <>
+struct Traits<f16_t> {
+  using acc_t = float;
+  static constexpr bool kNarrow = true;
+  __device__ static inline acc_t to_acc(f16_t x) { return (float)x; }
+  __device__ static inline f16_t from_acc(acc_t a) { return (f16_t)a; }
+  __device__ static inline acc_t round_acc(acc_t a) { return (float)(f16_t)a; }
+  __device__ static inline acc_t max_init() { return 65504.0f; }
+  __device__ static inline acc_t lowest_init() { return -65504.0f; }
+};
+
+template <>
+struct Traits<bf16_t> {
+  using acc_t = float;
+  static constexpr bool kNarrow = true;
+  __device__ static inline acc_t to_acc(bf16_t x) { return bf16_to_f32(x); }
+  __device__ static inline bf16_t from_acc(acc_t a) { return f32_to_bf16(a); }
+  __device__ static inline acc_t round_acc(acc_t a) { return bf16_to_f32(f32_to_bf16(a)); }
+  // 0x7F7F = largest finite bf16
+  __device__ static inline acc_t max_init() { return 3.38953139e+38f; }
+  __device__ static inline acc_t lowest_init() { return -3.38953139e+38f; }
+};
+
+template <>
+struct Traits<int32_t> {
+  using acc_t = int32_t;
+  static constexpr bool kNarrow = false;
+  __device__ static inline acc_t to_acc(int32_t x) { return x; }
+  __device__ static inline int32_t from_acc(acc_t a) { return a; }
+  __device__ static inline acc_t round_acc(acc_t a) { return a; }
+  __device__ static inline acc_t max_init() { return 2147483647; }
+  __device__ static inline acc_t lowest_init() { return (-2147483647 - 1); }
+};
+
+template <>
+struct Traits<int64_t> {
+  using acc_t = int64_t;
+  static constexpr bool kNarrow = false;
+  __device__ static inline acc_t to_acc(int64_t x) { return x; }
+  __device__ static inline int64_t from_acc(acc_t a) { return a; }
+  __device__ static inline acc_t round_acc(acc_t a) { return a; }
+  __device__ static inline acc_t max_init() { return 9223372036854775807LL; }
+  __device__ static inline acc_t lowest_init() { return (-9223372036854775807LL - 1); }
+};
+
+static inline size_t dtype_size(int dtype) {
+  switch (dtype) {
+    case TSAMD_F32: return 4;
+    case TSAMD_F64: return 8;
+    case TSAMD_F16: return 2;
+    case TSAMD_BF16: return 2;
+    case TSAMD_I32: return 4;
+    case TSAMD_I64: return 8;
+    default: return 0;
+  }
+}
+static inline size_t acc_size(int dtype) {
+  switch (dtype) {
+    case TSAMD_F32: case TSAMD_F16: case TSAMD_BF16: case TSAMD_I32: return 4;
+    case TSAMD_F64: case TSAMD_I64: return 8;
+    default: return 0;
+  }
+}
+
+// Dispatch a tsamd_dtype to a C++ element type.
+#define TSAMD_DISPATCH_DTYPE(dtype, ...)                                   \
+  [&]() -> int {                                                           \
+    switch (dtype) {                                                       \
+      case TSAMD_F32: { using scalar_t = float; return __VA_ARGS__(); }    \
+      case TSAMD_F64: { using scalar_t = double; return __VA_ARGS__(); }   \
+      case TSAMD_F16: { using scalar_t = ::tsamd::f16_t; return __VA_ARGS__(); }  \
+      case TSAMD_BF16: { using scalar_t = ::tsamd::bf16_t; return __VA_ARGS__(); } \
+      case TSAMD_I32: { using scalar_t = int32_t; return __VA_ARGS__(); }  \
+      case TSAMD_I64: { using scalar_t = int64_t; return __VA_ARGS__(); }  \
+      default: return (int)TSAMD_ERR_UNSUPPORTED;                          \
+    }                                                                      \
+  }()
+
+// --------------------------------------------------------------------------
+// wave64 cross-lane helpers.  ds_bpermute takes a byte address (lane * 4).
+// --------------------------------------------------------------------------
+__device__ inline uint32_t lane_read_u32(uint32_t v, int src_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+__device__ inline float lane_read(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ inline int32_t lane_read(int32_t v, int src_lane) {
+  return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
+}
+__device__ inline uint32_t lane_read(uint32_t v, int src_lane) {
+  return lane_read_u32(v, src_lane);
+}
+__device__ inline int64_t lane_read(int64_t v, int src_lane) {
+  uint32_t lo = lane_read_u32((uint32_t)(uint64_t)v, src_lane);
+  uint32_t hi = lane_read_u32((uint32_t)((uint64_t)v >> 32), src_lane);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ inline double lane_read(double v, int src_lane) {
+  return __longlong_as_double(lane_read((int64_t)__double_as_longlong(v), src_lane));
+}
+
+template <typename A>
+__device__ inline A lane_xor(A v, int mask) {
+  int lane = (int)(threadIdx.x & 63);
+  return lane_read(v, lane ^ mask);
+}
+
+// A 16-byte (or narrower) packet of VEC elements; alignment lets the compiler
+// emit one global_load_dwordx4 / global_store_dwordx4 per lane.
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) Pack {
+  T v[VEC];
+};
+
+}  // namespace tsamd
