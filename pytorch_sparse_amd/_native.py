@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtsamd.so')
+LIB_PATH = os.environ.get('TSAMD_LIB') or os.path.join(_HERE, 'lib', 'libtsamd.so')
 
 # Every symbol include/tsamd.h declares (tests check that all of them resolve).
 SYMBOLS = [
@@ -106,8 +106,6 @@ def spmm(rowptr, col, value, mat, reduce):
     M, E = rowptr.numel() - 1, col.numel()
     N, K = mat.size(-2), mat.size(-1)
     B = mat.numel() // max(N * K, 1) if N * K > 0 else 1
-    for s in mat.shape[:-2]:
-        pass
     sizes = list(mat.shape)
     sizes[-2] = M
     out = torch.empty(sizes, dtype=mat.dtype, device=mat.device)

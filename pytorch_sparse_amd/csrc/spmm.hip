@@ -1,27 +1,37 @@
-// CSR SpMM forward for gfx950 (MI355X), wave64 row-split.
+// CSR SpMM forward for gfx950 (MI355X): merge-path balanced, wave64 row-split.
 //
 // Replaces spmm_cuda / spmm_cpu of the reference (csrc/cuda/spmm_cuda.cu:92-155,
 // csrc/cpu/spmm_cpu.cpp:8-101).  The arithmetic contract (init values, strict
 // compares, first-occurrence ties, empty-row handling, mean divisor) follows
 // csrc/cpu/reducer.h:43-84.
 //
-// Mapping ("SpMM kernel"):
-//   * one wavefront owns one output row (b, m);
-//   * the 64 lanes are split into G = 64 / LPR groups of LPR lanes, each lane
-//     holding VEC consecutive features (16 bytes when the row pitch allows it),
-//     so one vector-memory instruction gathers G different rows of `mat`, each
-//     as one contiguous LPR*16-byte read (F=128 fp32: 2 rows x 512 B);
-//   * a row's (col, value) pairs are read once, 64 per coalesced load, and
-//     handed to the groups with ds_bpermute (no LDS allocation, no re-reads
-//     per 32-column tile as in the reference kernel);
-//   * U gathers are issued back to back before the first use (U*G rows in
-//     flight per wave);
-//   * groups are combined with a bpermute butterfly; MIN/MAX carry
-//     (value, edge id) and break ties towards the smaller edge id;
-//   * rows longer than kLongRow edges are not processed by their wave: they are
-//     appended to a work list, cut into kChunk-edge pieces that are spread over
-//     the whole chip by a second kernel, and merged in edge order by a third
-//     (deterministic, no atomics on the data path).
+// Why not "one wave per row" (the reference's mapping): on power-law graphs the
+// row degree is correlated with the row index bits, the hardware deals
+// workgroups to the 8 XCDs round-robin, and one XCD ends up with ~44 % of the
+// edges of an R-MAT matrix (measured: 2x slowdown).  Here the
+// work list "M row ends + E edges" is cut into P equal pieces along the merge
+// path (Merrill & Garland's SpMV decomposition), so every wavefront gets the
+// same number of (row, edge) items whatever the degree distribution, hub rows
+// are split over many waves, and no atomics are needed:
+//
+//   1. spmm_partition_kernel   P+1 diagonal binary searches -> (row, edge) table
+//   2. spmm_merge_kernel       wave p walks its rows/edges:
+//        * (col, value) arrive in 64-edge windows, one coalesced load each,
+//          the next window is requested before the current one is consumed;
+//        * the 64 lanes form G = 64/LPR groups of LPR lanes x VEC features
+//          (16 B per lane), so one vector-memory instruction gathers G rows of
+//          `mat`, each as one contiguous LPR*16-byte read; U such gathers are
+//          issued back to back (G*U rows in flight per wave);
+//        * window entries reach the groups through ds_bpermute (no LDS);
+//        * a row that ends inside the piece is reduced across groups
+//          (bpermute butterfly) and stored once; the pieces of a row that is
+//          cut by a partition boundary go to carry records (accumulator
+//          precision, plus the arg for min/max);
+//   3. spmm_fixup_kernel       the wave of the partition in which a cut row
+//        ends folds that row's carry records (ties -> smaller edge id) and
+//        writes the final value (mean divide / empty handling happen here).
+//
+// Deterministic: the partition only depends on rowptr, every combine order is fixed.
 #include "common.h"
 
 namespace tsamd {
@@ -31,79 +41,115 @@ constexpr int RED_ADD = 0;  // sum and mean
 constexpr int RED_MIN = 1;
 constexpr int RED_MAX = 2;
 
-constexpr int kUnroll = 4;          // gathers in flight per group
-constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
-constexpr int kLongRow = 512;       // rows above this go to the long-row path
-constexpr int kChunk = 512;         // edges per long-row work item
+// tuning knobs (overridable with -D for A/B experiments, see scripts/variants.py)
+#ifndef TSAMD_UNROLL
+#define TSAMD_UNROLL 4
+#endif
+#ifndef TSAMD_WPB
+#define TSAMD_WPB 4
+#endif
+#ifndef TSAMD_ITEMS_MAX
+#define TSAMD_ITEMS_MAX 1024
+#endif
+#ifndef TSAMD_ITEMS_MIN
+#define TSAMD_ITEMS_MIN 128
+#endif
+#ifndef TSAMD_TARGET_WAVES
+#define TSAMD_TARGET_WAVES 32768
+#endif
+constexpr int kUnroll = TSAMD_UNROLL;      // gathers in flight per group
+constexpr int kWavesPerBlock = TSAMD_WPB;  // 256-thread workgroups
 constexpr int64_t kNoArg = 0x7fffffffffffffffLL;
 
-struct LongRec {  // one long row
-  int64_t vrow;   // b * M + m
-  int64_t first;  // first work item
-  int64_t nchunk;
-};
-struct LongItem {  // one kChunk-edge piece of a long row
-  int64_t vrow;
-  int64_t chunk;
+struct Coord {  // a point on the merge path: rows [0,row) done, edges [0,edge) consumed
+  int64_t row;
+  int64_t edge;
 };
 
 struct Workspace {
-  unsigned int *counters;  // [0] = #items, [1] = #long rows
-  LongRec *recs;
-  LongItem *items;
-  void *part_val;     // [items][K] acc_t
-  int64_t *part_arg;  // [items][K] (min/max only)
-  int64_t max_recs, max_items;
+  Coord *table;       // [P+1]
+  int64_t *tail_row;  // [P]   row id of the unfinished row's partial, or -1
+  void *head_val;     // [B][P][K] acc_t : piece of the first row (it started earlier)
+  void *tail_val;     // [B][P][K] acc_t : piece of the last row (it continues later)
+  int64_t *head_arg;  // min/max only
+  int64_t *tail_arg;
+  int64_t P;
+  int64_t items;  // (row, edge) items per partition
 };
 
-// Accumulate edges [eb, ee) of one row into val/arg.  All 64 lanes stay
-// active; lanes whose feature slot is out of range load from slot 0 and are
-// masked at the store.
+// ---------------------------------------------------------------------------
+// 1. merge-path partition: list A = row ends rowptr[1..M], list B = edge ids
+// ---------------------------------------------------------------------------
+__global__ void spmm_partition_kernel(const int64_t *__restrict__ rowptr, int64_t M, int64_t E,
+                                      Workspace ws) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > ws.P) return;
+  int64_t d = p * ws.items;
+  if (d > M + E) d = M + E;
+  int64_t lo = d > E ? d - E : 0;
+  int64_t hi = d < M ? d : M;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid + 1] <= d - mid - 1) lo = mid + 1;
+    else hi = mid;
+  }
+  ws.table[p] = Coord{lo, d - lo};
+}
+
+// ---------------------------------------------------------------------------
+// accumulation helpers
+// ---------------------------------------------------------------------------
 template <typename T, int VEC, int RED>
-__device__ __forceinline__ void accumulate_range(
-    int64_t eb, int64_t ee, const int64_t *__restrict__ col,
-    const T *__restrict__ value, const T *__restrict__ matk, uint32_t K, int lane,
-    int lgG, int g, typename Traits<T>::acc_t (&val)[VEC], int64_t (&arg)[VEC]) {
+__device__ __forceinline__ void init_acc(typename Traits<T>::acc_t (&val)[VEC],
+                                         int64_t (&arg)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    if constexpr (RED == RED_ADD) val[j] = 0;
+    else if constexpr (RED == RED_MIN) val[j] = Traits<T>::max_init();
+    else val[j] = Traits<T>::lowest_init();
+    arg[j] = kNoArg;
+  }
+}
+
+// Accumulate window entries [lo, hi) (window-relative, 0..64) of one row.
+// c_l / w_l hold the window's column ids / weights, one per lane.  All lanes
+// stay active; slots past `hi` re-read the last valid entry and are masked.
+template <typename T, int VEC, int RED>
+__device__ __forceinline__ void accumulate_window(
+    int lo, int hi, int64_t wbase, uint32_t c_l, typename Traits<T>::acc_t w_l,
+    const T *__restrict__ matk, uint32_t K, int lgG, int g,
+    typename Traits<T>::acc_t (&val)[VEC], int64_t (&arg)[VEC]) {
   using A = typename Traits<T>::acc_t;
   using P = Pack<T, VEC>;
-  for (int64_t base = eb; base < ee; base += kWave) {
-    const int64_t rem = ee - base;
-    const int n = rem < kWave ? (int)rem : kWave;
-    uint32_t c_l = 0;
-    A w_l = A(1);
-    if (lane < n) {
-      c_l = (uint32_t)col[base + lane];
-      if (value != nullptr) w_l = Traits<T>::to_acc(value[base + lane]);
+  const int n = hi - lo;
+  const int nsteps = (n + (1 << lgG) - 1) >> lgG;
+  for (int s = 0; s < nsteps; s += kUnroll) {
+    P x[kUnroll];
+    A w[kUnroll];
+    int idx[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      idx[u] = lo + ((s + u) << lgG) + g;
+      const int src = idx[u] < hi ? idx[u] : hi - 1;
+      const uint32_t c = lane_read(c_l, src);
+      w[u] = lane_read(w_l, src);
+      x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
     }
-    const int nsteps = (n + (1 << lgG) - 1) >> lgG;
-    for (int s = 0; s < nsteps; s += kUnroll) {
-      P x[kUnroll];
-      A w[kUnroll];
-      int idx[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        idx[u] = ((s + u) << lgG) + g;
-        const int src = idx[u] < n ? idx[u] : n - 1;
-        const uint32_t c = lane_read(c_l, src);
-        w[u] = lane_read(w_l, src);
-        x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
-      }
+    for (int u = 0; u < kUnroll; ++u) {
+      const bool ok = idx[u] < hi;
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const bool ok = idx[u] < n;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const A xv = Traits<T>::to_acc(x[u].v[j]);
-          if constexpr (RED == RED_ADD) {
-            const A p = w[u] * xv;
-            val[j] += ok ? p : A(0);
-          } else {
-            const A p = Traits<T>::round_acc(w[u] * xv);
-            const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
-            if (ok && better) {
-              val[j] = p;
-              arg[j] = base + idx[u];
-            }
+      for (int j = 0; j < VEC; ++j) {
+        const A xv = Traits<T>::to_acc(x[u].v[j]);
+        if constexpr (RED == RED_ADD) {
+          const A p = w[u] * xv;
+          val[j] += ok ? p : A(0);
+        } else {
+          const A p = Traits<T>::round_acc(w[u] * xv);
+          const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
+          if (ok && better) {
+            val[j] = p;
+            arg[j] = wbase + idx[u];
           }
         }
       }
@@ -111,7 +157,7 @@ __device__ __forceinline__ void accumulate_range(
   }
 }
 
-// Butterfly over the G groups; afterwards every lane holds the row result.
+// Butterfly over the G groups; afterwards every lane holds the combined result.
 template <typename A, int VEC, int RED>
 __device__ __forceinline__ void reduce_groups(int lgG, A (&val)[VEC], int64_t (&arg)[VEC]) {
   for (int off = 32; off >= (64 >> lgG); off >>= 1) {
@@ -129,18 +175,6 @@ __device__ __forceinline__ void reduce_groups(int lgG, A (&val)[VEC], int64_t (&
         }
       }
     }
-  }
-}
-
-template <typename T, int VEC, int RED>
-__device__ __forceinline__ void init_acc(typename Traits<T>::acc_t (&val)[VEC],
-                                         int64_t (&arg)[VEC]) {
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    if constexpr (RED == RED_ADD) val[j] = 0;
-    else if constexpr (RED == RED_MIN) val[j] = Traits<T>::max_init();
-    else val[j] = Traits<T>::lowest_init();
-    arg[j] = kNoArg;
   }
 }
 
@@ -167,6 +201,8 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
     for (int j = 0; j < VEC; ++j) {
       if (deg > 0) {
         o.v[j] = Traits<T>::from_acc(val[j]);
+        // no entry beat the init value (NaN-only / +-max inputs): the reference
+        // leaves a stale index here; we report E ("no winner").
         a.v[j] = arg[j] == kNoArg ? E : arg[j];
       } else {
         o.v[j] = Traits<T>::from_acc(A(0));
@@ -174,190 +210,239 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
       }
     }
     *reinterpret_cast<Pack<T, VEC> *>(outk) = o;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) argk[j] = a.v[j];
+    *reinterpret_cast<Pack<int64_t, VEC> *>(argk) = a;
   }
 }
 
-// --------------------------------------------------------------------------
-// main kernel: one wave per (row, feature tile)
-// --------------------------------------------------------------------------
 template <typename T, int VEC, int RED>
-__global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_rows_kernel(
+__device__ __forceinline__ void write_carry(void *cval, int64_t *carg, uint64_t off,
+                                            typename Traits<T>::acc_t (&val)[VEC],
+                                            int64_t (&arg)[VEC]) {
+  using A = typename Traits<T>::acc_t;
+  Pack<A, VEC> v;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) v.v[j] = val[j];
+  *reinterpret_cast<Pack<A, VEC> *>(reinterpret_cast<A *>(cval) + off) = v;
+  if constexpr (RED != RED_ADD) {
+    Pack<int64_t, VEC> a;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a.v[j] = arg[j];
+    *reinterpret_cast<Pack<int64_t, VEC> *>(carg + off) = a;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 2. main kernel: wave p consumes merge-path items [table[p], table[p+1])
+//    grid = (ceil(P / waves per block), B * ktiles)
+// ---------------------------------------------------------------------------
+template <typename T, int VEC, int RED>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
     const T *__restrict__ value, const T *__restrict__ mat, T *__restrict__ out,
-    int64_t *__restrict__ arg_out, int64_t BM, int64_t M, int64_t N, uint32_t K,
-    int64_t E, int lgG, bool mean, Workspace ws) {
+    int64_t *__restrict__ arg_out, int64_t M, int64_t N, uint32_t K, int64_t E,
+    uint32_t ktiles, int lgG, bool mean, Workspace ws) {
   using A = typename Traits<T>::acc_t;
   const int lane = (int)(threadIdx.x & 63);
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t vrow = (int64_t)blockIdx.x * kWavesPerBlock + wib;
-  if (vrow >= BM) return;
-  const int64_t b = vrow / M;
-  const int64_t m = vrow - b * M;
-  const int64_t e0 = rowptr[m];
-  const int64_t e1 = rowptr[m + 1];
-  const int64_t deg = e1 - e0;
+  const int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  if (p >= ws.P) return;
+  const uint32_t y = blockIdx.y;
+  const uint32_t b = y / ktiles;
+  const uint32_t kt = y - b * ktiles;
 
-  if (deg > kLongRow) {
-    if (blockIdx.y == 0) {
-      const int64_t nch = (deg + kChunk - 1) / kChunk;
-      unsigned int first = 0, r = 0;
-      if (lane == 0) {
-        first = atomicAdd(&ws.counters[0], (unsigned int)nch);
-        r = atomicAdd(&ws.counters[1], 1u);
-      }
-      first = __builtin_amdgcn_readfirstlane(first);
-      r = __builtin_amdgcn_readfirstlane(r);
-      if (lane == 0) ws.recs[r] = LongRec{vrow, (int64_t)first, nch};
-      for (int64_t c = lane; c < nch; c += kWave) ws.items[first + c] = LongItem{vrow, c};
-    }
-    return;
-  }
+  const Coord c0 = ws.table[p];
+  const Coord c1 = ws.table[p + 1];
+  const int64_t r0 = c0.row, e0 = c0.edge, r1 = c1.row, e1 = c1.edge;
 
   const int lpr = 64 >> lgG;
   const int g = lane >> (6 - lgG);
   const int kl = lane & (lpr - 1);
-  const uint32_t k0 = (blockIdx.y * 64u + (uint32_t)kl) * VEC;
+  const uint32_t k0 = (kt * 64u + (uint32_t)kl) * VEC;
   const bool kok = k0 < K;
   const T *matk = mat + (uint64_t)b * N * K + (kok ? k0 : 0u);
+  const uint64_t out_b = (uint64_t)b * M * K + k0;
+  const bool writer = g == 0 && kok;
+  const uint64_t carry_off = ((uint64_t)b * ws.P + (uint64_t)p) * K + k0;  // [b][p][K]
 
+  // the first row may have been started by an earlier partition
+  const bool incoming = r0 < M && e0 > rowptr[r0];
+
+  // (col, value) windows: [wbase, wbase+64) current, the next one in flight
+  int64_t wbase = e0;
+  uint32_t c_cur, c_nxt;
+  A w_cur, w_nxt;
+  auto load_window = [&](int64_t base, uint32_t &c_l, A &w_l) {
+    const int64_t e = base + lane;
+    c_l = 0;
+    w_l = A(1);
+    if (e < e1) {
+      c_l = (uint32_t)col[e];
+      if (value != nullptr) w_l = Traits<T>::to_acc(value[e]);
+    }
+  };
+  load_window(wbase, c_cur, w_cur);
+  load_window(wbase + kWave, c_nxt, w_nxt);
+
+  // row ends: lane j holds rowptr[rp_base + 1 + j]
+  int64_t rp_base = r0;
+  auto load_rowends = [&](int64_t base) -> int64_t {
+    const int64_t r = base + 1 + lane;
+    return rowptr[r <= M ? r : M];
+  };
+  int64_t rp_l = load_rowends(rp_base);
+
+  int64_t e = e0;
   A val[VEC];
   int64_t arg[VEC];
-  init_acc<T, VEC, RED>(val, arg);
-  accumulate_range<T, VEC, RED>(e0, e1, col, value, matk, K, lane, lgG, g, val, arg);
-  reduce_groups<A, VEC, RED>(lgG, val, arg);
-  if (g == 0 && kok) {
-    const uint64_t o = (uint64_t)vrow * K + k0;
-    write_row<T, VEC, RED>(out + o, arg_out ? arg_out + o : nullptr, val, arg, deg, mean, E);
-  }
-}
 
-// --------------------------------------------------------------------------
-// long rows, pass 1: one wave per kChunk-edge work item, all feature tiles
-// --------------------------------------------------------------------------
-template <typename T, int VEC, int RED>
-__global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_long_chunks_kernel(
-    const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
-    const T *__restrict__ value, const T *__restrict__ mat, int64_t M, int64_t N,
-    uint32_t K, int lgG, Workspace ws) {
-  using A = typename Traits<T>::acc_t;
-  const int lane = (int)(threadIdx.x & 63);
-  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t nitems = ws.counters[0];
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  const int lpr = 64 >> lgG;
-  const int g = lane >> (6 - lgG);
-  const int kl = lane & (lpr - 1);
-  const uint32_t ktiles = (K + 64u * VEC - 1) / (64u * VEC);
-  A *part_val = reinterpret_cast<A *>(ws.part_val);
-  for (int64_t it = (int64_t)blockIdx.x * kWavesPerBlock + wib; it < nitems; it += nwaves) {
-    const LongItem item = ws.items[it];
-    const int64_t b = item.vrow / M;
-    const int64_t m = item.vrow - b * M;
-    const int64_t e0 = rowptr[m] + item.chunk * kChunk;
-    const int64_t e1r = rowptr[m + 1];
-    const int64_t e1 = e0 + kChunk < e1r ? e0 + kChunk : e1r;
-    for (uint32_t kt = 0; kt < ktiles; ++kt) {
-      const uint32_t k0 = (kt * 64u + (uint32_t)kl) * VEC;
-      const bool kok = k0 < K;
-      const T *matk = mat + (uint64_t)b * N * K + (kok ? k0 : 0u);
-      A val[VEC];
-      int64_t arg[VEC];
-      init_acc<T, VEC, RED>(val, arg);
-      accumulate_range<T, VEC, RED>(e0, e1, col, value, matk, K, lane, lgG, g, val, arg);
+  // accumulate edges [e, end) of the current row, advancing windows as needed
+  auto run_segment = [&](int64_t end) {
+    while (e < end) {
+      if (e >= wbase + kWave) {  // uniform: advance the window, request the next
+        wbase += kWave;
+        c_cur = c_nxt;
+        w_cur = w_nxt;
+        load_window(wbase + kWave, c_nxt, w_nxt);
+      }
+      const int64_t wend = wbase + kWave;
+      const int64_t stop = end < wend ? end : wend;
+      accumulate_window<T, VEC, RED>((int)(e - wbase), (int)(stop - wbase), wbase, c_cur, w_cur,
+                                     matk, K, lgG, g, val, arg);
+      e = stop;
+    }
+  };
+
+  for (int64_t r = r0; r < r1; ++r) {
+    int j = (int)(r - rp_base);
+    if (j == kWave) {
+      rp_base = r;
+      rp_l = load_rowends(rp_base);
+      j = 0;
+    }
+    const int64_t rend = lane_read(rp_l, j);  // uniform
+    const int64_t estart = e;                 // == rowptr[r] unless the row is cut
+    init_acc<T, VEC, RED>(val, arg);
+    if (e < rend) {
+      run_segment(rend);
       reduce_groups<A, VEC, RED>(lgG, val, arg);
-      if (g == 0 && kok) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          part_val[(uint64_t)it * K + k0 + j] = val[j];
-          if constexpr (RED != RED_ADD) ws.part_arg[(uint64_t)it * K + k0 + j] = arg[j];
-        }
+    }
+    if (writer) {
+      if (incoming && r == r0) {  // head of a cut row: the fix-up kernel finishes it
+        write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg);
+      } else {
+        const uint64_t o = out_b + (uint64_t)r * K;
+        write_row<T, VEC, RED>(out + o, arg_out + o, val, arg, rend - estart, mean, E);
       }
     }
   }
+
+  // tail: the unfinished row r1 (if any of its edges fall into this partition)
+  int64_t trow = -1;
+  if (r1 < M && e < e1) {
+    init_acc<T, VEC, RED>(val, arg);
+    run_segment(e1);
+    reduce_groups<A, VEC, RED>(lgG, val, arg);
+    if (writer) write_carry<T, VEC, RED>(ws.tail_val, ws.tail_arg, carry_off, val, arg);
+    trow = r1;
+  }
+  if (y == 0 && lane == 0) ws.tail_row[p] = trow;
 }
 
-// --------------------------------------------------------------------------
-// long rows, pass 2: one wave per long row merges its pieces in edge order
-// --------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// 3. fix-up: partition q in which a cut row ends (it has a head record) folds
+//    that row's tail records q-1, q-2, ... and writes the final value.
+//    One wave per (q, b); lanes stride over K.
+// ---------------------------------------------------------------------------
 template <typename T, int RED>
-__global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_long_merge_kernel(
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
     const int64_t *__restrict__ rowptr, T *__restrict__ out, int64_t *__restrict__ arg_out,
     int64_t M, uint32_t K, int64_t E, bool mean, Workspace ws) {
   using A = typename Traits<T>::acc_t;
   const int lane = (int)(threadIdx.x & 63);
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t nrecs = ws.counters[1];
-  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
-  const A *part_val = reinterpret_cast<const A *>(ws.part_val);
-  for (int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wib; r < nrecs; r += nwaves) {
-    const LongRec rec = ws.recs[r];
-    const int64_t m = rec.vrow % M;
-    const int64_t deg = rowptr[m + 1] - rowptr[m];
-    for (uint32_t k = lane; k < K; k += kWave) {
-      A val[1];
-      int64_t arg[1];
-      init_acc<T, 1, RED>(val, arg);
-      for (int64_t c = 0; c < rec.nchunk; ++c) {
-        const uint64_t p = (uint64_t)(rec.first + c) * K + k;
-        const A o = part_val[p];
-        if constexpr (RED == RED_ADD) {
-          val[0] += o;
-        } else {
-          const int64_t oa = ws.part_arg[p];
-          const bool better = RED == RED_MIN ? (o < val[0]) : (o > val[0]);
-          // pieces arrive in edge order: a strict compare keeps the first winner
-          if (better) {
-            val[0] = o;
-            arg[0] = oa;
-          }
+  const int64_t q = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  if (q >= ws.P) return;
+  const uint32_t b = blockIdx.y;
+  const Coord c0 = ws.table[q];
+  const Coord c1 = ws.table[q + 1];
+  const int64_t R = c0.row;
+  if (R >= M || c1.row <= R) return;  // no row ends here that started earlier
+  const int64_t rs = rowptr[R];
+  if (c0.edge <= rs) return;  // row R starts in this partition: not cut
+  const int64_t deg = rowptr[R + 1] - rs;
+  // tail records of row R sit in the partitions right before q
+  int64_t run = 0;
+  while (run < q && ws.tail_row[q - 1 - run] == R) ++run;
+
+  const A *head_val = reinterpret_cast<const A *>(ws.head_val);
+  const A *tail_val = reinterpret_cast<const A *>(ws.tail_val);
+  const uint64_t plane = (uint64_t)b * ws.P;
+  for (uint32_t k = lane; k < K; k += kWave) {
+    A val[1];
+    int64_t arg[1];
+    val[0] = head_val[(plane + q) * K + k];
+    arg[0] = kNoArg;
+    if constexpr (RED != RED_ADD) arg[0] = ws.head_arg[(plane + q) * K + k];
+    for (int64_t i = 0; i < run; ++i) {
+      const uint64_t o = (plane + (q - 1 - i)) * K + k;
+      const A v = tail_val[o];
+      if constexpr (RED == RED_ADD) {
+        val[0] += v;
+      } else {
+        const int64_t a = ws.tail_arg[o];
+        const bool better = RED == RED_MIN ? (v < val[0]) : (v > val[0]);
+        if (better || (v == val[0] && a < arg[0])) {
+          val[0] = v;
+          arg[0] = a;
         }
       }
-      const uint64_t o = (uint64_t)rec.vrow * K + k;
-      write_row<T, 1, RED>(out + o, arg_out ? arg_out + o : nullptr, val, arg, deg, mean, E);
     }
+    const uint64_t o = ((uint64_t)b * M + R) * K + k;
+    write_row<T, 1, RED>(out + o, arg_out + o, val, arg, deg, mean, E);
   }
 }
 
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
 int ilog2_ceil(uint32_t x) {
   int l = 0;
   while ((1u << l) < x) ++l;
   return l;
 }
 
-Workspace carve_workspace(void *base, int dtype, int reduce, int64_t B, int64_t K, int64_t E) {
-  Workspace ws;
-  const int64_t BE = B * E;
-  ws.max_recs = BE / (kLongRow + 1) + 1;
-  ws.max_items = BE / kChunk + ws.max_recs + 1;
-  char *p = reinterpret_cast<char *>(base);
-  size_t off = 0;
-  ws.counters = reinterpret_cast<unsigned int *>(p + off);
-  off += 256;
-  ws.recs = reinterpret_cast<LongRec *>(p + off);
-  off += align_up(sizeof(LongRec) * ws.max_recs, 256);
-  ws.items = reinterpret_cast<LongItem *>(p + off);
-  off += align_up(sizeof(LongItem) * ws.max_items, 256);
-  ws.part_val = p + off;
-  off += align_up(acc_size(dtype) * (size_t)ws.max_items * K, 256);
-  ws.part_arg = reinterpret_cast<int64_t *>(p + off);
-  if (reduce == TSAMD_MIN || reduce == TSAMD_MAX)
-    off += align_up(sizeof(int64_t) * (size_t)ws.max_items * K, 256);
-  (void)off;
-  return ws;
+void plan_partition(int64_t M, int64_t E, int64_t *P, int64_t *items) {
+  const int64_t total = M + E > 0 ? M + E : 1;
+  int64_t it = ceil_div(total, (int64_t)TSAMD_TARGET_WAVES);
+  if (it < TSAMD_ITEMS_MIN) it = TSAMD_ITEMS_MIN;
+  if (it > TSAMD_ITEMS_MAX) it = TSAMD_ITEMS_MAX;
+  *items = it;
+  *P = ceil_div(total, it);
 }
 
-size_t workspace_bytes(int dtype, int reduce, int64_t B, int64_t K, int64_t E) {
-  const int64_t BE = B * E;
-  const int64_t max_recs = BE / (kLongRow + 1) + 1;
-  const int64_t max_items = BE / kChunk + max_recs + 1;
-  size_t off = 256;
-  off += align_up(sizeof(LongRec) * max_recs, 256);
-  off += align_up(sizeof(LongItem) * max_items, 256);
-  off += align_up(acc_size(dtype) * (size_t)max_items * K, 256);
-  if (reduce == TSAMD_MIN || reduce == TSAMD_MAX)
-    off += align_up(sizeof(int64_t) * (size_t)max_items * K, 256);
+size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t K, int64_t E,
+             Workspace *ws) {
+  int64_t P, items;
+  plan_partition(M, E, &P, &items);
+  const bool minmax = reduce == TSAMD_MIN || reduce == TSAMD_MAX;
+  char *p = reinterpret_cast<char *>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) -> void * {
+    void *r = p ? p + off : nullptr;
+    off += align_up(bytes, 256);
+    return r;
+  };
+  const size_t plane = (size_t)B * P * K;
+  Workspace w;
+  w.P = P;
+  w.items = items;
+  w.table = reinterpret_cast<Coord *>(take(sizeof(Coord) * (P + 1)));
+  w.tail_row = reinterpret_cast<int64_t *>(take(sizeof(int64_t) * P));
+  w.head_val = take(acc_size(dtype) * plane);
+  w.tail_val = take(acc_size(dtype) * plane);
+  w.head_arg = reinterpret_cast<int64_t *>(minmax ? take(sizeof(int64_t) * plane) : nullptr);
+  w.tail_arg = reinterpret_cast<int64_t *>(minmax ? take(sizeof(int64_t) * plane) : nullptr);
+  if (ws) *ws = w;
   return off;
 }
 
@@ -365,28 +450,23 @@ template <typename T, int VEC, int RED>
 int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const T *mat,
                 T *out, int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K,
                 int64_t E, bool mean, Workspace ws, hipStream_t stream) {
-  const int64_t BM = B * M;
   const uint32_t slots = (uint32_t)((K + VEC - 1) / VEC);  // feature packets per row
   const uint32_t lpr = slots >= 64 ? 64u : (1u << ilog2_ceil(slots));
   const int lgG = 6 - ilog2_ceil(lpr);
   const uint32_t ktiles = (slots + 63) / 64;
+  const unsigned int threads = kWavesPerBlock * kWave;
 
-  TSAMD_HIP_TRY(hipMemsetAsync(ws.counters, 0, 2 * sizeof(unsigned int), stream));
-  {
-    dim3 grid((unsigned int)ceil_div(BM, kWavesPerBlock), ktiles, 1);
-    hipLaunchKernelGGL((spmm_rows_kernel<T, VEC, RED>), grid, dim3(kWavesPerBlock * kWave), 0,
-                       stream, rowptr, col, value, mat, out, arg_out, BM, M, N, (uint32_t)K, E,
-                       lgG, mean, ws);
-    TSAMD_LAUNCH_CHECK();
-  }
-  if (E > kLongRow) {  // a row can only be long if the matrix has that many entries
-    const unsigned int nblk = 2048;
-    hipLaunchKernelGGL((spmm_long_chunks_kernel<T, VEC, RED>), dim3(nblk),
-                       dim3(kWavesPerBlock * kWave), 0, stream, rowptr, col, value, mat, M, N,
-                       (uint32_t)K, lgG, ws);
-    TSAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL((spmm_long_merge_kernel<T, RED>), dim3(256), dim3(kWavesPerBlock * kWave),
-                       0, stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+  hipLaunchKernelGGL(spmm_partition_kernel, dim3((unsigned int)ceil_div(ws.P + 1, 256)), dim3(256),
+                     0, stream, rowptr, M, E, ws);
+  TSAMD_LAUNCH_CHECK();
+  const unsigned int gx = (unsigned int)ceil_div(ws.P, kWavesPerBlock);
+  hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                     dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N,
+                     (uint32_t)K, E, ktiles, lgG, mean, ws);
+  TSAMD_LAUNCH_CHECK();
+  if (ws.P > 1) {
+    hipLaunchKernelGGL((spmm_fixup_kernel<T, RED>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
+                       stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
     TSAMD_LAUNCH_CHECK();
   }
   return TSAMD_OK;
@@ -422,9 +502,8 @@ using namespace tsamd;
 
 extern "C" size_t tsamd_spmm_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M,
                                              int64_t K, int64_t E) {
-  (void)M;
-  if (dtype_size(dtype) == 0 || B < 0 || K < 0 || E < 0) return 0;
-  return workspace_bytes(dtype, reduce, B, K, E);
+  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || K < 0 || E < 0) return 0;
+  return carve(nullptr, dtype, reduce, B, M, K, E, nullptr);
 }
 
 extern "C" int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
@@ -435,17 +514,19 @@ extern "C" int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const in
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
-  if (N >= (int64_t)1 << 32 || K >= (int64_t)1 << 31) return TSAMD_ERR_UNSUPPORTED;
+  if (N >= (int64_t)1 << 32 || K >= (int64_t)1 << 31 || B >= 65536) return TSAMD_ERR_UNSUPPORTED;
   const bool minmax = reduce == TSAMD_MIN || reduce == TSAMD_MAX;
   if (B * M * K == 0) return TSAMD_OK;  // nothing to write
   if (!rowptr || !out || (E > 0 && (!col || !mat)) || (minmax && !arg_out))
     return TSAMD_ERR_INVALID;
-  const size_t need = workspace_bytes(dtype, reduce, B, K, E);
+  const size_t need = carve(nullptr, dtype, reduce, B, M, K, E, nullptr);
   if (!workspace || workspace_bytes_given < need) return TSAMD_ERR_WORKSPACE;
-  Workspace ws = carve_workspace(workspace, dtype, reduce, B, K, E);
+  if ((uintptr_t)workspace % 256 != 0) return TSAMD_ERR_WORKSPACE;
+  Workspace ws;
+  carve(workspace, dtype, reduce, B, M, K, E, &ws);
   const size_t es = dtype_size(dtype);
   const bool vec_ok = (K * es) % 16 == 0 && ((uintptr_t)mat % 16 == 0) &&
-                      ((uintptr_t)out % 16 == 0);
+                      ((uintptr_t)out % 16 == 0) && (!minmax || (uintptr_t)arg_out % 64 == 0);
 
   return TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
     return dispatch_spmm<scalar_t>(reduce, vec_ok, rowptr, col, value, mat, out, arg_out, B, M, N,
