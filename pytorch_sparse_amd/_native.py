@@ -47,8 +47,7 @@ def lib():
         L.tsamd_hip_version.restype = ctypes.c_int64
         L.tsamd_status_string.restype = ctypes.c_char_p
         L.tsamd_spmm_workspace_bytes.restype = ctypes.c_size_t
-        if hasattr(L, 'tsamd_spmm_minmax_bw_workspace_bytes'):
-            L.tsamd_spmm_minmax_bw_workspace_bytes.restype = ctypes.c_size_t
+        L.tsamd_spmm_minmax_bw_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 
@@ -121,6 +120,49 @@ def spmm(rowptr, col, value, mat, reduce):
                           ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
     check(st, 'tsamd_spmm')
     return out, arg
+
+
+def spmm_value_bw(row, rowptr, col, mat, grad, reduce):
+    """C-ABI ``tsamd_spmm_value_bw``: gradient w.r.t. the sparse values, [E]."""
+    require_gpu(rowptr, col, mat, grad, row)
+    red = REDUCES[reduce]
+    dt = dtype_code(mat.dtype)
+    mat, grad = mat.contiguous(), grad.contiguous()
+    if grad.dtype != mat.dtype:
+        raise TsamdError('expected scalar type %s but found %s' % (mat.dtype, grad.dtype))
+    M, E = rowptr.numel() - 1, col.numel()
+    N, K = mat.size(-2), mat.size(-1)
+    B = mat.numel() // (N * K) if N * K > 0 else 1
+    out = torch.empty(E, dtype=mat.dtype, device=mat.device)
+    with torch.cuda.device(mat.device):
+        st = lib().tsamd_spmm_value_bw(dt, red, _ptr(row), _ptr(rowptr), _ptr(col), _ptr(mat),
+                                       _ptr(grad), _ptr(out), _i64(B), _i64(M), _i64(N), _i64(K),
+                                       _i64(E), stream_ptr(mat.device))
+    check(st, 'tsamd_spmm_value_bw')
+    return out
+
+
+def spmm_minmax_bw(col, value, mat, grad_out, arg_out, want_value=True, want_mat=True):
+    """C-ABI ``tsamd_spmm_minmax_bw``: (grad_value or None, grad_mat or None)."""
+    require_gpu(col, value, mat, grad_out, arg_out)
+    dt = dtype_code(mat.dtype)
+    mat, grad_out, arg_out = mat.contiguous(), grad_out.contiguous(), arg_out.contiguous()
+    E = col.numel()
+    N, K = mat.size(-2), mat.size(-1)
+    M = grad_out.size(-2)
+    B = mat.numel() // (N * K) if N * K > 0 else 1
+    gv = torch.empty(E, dtype=mat.dtype, device=mat.device) if want_value else None
+    gm = torch.empty_like(mat) if want_mat else None
+    L = lib()
+    nb = L.tsamd_spmm_minmax_bw_workspace_bytes(dt, _i64(B), _i64(N), _i64(K), _i64(E))
+    ws = workspace(nb, mat.device)
+    with torch.cuda.device(mat.device):
+        st = L.tsamd_spmm_minmax_bw(dt, _ptr(col), _ptr(value), _ptr(mat), _ptr(grad_out),
+                                    _ptr(arg_out), _ptr(gv), _ptr(gm), _i64(B), _i64(M), _i64(N),
+                                    _i64(K), _i64(E), _ptr(ws), ctypes.c_size_t(ws.numel()),
+                                    stream_ptr(mat.device))
+    check(st, 'tsamd_spmm_minmax_bw')
+    return gv, gm
 
 
 def ind2ptr(ind, M):

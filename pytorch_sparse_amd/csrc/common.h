@@ -98,7 +98,12 @@ struct Traits<f16_t> {
   static constexpr bool kNarrow = true;
   __device__ static inline acc_t to_acc(f16_t x) { return (float)x; }
   __device__ static inline f16_t from_acc(acc_t a) { return (f16_t)a; }
-  __device__ static inline acc_t round_acc(acc_t a) { return (float)(f16_t)a; }
+  // The asm barrier keeps LLVM from folding `fptrunc(fmul a, b)` into
+  // v_fma_mixlo_f16(a, b, +0), which turns a -0.0 product into +0.0.
+  __device__ static inline acc_t round_acc(acc_t a) {
+    asm("" : "+v"(a));
+    return (float)(f16_t)a;
+  }
   __device__ static inline acc_t max_init() { return 65504.0f; }
   __device__ static inline acc_t lowest_init() { return -65504.0f; }
 };

@@ -1,0 +1,201 @@
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE ITSELF in this
+container (it cannot travel to the GPU box; the fixtures can).
+
+  part 1  spmm_*.npz            : torch.ops.ts_ref.spmm_{sum,mean,min,max}, i.e. the reference's
+                                  csrc/cpu/spmm_cpu.cpp compiled unmodified (oracle/build_ref.py)
+  part 2  py_*.npz              : the reference *Python* package imported from /root/reference
+                                  (coalesce / transpose / t() / SparseTensor ctor / spspmm /
+                                  legacy spmm / matmul fwd+bwd).  The package needs
+                                  `torch.ops.torch_sparse.*` and `torch_scatter`; a scratch copy
+                                  of the op library with the reference's own registration names is
+                                  built under $TMPDIR, and tests/golden/shims/torch_scatter stands
+                                  in for the pip dependency.  Runs in a subprocess so the
+                                  `torch_sparse::` names never meet the product's.
+
+Usage:  python tests/golden/make_golden.py          (needs /root/reference)
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get('TS_REFERENCE', '/root/reference')
+
+
+def tonp(t):
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16)
+    return t.numpy()
+
+
+def part1():
+    from oracle import ref
+    from pytorch_sparse_amd import synth
+    from tests.util import CODE
+    r = ref.ops()
+    n_written = 0
+    cases = [('rmat', 8, 6), ('uniform', 200, 700)]
+    for gname, a, b in cases:
+        if gname == 'rmat':
+            rp, c = synth.rmat_csr(a, b, seed=7)
+            n = m = 1 << a
+        else:
+            row, col = synth.uniform_edges(a, 300, b, seed=8)
+            rp, c = synth.to_csr(row, col, a, 300)
+            m, n = a, 300
+        E = c.numel()
+        for dtype in CODE:
+            for reduce in ('sum', 'mean', 'min', 'max'):
+                for has_value in (True, False):
+                    K = 5 if has_value else 8
+                    if dtype.is_floating_point:
+                        v = synth.values(E, dtype=dtype)
+                        x = synth.features(n, K, dtype=dtype, batch=(2, ) if has_value else ())
+                    else:
+                        g = torch.Generator().manual_seed(11)
+                        v = torch.randint(-4, 5, (E, ), dtype=dtype, generator=g)
+                        x = torch.randint(-9, 9, (n, K), dtype=dtype, generator=g)
+                    value = v if has_value else None
+                    if reduce == 'sum':
+                        out, arg = r.spmm_sum(None, rp, c, value, None, None, x), None
+                    elif reduce == 'mean':
+                        out, arg = r.spmm_mean(None, rp, c, value, None, None, None, x), None
+                    elif reduce == 'min':
+                        out, arg = r.spmm_min(rp, c, value, x)
+                    else:
+                        out, arg = r.spmm_max(rp, c, value, x)
+                    d = dict(dtype_code=CODE[dtype], reduce=reduce, rowptr=rp.numpy(), col=c.numpy(),
+                             mat=tonp(x), out=tonp(out))
+                    if has_value:
+                        d['value'] = tonp(v)
+                    if arg is not None:
+                        d['arg_out'] = arg.numpy()
+                    name = 'spmm_%s_%s_%s_%s.npz' % (gname, str(dtype).split('.')[1], reduce,
+                                                     'val' if has_value else 'noval')
+                    np.savez_compressed(os.path.join(HERE, name), **d)
+                    n_written += 1
+    print('part 1: wrote %d spmm fixtures' % n_written)
+
+
+PART2 = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ['TS_SCRATCH'])
+import torch_sparse
+from torch_sparse import SparseTensor, coalesce, transpose, spspmm, spmm
+from torch_sparse.matmul import matmul
+out_dir = os.environ['TS_OUT']
+torch.manual_seed(0)
+def save(name, **kw):
+    np.savez_compressed(os.path.join(out_dir, name), **{k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+
+# --- coalesce / transpose (functional API), values exactly representable so that the
+#     unspecified duplicate order of the reference's unstable sort cannot change the sums
+for seed, (m, n, nnz) in enumerate([(50, 40, 600), (1, 1, 5), (300, 7, 2000)]):
+    g = torch.Generator().manual_seed(seed)
+    index = torch.stack([torch.randint(0, m, (nnz,), generator=g), torch.randint(0, n, (nnz,), generator=g)])
+    for vname, value in (('i64', torch.randint(-8, 9, (nnz, 2), generator=g)),
+                         ('f32', torch.randint(-8, 9, (nnz,), generator=g).float() / 4)):
+        for op in ('add', 'mean', 'min', 'max'):
+            if op == 'mean' and vname == 'i64':
+                continue
+            oi, ov = coalesce(index, value, m, n, op=op)
+            save('py_coalesce_%d_%s_%s.npz' % (seed, vname, op), index=index, value=value, m=m, n=n, op=op, out_index=oi, out_value=ov)
+        ti, tv = transpose(index, value, m, n)
+        save('py_transpose_%d_%s.npz' % (seed, vname), index=index, value=value, m=m, n=n, out_index=ti, out_value=tv)
+    oi, ov = coalesce(index, None, m, n)
+    save('py_coalesce_%d_none.npz' % seed, index=index, m=m, n=n, out_index=oi)
+
+# --- SparseTensor ctor (sort) + caches + t()
+g = torch.Generator().manual_seed(10)
+m, n, nnz = 37, 53, 400
+key = torch.randperm(m * n, generator=g)[:nnz]
+row, col = key // n, key % n
+val = torch.randn(nnz, generator=g)
+A = SparseTensor(row=row, col=col, value=val, sparse_sizes=(m, n))
+r2, c2, v2 = A.coo()
+rowptr = A.storage.rowptr(); colptr = A.storage.colptr(); csr2csc = A.storage.csr2csc(); csc2csr = A.storage.csc2csr()
+At = A.t(); tr, tc, tv = At.coo()
+save('py_storage.npz', row=row, col=col, value=val, m=m, n=n, s_row=r2, s_col=c2, s_value=v2, rowptr=rowptr,
+     colptr=colptr, csr2csc=csr2csc, csc2csr=csc2csr, rowcount=A.storage.rowcount(), colcount=A.storage.colcount(),
+     t_row=tr, t_col=tc, t_value=tv)
+
+# --- SpSpMM (torch.sparse.mm behind the reference's spspmm), fp32 + fp64, with/without values
+for seed, (m, k, n, nA, nB) in enumerate([(40, 30, 50, 300, 250), (64, 64, 64, 500, 500), (5, 3, 4, 6, 5)]):
+    g = torch.Generator().manual_seed(20 + seed)
+    kA = torch.randperm(m * k, generator=g)[:nA].sort().values
+    kB = torch.randperm(k * n, generator=g)[:nB].sort().values
+    iA = torch.stack([kA // k, kA % k]); iB = torch.stack([kB // n, kB % n])
+    for dt in (torch.float32, torch.float64):
+        vA = torch.randint(-6, 7, (nA,), generator=g).to(dt) / 2
+        vB = torch.randint(-6, 7, (nB,), generator=g).to(dt) / 2
+        iC, vC = spspmm(iA, vA, iB, vB, m, k, n)
+        save('py_spspmm_%d_%s.npz' % (seed, str(dt).split('.')[1]), iA=iA, vA=vA, iB=iB, vB=vB, m=m, k=k, n=n, iC=iC, vC=vC)
+    C = matmul(SparseTensor(row=iA[0], col=iA[1], sparse_sizes=(m, k)), SparseTensor(row=iB[0], col=iB[1], sparse_sizes=(k, n)))
+    cr, cc, cv = C.coo()
+    assert cv is None
+    save('py_spspmm_%d_noval.npz' % seed, iA=iA, iB=iB, m=m, k=k, n=n, iC=torch.stack([cr, cc]))
+
+# --- legacy functional spmm (unsorted + duplicate indices allowed) and matmul fwd+bwd
+g = torch.Generator().manual_seed(30)
+m, n, nnz, F = 20, 25, 150, 6
+index = torch.stack([torch.randint(0, m, (nnz,), generator=g), torch.randint(0, n, (nnz,), generator=g)])
+value = torch.randn(nnz, generator=g); x = torch.randn(n, F, generator=g)
+save('py_legacy_spmm.npz', index=index, value=value, m=m, n=n, mat=x, out=spmm(index, value, m, n, x))
+for reduce in ('sum', 'mean', 'min', 'max'):
+    key = torch.randperm(m * n, generator=g)[:nnz].sort().values
+    row, col = key // n, key % n
+    value = torch.randn(nnz, generator=g, dtype=torch.float64).requires_grad_()
+    x = torch.randn(2, n, F, generator=g, dtype=torch.float64).requires_grad_()
+    gout = torch.randn(2, m, F, generator=g, dtype=torch.float64)
+    A = SparseTensor(row=row, col=col, value=value, sparse_sizes=(m, n))
+    out = matmul(A, x, reduce)
+    out.backward(gout)
+    save('py_matmul_%s.npz' % reduce, row=row, col=col, value=value.detach(), mat=x.detach(), grad_out=gout, m=m, n=n,
+         out=out.detach(), grad_value=value.grad, grad_mat=x.grad)
+print('part 2: reference python fixtures written')
+'''
+
+
+def part2():
+    """Import the reference Python from a scratch dir (symlinks + a loader __init__)."""
+    from torch.utils import cpp_extension as ce
+    scratch = tempfile.mkdtemp(prefix='ts_ref_py_')
+    pkg = os.path.join(scratch, 'torch_sparse')
+    os.makedirs(pkg)
+    refpkg = os.path.join(REF, 'torch_sparse')
+    keep = ['storage', 'tensor', 'utils', 'typing', 'matmul', 'coalesce', 'transpose', 'spmm', 'spspmm',
+            'testing']
+    for f in keep:
+        os.symlink(os.path.join(refpkg, f + '.py'), os.path.join(pkg, f + '.py'))
+    os.symlink(os.path.join(HERE, 'shims', 'torch_scatter'), os.path.join(scratch, 'torch_scatter'))
+    # the op library with the reference's own names, built straight from its sources
+    csrc = os.path.join(REF, 'csrc')
+    lib = os.path.join(pkg, '_ops_cpu.so')
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    inc = [csrc, os.path.join(ROOT, 'oracle', 'shim')] + ce.include_paths()
+    srcs = [os.path.join(csrc, s) for s in ('spmm.cpp', 'cpu/spmm_cpu.cpp', 'convert.cpp', 'cpu/convert_cpu.cpp')]
+    subprocess.check_call(['g++', '-O2', '-fopenmp', '-DAT_PARALLEL_OPENMP', '-Wno-sign-compare', '-std=c++17',
+                           '-fPIC', '-shared', '-D_GLIBCXX_USE_CXX11_ABI=%d' % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+                          + ['-I' + i for i in inc] + srcs +
+                          ['-o', lib, '-L' + tlib, '-ltorch', '-ltorch_cpu', '-lc10', '-Wl,-rpath,' + tlib])
+    with open(os.path.join(pkg, '__init__.py'), 'w') as f:
+        f.write("import os, torch\n"
+                "torch.ops.load_library(os.path.join(os.path.dirname(__file__), '_ops_cpu.so'))\n"
+                "from .storage import SparseStorage\nfrom .tensor import SparseTensor\n"
+                "from .transpose import t, transpose\nfrom .matmul import matmul\n"
+                "from .coalesce import coalesce\nfrom .spmm import spmm\nfrom .spspmm import spspmm\n")
+    env = dict(os.environ, TS_SCRATCH=scratch, TS_OUT=HERE, OMP_NUM_THREADS='1')
+    subprocess.check_call([sys.executable, '-c', PART2], env=env)
+
+
+if __name__ == '__main__':
+    if not os.path.isdir(REF):
+        sys.exit('reference tree %s not present' % REF)
+    part1()
+    part2()

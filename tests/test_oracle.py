@@ -1,0 +1,145 @@
+"""Pin the oracle: reference golden vectors, committed reference-generated fixtures, and (when
+built) the compiled reference itself.  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as oc
+from oracle import ref
+from pytorch_sparse_amd import synth
+from tests.util import ALL_DTYPES, CODE, fromnp, tonp
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_readme_spmm_vector():
+    # reference test/test_spmm.py:10-19 == README.md:225-238 (all six dtypes)
+    rowptr, col = [0, 2, 3, 5], [0, 2, 1, 0, 1]
+    val, x = [1, 2, 4, 1, 3], [[1, 4], [2, 5], [3, 6]]
+    for code in (oc.F32, oc.F64, oc.F16, oc.I32, oc.I64):
+        out, _ = oc.spmm(code, 'sum', rowptr, col, val, x)
+        assert out.tolist() == [[7, 16], [8, 20], [7, 19]]
+    out, _ = oc.spmm(oc.BF16, 'sum', rowptr, col, oc.f32_to_bf16_bits(np.float32(val)),
+                     oc.f32_to_bf16_bits(np.float32(x)))
+    assert oc.bf16_bits_to_f32(out).tolist() == [[7, 16], [8, 20], [7, 19]]
+
+
+def test_survey_pinned_semantics():
+    # SURVEY.md 8c, probed on the compiled reference: ties -> first edge, empty row -> 0 / arg=E
+    rp, c, x = [0, 3, 3, 5], [0, 1, 2, 0, 0], [[1, 5], [1, 7], [1, 7]]
+    out, arg = oc.spmm(oc.F32, 'max', rp, c, None, x)
+    assert out.tolist() == [[1, 7], [0, 0], [1, 5]] and arg.tolist() == [[0, 1], [5, 5], [3, 3]]
+    out, arg = oc.spmm(oc.F32, 'min', rp, c, None, x)
+    assert arg.tolist() == [[0, 0], [5, 5], [3, 3]]
+    out, _ = oc.spmm(oc.F32, 'mean', rp, c, None, x)
+    assert np.allclose(out, [[1, 6.3333335], [0, 0], [1, 5]], rtol=0, atol=1e-7)
+    # max with the reference's example values: out [[6,12],[8,20],[6,15]], arg [[1,1],[2,2],[4,4]]
+    out, arg = oc.spmm(oc.F32, 'max', [0, 2, 3, 5], [0, 2, 1, 0, 1], [1, 2, 4, 1, 3],
+                       [[1, 4], [2, 5], [3, 6]])
+    assert out.tolist() == [[6, 12], [8, 20], [6, 15]] and arg.tolist() == [[1, 1], [2, 2], [4, 4]]
+
+
+def test_nan_semantics():
+    # NaN in X: never wins a max/min (strict compare), propagates through sum
+    rp, c = [0, 3], [0, 1, 2]
+    x = np.array([[1.0], [np.nan], [3.0]], dtype=np.float32)
+    out, arg = oc.spmm(oc.F32, 'max', rp, c, None, x)
+    assert out.tolist() == [[3.0]] and arg.tolist() == [[2]]
+    out, _ = oc.spmm(oc.F32, 'sum', rp, c, None, x)
+    assert np.isnan(out).all()
+
+
+def test_narrow_accumulation_is_sequential():
+    # fp16 sum of 4096 U(0,1) accumulates in fp16 (!= exact); bf16 saturates at 256
+    rp, c = [0, 4096], np.zeros(4096, dtype=np.int64)
+    ones = np.ones((1, 1), dtype=np.float32)
+    out, _ = oc.spmm(oc.BF16, 'sum', rp, c, None, oc.f32_to_bf16_bits(ones))
+    assert oc.bf16_bits_to_f32(out).item() == 256.0
+    out, _ = oc.spmm(oc.BF16, 'sum', rp, c, None, oc.f32_to_bf16_bits(ones), wide_acc=True)
+    assert oc.bf16_bits_to_f32(out).item() == 4096.0
+
+
+def test_ind2ptr_ptr2ind_vectors():
+    # reference test/test_storage.py:10-24
+    assert oc.ind2ptr([2, 2, 4, 5, 5, 6], 8).tolist() == [0, 0, 0, 2, 2, 3, 5, 6, 6]
+    assert oc.ptr2ind([0, 0, 0, 2, 2, 3, 5, 6, 6], 6).tolist() == [2, 2, 4, 5, 5, 6]
+    assert oc.ind2ptr([], 4).tolist() == [0, 0, 0, 0, 0]
+    assert oc.ptr2ind([0, 0, 0], 0).tolist() == []
+
+
+@pytest.mark.skipif(not ref.available(), reason='oracle/_ref not built')
+@pytest.mark.parametrize('dtype', ALL_DTYPES)
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'min', 'max'])
+def test_c_oracle_matches_compiled_reference(dtype, reduce):
+    r = ref.ops()
+    rp, c = synth.rmat_csr(9, 8, seed=3)
+    E, n = c.numel(), 512
+    if dtype.is_floating_point:
+        v = synth.values(E, dtype=dtype)
+        x = synth.features(n, 7, dtype=dtype, batch=(2, ))
+    else:
+        g = torch.Generator().manual_seed(0)
+        v = torch.randint(-5, 5, (E, ), dtype=dtype, generator=g)
+        x = torch.randint(-9, 9, (2, n, 7), dtype=dtype, generator=g)
+    for value in (v, None):
+        if reduce == 'sum':
+            ro, ra = r.spmm_sum(None, rp, c, value, None, None, x), None
+        elif reduce == 'mean':
+            ro, ra = r.spmm_mean(None, rp, c, value, None, None, None, x), None
+        elif reduce == 'min':
+            ro, ra = r.spmm_min(rp, c, value, x)
+        else:
+            ro, ra = r.spmm_max(rp, c, value, x)
+        co, ca = oc.spmm(CODE[dtype], reduce, rp.numpy(), c.numpy(), tonp(value), tonp(x))
+        assert np.array_equal(tonp(ro), co)  # bit-exact, narrow types included
+        if ra is not None:
+            assert np.array_equal(ra.numpy(), ca)
+
+
+@pytest.mark.skipif(not ref.available(), reason='oracle/_ref not built')
+def test_c_oracle_convert_matches_compiled_reference():
+    r = ref.ops()
+    g = torch.Generator().manual_seed(1)
+    ind, _ = torch.sort(torch.randint(0, 300, (2000, ), generator=g))
+    ptr = r.ind2ptr(ind, 300)
+    assert np.array_equal(ptr.numpy(), oc.ind2ptr(ind.numpy(), 300))
+    assert np.array_equal(r.ptr2ind(ptr, 2000).numpy(), oc.ptr2ind(ptr.numpy(), 2000))
+
+
+@pytest.mark.skipif(not ref.available(), reason='oracle/_ref not built')
+@pytest.mark.parametrize('reduce', ['sum', 'mean'])
+def test_c_oracle_value_bw_matches_compiled_reference(reduce):
+    # the reference reaches spmm_value_bw only through autograd (csrc/spmm.cpp:96-98)
+    r = ref.ops()
+    rp, c = synth.rmat_csr(8, 6, seed=4)
+    E, n = c.numel(), 256
+    row = torch.from_numpy(oc.ptr2ind(rp.numpy(), E))
+    for dtype in (torch.float32, torch.float64):
+        v = synth.values(E, dtype=dtype).requires_grad_()
+        x = synth.features(n, 6, dtype=dtype, batch=(2, ))
+        gout = synth.features(n, 6, seed=3, dtype=dtype, batch=(2, ))
+        if reduce == 'sum':
+            out = r.spmm_sum(row, rp, c, v, None, None, x)
+        else:
+            out = r.spmm_mean(row, rp, c, v, None, None, None, x)
+        out.backward(gout)
+        got = oc.spmm_value_bw(CODE[dtype], reduce, row.numpy(), rp.numpy(), c.numpy(), tonp(x),
+                               tonp(gout))
+        assert np.array_equal(tonp(v.grad), got)
+
+
+def test_golden_fixtures():
+    """Fixtures written by tests/golden/make_golden.py from the reference's own code."""
+    files = sorted(glob.glob(os.path.join(GOLDEN, 'spmm_*.npz')))
+    assert files, 'no golden fixtures committed'
+    for f in files:
+        z = np.load(f)
+        code, reduce = int(z['dtype_code']), str(z['reduce'])
+        value = z['value'] if 'value' in z.files else None
+        out, arg = oc.spmm(code, reduce, z['rowptr'], z['col'], value, z['mat'])
+        assert np.array_equal(out, z['out']), f
+        if arg is not None:
+            assert np.array_equal(arg, z['arg_out']), f

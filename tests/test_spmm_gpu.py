@@ -1,0 +1,264 @@
+"""Parity of the HIP hot path against the oracle, through the C-ABI (pytorch_sparse_amd._native).
+All tests here need a real MI355X."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as oc
+from pytorch_sparse_amd import _native as nat
+from pytorch_sparse_amd import synth
+from tests.util import (ALL_DTYPES, CODE, FLOAT_DTYPES, SUM_ATOL, SUM_TOL, bits_equal, check_spmm, fromnp,
+                        oracle_spmm, tonp)
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def make_inputs(rp, c, n, K, dtype, has_value, batch=(), seed=0):
+    E = c.numel()
+    if dtype.is_floating_point:
+        v = synth.values(E, seed=seed + 1, dtype=dtype) - 0.3 if has_value else None
+        x = synth.features(n, K, seed=seed + 2, dtype=dtype, batch=batch)
+    else:
+        g = torch.Generator().manual_seed(seed)
+        v = torch.randint(-4, 5, (E, ), dtype=dtype, generator=g) if has_value else None
+        x = torch.randint(-9, 9, (*batch, n, K), dtype=dtype, generator=g)
+    return v, x
+
+
+def run_gpu(dev, rp, c, v, x, reduce):
+    out, arg = nat.spmm(rp.to(dev), c.to(dev), None if v is None else v.to(dev), x.to(dev), reduce)
+    torch.cuda.synchronize()
+    return out, arg
+
+
+@pytest.mark.parametrize('dtype', ALL_DTYPES)
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'min', 'max'])
+def test_spmm_rmat_all_dtypes(dev, dtype, reduce):
+    rp, c = synth.rmat_csr(10, 16, seed=0)  # max degree 354, 128-item partitions => cut rows
+    for K, has_value, batch in ((128, True, ()), (16, False, ()), (3, True, (2, )), (64, True, ())):
+        v, x = make_inputs(rp, c, 1 << 10, K, dtype, has_value, batch)
+        out, arg = run_gpu(dev, rp, c, v, x, reduce)
+        check_spmm(out, arg, rp, c, v, x, reduce)
+
+
+@pytest.mark.parametrize('K', [1, 2, 5, 32, 100, 256, 512, 1000])
+@pytest.mark.parametrize('reduce', ['sum', 'max'])
+def test_spmm_feature_widths(dev, K, reduce):
+    rp, c = synth.rmat_csr(11, 12, seed=1)
+    v, x = make_inputs(rp, c, 1 << 11, K, torch.float32, True)
+    out, arg = run_gpu(dev, rp, c, v, x, reduce)
+    check_spmm(out, arg, rp, c, v, x, reduce)
+
+
+def test_reference_test_shape(dev):
+    # test/test_matmul.py:18-25 of the reference: 10x8 with empty rows 2:4 / cols 2:4, other [2,8,2]
+    torch.manual_seed(0)
+    src = torch.randn(10, 8)
+    src[2:4, :] = 0
+    src[:, 2:4] = 0
+    row, col = src.nonzero().t()
+    val = src[row, col]
+    rp = torch.from_numpy(oc.ind2ptr(row.numpy(), 10))
+    for dtype in FLOAT_DTYPES:
+        other = torch.randn(2, 8, 2).to(dtype)
+        for reduce in ('sum', 'mean', 'min', 'max'):
+            out, arg = run_gpu(dev, rp, col, val.to(dtype), other, reduce)
+            assert out.shape == (2, 10, 2)
+            check_spmm(out, arg, rp, col, val.to(dtype), other, reduce)
+
+
+def test_empty_and_degenerate(dev):
+    # E == 0: every row empty -> zeros, arg == E == 0
+    rp = torch.zeros(6, dtype=torch.int64)
+    c = torch.zeros(0, dtype=torch.int64)
+    x = torch.randn(4, 8)
+    for reduce in ('sum', 'mean', 'min', 'max'):
+        out, arg = run_gpu(dev, rp, c, None, x, reduce)
+        assert out.shape == (5, 8) and (out == 0).all()
+        if arg is not None:
+            assert (arg == 0).all()
+    # M == 0
+    out, _ = run_gpu(dev, torch.zeros(1, dtype=torch.int64), c, None, x, 'sum')
+    assert out.shape == (0, 8)
+    # K == 0
+    out, _ = run_gpu(dev, rp, c, None, torch.randn(4, 0), 'sum')
+    assert out.shape == (5, 0)
+
+
+def test_single_hub_row_and_many_empty(dev):
+    # one row with 100k entries (cut into ~100+ partitions) between empty rows, plus a long tail
+    n = 5000
+    g = torch.Generator().manual_seed(3)
+    hub = torch.randint(0, n, (100000, ), generator=g)
+    deg = torch.zeros(3000, dtype=torch.int64)
+    deg[1234] = hub.numel()
+    deg[2000:2100] = 7
+    rp = torch.zeros(3001, dtype=torch.int64)
+    torch.cumsum(deg, 0, out=rp[1:])
+    c = torch.cat([hub, torch.randint(0, n, (700, ), generator=g)])
+    for dtype in (torch.float32, torch.bfloat16):
+        v, x = make_inputs(rp, c, n, 64, dtype, True)
+        for reduce in ('sum', 'mean', 'min', 'max'):
+            out, arg = run_gpu(dev, rp, c, v, x, reduce)
+            check_spmm(out, arg, rp, c, v, x, reduce)
+
+
+def test_ties_nan_and_no_winner(dev):
+    rp = torch.tensor([0, 3, 3, 5])
+    c = torch.tensor([0, 1, 2, 0, 0])
+    x = torch.tensor([[1., 5.], [1., 7.], [1., 7.]])
+    out, arg = run_gpu(dev, rp, c, None, x, 'max')
+    assert out.tolist() == [[1, 7], [0, 0], [1, 5]] and arg.tolist() == [[0, 1], [5, 5], [3, 3]]
+    out, arg = run_gpu(dev, rp, c, None, x, 'min')
+    assert arg.tolist() == [[0, 0], [5, 5], [3, 3]]
+    # many equal values across partitions / groups: the smallest edge id must win
+    E = 3000
+    rp = torch.tensor([0, E])
+    c = torch.zeros(E, dtype=torch.int64)
+    x = torch.full((1, 16), 2.5)
+    for reduce in ('min', 'max'):
+        out, arg = run_gpu(dev, rp, c, None, x, reduce)
+        assert (arg == 0).all() and (out == 2.5).all()
+    # NaN never wins, propagates through sum
+    x = torch.tensor([[1.0], [float('nan')], [3.0]])
+    out, arg = run_gpu(dev, torch.tensor([0, 3]), torch.tensor([0, 1, 2]), None, x, 'max')
+    assert out.item() == 3.0 and arg.item() == 2
+    out, _ = run_gpu(dev, torch.tensor([0, 3]), torch.tensor([0, 1, 2]), None, x, 'sum')
+    assert torch.isnan(out).all()
+    # a row of NaNs only: value stays at the reducer's init, arg reports E (documented divergence:
+    # the reference leaves a stale index there)
+    x = torch.full((2, 4), float('nan'))
+    out, arg = run_gpu(dev, torch.tensor([0, 2]), torch.tensor([0, 1]), None, x, 'max')
+    assert (arg == 2).all() and (out == torch.finfo(torch.float32).min).all()
+
+
+def test_golden_fixtures_on_gpu(dev):
+    files = sorted(glob.glob(os.path.join(GOLDEN, 'spmm_*.npz')))
+    assert files
+    inv = {v: k for k, v in CODE.items()}
+    for f in files:
+        z = np.load(f)
+        dtype, reduce = inv[int(z['dtype_code'])], str(z['reduce'])
+        rp, c = torch.from_numpy(z['rowptr']), torch.from_numpy(z['col'])
+        x = fromnp(z['mat'], dtype)
+        v = fromnp(z['value'], dtype) if 'value' in z.files else None
+        out, arg = run_gpu(dev, rp, c, v, x, reduce)
+        exact = reduce in ('min', 'max') or not dtype.is_floating_point
+        if exact:
+            assert bits_equal(out, fromnp(z['out'], dtype)), f
+            if arg is not None:
+                assert torch.equal(arg.cpu(), torch.from_numpy(z['arg_out'])), f
+        elif dtype in (torch.float32, torch.float64):
+            ref = fromnp(z['out'], dtype).double()
+            tol = 1e-5 if dtype == torch.float32 else 1e-12
+            assert torch.allclose(out.cpu().double(), ref, rtol=tol, atol=tol), f
+        else:  # narrow sum/mean: fp32 accumulation by design, checked against the wide oracle
+            check_spmm(out, arg, rp, c, v, x, reduce)
+
+
+@pytest.mark.parametrize('dtype', FLOAT_DTYPES)
+@pytest.mark.parametrize('reduce', ['sum', 'mean'])
+def test_value_bw(dev, dtype, reduce):
+    rp, c = synth.rmat_csr(10, 12, seed=5)
+    n, E = 1 << 10, c.numel()
+    row = torch.from_numpy(oc.ptr2ind(rp.numpy(), E))
+    for K, batch in ((128, ()), (20, (2, )), (3, ())):
+        x = synth.features(n, K, seed=2, dtype=dtype, batch=batch)
+        g = synth.features(n, K, seed=3, dtype=dtype, batch=batch)
+        for use_row in (True, False):
+            got = nat.spmm_value_bw(row.to(dev) if use_row else None, rp.to(dev), c.to(dev), x.to(dev),
+                                    g.to(dev), reduce)
+            exact = oc.spmm_value_bw(oc.F64, reduce, row.numpy(), rp.numpy(), c.numpy(),
+                                     x.double().numpy(), g.double().numpy())
+            l1 = oc.spmm_value_bw(oc.F64, reduce, row.numpy(), rp.numpy(), c.numpy(),
+                                  x.double().abs().numpy(), g.double().abs().numpy())
+            err = np.abs(got.cpu().double().numpy() - exact)
+            assert (err <= SUM_TOL[dtype] * l1 + SUM_ATOL[dtype]).all()
+
+
+@pytest.mark.parametrize('dtype', FLOAT_DTYPES)
+@pytest.mark.parametrize('reduce', ['min', 'max'])
+def test_minmax_bw(dev, dtype, reduce):
+    rp, c = synth.rmat_csr(9, 10, seed=6)
+    n, E = 1 << 9, c.numel()
+    for K, batch, has_value in ((16, (), True), (5, (2, ), True), (32, (), False)):
+        v, x = make_inputs(rp, c, n, K, dtype, has_value, batch)
+        gout = synth.features(n, K, seed=9, dtype=dtype, batch=batch)
+        out, arg = run_gpu(dev, rp, c, v, x, reduce)
+        gv, gm = nat.spmm_minmax_bw(c.to(dev), None if v is None else v.to(dev), x.to(dev),
+                                    gout.to(dev), arg, want_value=has_value, want_mat=True)
+        egv, egm = oc.spmm_minmax_bw(oc.F64, c.numpy(), None if v is None else v.double().numpy(),
+                                     x.double().numpy(), gout.double().numpy(), arg.cpu().numpy(),
+                                     want_value=has_value)
+        tol = {torch.float32: 1e-5, torch.float64: 1e-12, torch.float16: 4e-3,
+               torch.bfloat16: 3e-2}[dtype]
+        assert np.allclose(gm.cpu().double().numpy(), egm, rtol=tol, atol=tol)
+        if has_value:
+            scale = max(1.0, float(np.abs(egv).max()))
+            assert np.allclose(gv.cpu().double().numpy(), egv, rtol=tol, atol=tol * scale)
+
+
+def test_ind2ptr_ptr2ind(dev):
+    assert nat.ind2ptr(torch.tensor([2, 2, 4, 5, 5, 6], device=dev), 8).tolist() == \
+        [0, 0, 0, 2, 2, 3, 5, 6, 6]
+    assert nat.ptr2ind(torch.tensor([0, 0, 0, 2, 2, 3, 5, 6, 6], device=dev), 6).tolist() == \
+        [2, 2, 4, 5, 5, 6]
+    assert nat.ind2ptr(torch.zeros(0, dtype=torch.int64, device=dev), 4).tolist() == [0] * 5
+    rp, c = synth.rmat_csr(14, 20, seed=2)
+    row = nat.ptr2ind(rp.to(dev), c.numel())
+    assert np.array_equal(row.cpu().numpy(), oc.ptr2ind(rp.numpy(), c.numel()))
+    back = nat.ind2ptr(row, 1 << 14)
+    assert torch.equal(back.cpu(), rp)
+
+
+def test_determinism(dev):
+    rp, c = synth.rmat_csr(14, 20, seed=0, device=dev)
+    v = synth.values(c.numel(), device=dev)
+    x = synth.features(1 << 14, 128, device=dev)
+    a, _ = nat.spmm(rp, c, v, x, 'sum')
+    b, _ = nat.spmm(rp, c, v, x, 'sum')
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('config', ['c2', 'ns'])
+def test_full_size_properties(dev, config):
+    """BASELINE.json sizes: exact checks that do not need the (slow) oracle.
+    Small-integer inputs make every fp32 sum exact, so
+      * column checksum: sum_m out[m,:] == sum_c weight[c] * x[c,:]     (checksum of checksums)
+      * max: out == value[arg] * x[col[arg]] and arg lies in the row's edge range,
+        and a sampled set of rows is checked in full against the oracle."""
+    scale, K = (20, 64) if config == 'c2' else (21, 128)
+    n = 1 << scale
+    rp, c = synth.rmat_csr(scale, 20, seed=0, device=dev)
+    E = c.numel()
+    g = torch.Generator(device=dev).manual_seed(4)
+    v = torch.randint(1, 4, (E, ), generator=g, device=dev).float()
+    x = torch.randint(-4, 5, (n, K), generator=g, device=dev).float()
+    out, _ = nat.spmm(rp, c, v, x, 'sum')
+    w = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, c, v.double())
+    expect = (w[:, None] * x.double()).sum(0)
+    assert torch.equal(out.double().sum(0), expect)
+    # sampled rows (incl. the heaviest) against the oracle, bit-exact because sums are exact
+    deg = rp[1:] - rp[:-1]
+    rows = torch.cat([torch.topk(deg, 4).indices.cpu(), torch.randint(0, n, (60, ))]).unique()
+    rpc, cc, vc, xc = rp.cpu(), c.cpu(), v.cpu(), x.cpu()
+    for reduce in ('sum', 'max'):
+        o, a = nat.spmm(rp, c, v, x, reduce)
+        for r in rows.tolist():
+            s, e = int(rpc[r]), int(rpc[r + 1])
+            eo, ea = oracle_spmm(torch.tensor([0, e - s]), cc[s:e], vc[s:e], xc, reduce)
+            assert torch.equal(o[r].cpu(), eo[0]), (reduce, r)
+            if ea is not None:
+                ea = torch.where(ea == e - s, torch.full_like(ea, E), ea + s)
+                assert torch.equal(a[r].cpu(), ea[0]), (reduce, r)
+        if a is not None:
+            valid = a != E
+            assert torch.equal(valid.any(1), deg > 0)
+            ai = torch.where(valid, a, torch.zeros_like(a))
+            prod = v[ai] * x[c[ai], torch.arange(K, device=dev)[None, :]]
+            assert torch.equal(torch.where(valid, prod, torch.zeros_like(prod)), o)
+            assert ((ai >= rp[:-1, None]) & (ai < rp[1:, None]) | ~valid).all()

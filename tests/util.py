@@ -1,0 +1,77 @@
+"""Shared helpers for the parity tests: torch <-> oracle (numpy) plumbing and tolerances."""
+import numpy as np
+import torch
+
+from oracle import c_oracle as oc
+
+CODE = {torch.float32: oc.F32, torch.float64: oc.F64, torch.float16: oc.F16,
+        torch.bfloat16: oc.BF16, torch.int32: oc.I32, torch.int64: oc.I64}
+ALL_DTYPES = list(CODE)
+FLOAT_DTYPES = [torch.float32, torch.float64, torch.float16, torch.bfloat16]
+# |gpu - exact| <= TOL * sum_e |value_e * x_e|   (fp32: the 1e-5 rel bar of BASELINE.json;
+# narrow types: a few ulp of the once-rounded result)
+SUM_TOL = {torch.float32: 1e-5, torch.float64: 1e-13, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+# absolute floor: one fp16 subnormal step (results below 6e-5 cannot be relatively accurate)
+SUM_ATOL = {torch.float32: 1e-37, torch.float64: 1e-300, torch.float16: 6e-8, torch.bfloat16: 1e-37}
+
+
+def tonp(t):
+    if t is None:
+        return None
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16)
+    return t.numpy()
+
+
+def fromnp(a, dtype):
+    if dtype == torch.bfloat16:
+        return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+    return torch.from_numpy(a.copy())
+
+
+def bits_equal(a, b):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    if a.dtype in (torch.bfloat16, torch.float16):
+        return torch.equal(a.view(torch.int16), b.view(torch.int16))
+    if a.dtype == torch.float32:
+        return torch.equal(a.view(torch.int32), b.view(torch.int32))
+    if a.dtype == torch.float64:
+        return torch.equal(a.view(torch.int64), b.view(torch.int64))
+    return torch.equal(a, b)
+
+
+def oracle_spmm(rowptr, col, value, mat, reduce, wide_acc=False):
+    """C oracle on torch CPU tensors; returns torch tensors (out, arg)."""
+    o, a = oc.spmm(CODE[mat.dtype], reduce, tonp(rowptr), tonp(col), tonp(value), tonp(mat),
+                   wide_acc=wide_acc)
+    return fromnp(o, mat.dtype), (None if a is None else torch.from_numpy(a))
+
+
+def exact_sum_and_l1(rowptr, col, value, mat, reduce):
+    """fp64 result of sum/mean and the per-output L1 mass bound used for tolerances."""
+    rp, c = tonp(rowptr), tonp(col)
+    v64 = None if value is None else value.detach().cpu().double().numpy()
+    x64 = mat.detach().cpu().double().numpy()
+    ex, _ = oc.spmm(oc.F64, reduce, rp, c, v64, x64)
+    l1, _ = oc.spmm(oc.F64, reduce, rp, c, None if v64 is None else np.abs(v64), np.abs(x64))
+    return ex, l1
+
+
+def check_spmm(out, arg, rowptr, col, value, mat, reduce):
+    """Assert the GPU result (out, arg) against the oracle.  min/max and integer work are
+    bit-exact; floating sum/mean are bounded by SUM_TOL * L1 mass (fp32: 1e-5)."""
+    dtype = mat.dtype
+    rowptr, col = rowptr.cpu(), col.cpu()
+    value = None if value is None else value.cpu()
+    mat = mat.cpu()
+    if reduce in ('min', 'max') or not dtype.is_floating_point:
+        eo, ea = oracle_spmm(rowptr, col, value, mat, reduce)
+        assert bits_equal(out, eo), 'value mismatch (%s, %s)' % (dtype, reduce)
+        if ea is not None:
+            assert torch.equal(arg.cpu(), ea), 'arg_out mismatch (%s, %s)' % (dtype, reduce)
+    else:
+        ex, l1 = exact_sum_and_l1(rowptr, col, value, mat, reduce)
+        err = np.abs(out.detach().cpu().double().numpy() - ex)
+        bound = SUM_TOL[dtype] * l1 + SUM_ATOL[dtype]
+        assert (err <= bound).all(), 'max err/bound %.3g (%s, %s)' % ((err / bound).max(), dtype, reduce)
