@@ -85,6 +85,16 @@ int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
                int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
                void *workspace, size_t workspace_bytes, void *stream);
 
+/* Measurement aid (bench.py): same as tsamd_spmm, but brackets the three
+ * kernels of the launch sequence (merge-path partition, merge, carry fix-up)
+ * with hipEvents on `stream`, waits for the last one and writes their
+ * durations in milliseconds to kernel_ms_host[0..2] (host memory). */
+int tsamd_spmm_profiled(int dtype, int reduce, const int64_t *rowptr,
+                        const int64_t *col, const void *value, const void *mat,
+                        void *out, int64_t *arg_out, int64_t B, int64_t M, int64_t N,
+                        int64_t K, int64_t E, void *workspace, size_t workspace_bytes,
+                        void *stream, float *kernel_ms_host);
+
 /* ------------------------------------------------------------------------ *
  * Gradient of SUM/MEAN SpMM w.r.t. the sparse values (an SDDMM over the
  * pattern).  Replaces spmm_value_bw_cuda / spmm_value_bw_cpu

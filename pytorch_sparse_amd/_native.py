@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('TSAMD_LIB') or os.path.join(_HERE, 'lib', 'libtsamd.s
 # Every symbol include/tsamd.h declares (tests check that all of them resolve).
 SYMBOLS = [
     'tsamd_hip_version', 'tsamd_last_hip_error', 'tsamd_status_string',
-    'tsamd_spmm_workspace_bytes', 'tsamd_spmm',
+    'tsamd_spmm_workspace_bytes', 'tsamd_spmm', 'tsamd_spmm_profiled',
     'tsamd_spmm_value_bw',
     'tsamd_spmm_minmax_bw_workspace_bytes', 'tsamd_spmm_minmax_bw',
     'tsamd_ind2ptr', 'tsamd_ptr2ind',
@@ -92,8 +92,9 @@ def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def spmm(rowptr, col, value, mat, reduce):
-    """C-ABI ``tsamd_spmm``: returns (out, arg_out or None).  mat: [..., N, K] contiguous."""
+def spmm(rowptr, col, value, mat, reduce, out=None, profile=None):
+    """C-ABI ``tsamd_spmm``: returns (out, arg_out or None).  mat: [..., N, K] contiguous.
+    ``profile``: optional list; receives [partition_ms, merge_ms, fixup_ms] (synchronises)."""
     require_gpu(rowptr, col, value, mat)
     red = REDUCES[reduce]
     dt = dtype_code(mat.dtype)
@@ -107,7 +108,8 @@ def spmm(rowptr, col, value, mat, reduce):
     B = mat.numel() // max(N * K, 1) if N * K > 0 else 1
     sizes = list(mat.shape)
     sizes[-2] = M
-    out = torch.empty(sizes, dtype=mat.dtype, device=mat.device)
+    if out is None:
+        out = torch.empty(sizes, dtype=mat.dtype, device=mat.device)
     arg = None
     if red >= 2:
         arg = torch.empty(sizes, dtype=torch.int64, device=mat.device)
@@ -115,9 +117,15 @@ def spmm(rowptr, col, value, mat, reduce):
     nb = L.tsamd_spmm_workspace_bytes(dt, red, _i64(B), _i64(M), _i64(K), _i64(E))
     ws = workspace(nb, mat.device)
     with torch.cuda.device(mat.device):
-        st = L.tsamd_spmm(dt, red, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(out),
-                          _ptr(arg), _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
-                          ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
+        args = (dt, red, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(out), _ptr(arg),
+                _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws), ctypes.c_size_t(ws.numel()),
+                stream_ptr(mat.device))
+        if profile is None:
+            st = L.tsamd_spmm(*args)
+        else:
+            ms = (ctypes.c_float * 3)()
+            st = L.tsamd_spmm_profiled(*args, ms)
+            profile[:] = [float(ms[0]), float(ms[1]), float(ms[2])]
     check(st, 'tsamd_spmm')
     return out, arg
 

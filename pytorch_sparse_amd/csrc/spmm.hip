@@ -449,40 +449,45 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t K,
 template <typename T, int VEC, int RED>
 int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const T *mat,
                 T *out, int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K,
-                int64_t E, bool mean, Workspace ws, hipStream_t stream) {
+                int64_t E, bool mean, Workspace ws, hipStream_t stream, hipEvent_t *ev) {
   const uint32_t slots = (uint32_t)((K + VEC - 1) / VEC);  // feature packets per row
   const uint32_t lpr = slots >= 64 ? 64u : (1u << ilog2_ceil(slots));
   const int lgG = 6 - ilog2_ceil(lpr);
   const uint32_t ktiles = (slots + 63) / 64;
   const unsigned int threads = kWavesPerBlock * kWave;
 
+  if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[0], stream));
   hipLaunchKernelGGL(spmm_partition_kernel, dim3((unsigned int)ceil_div(ws.P + 1, 256)), dim3(256),
                      0, stream, rowptr, M, E, ws);
   TSAMD_LAUNCH_CHECK();
+  if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[1], stream));
   const unsigned int gx = (unsigned int)ceil_div(ws.P, kWavesPerBlock);
   hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED>), dim3(gx, (unsigned int)(B * ktiles), 1),
                      dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N,
                      (uint32_t)K, E, ktiles, lgG, mean, ws);
   TSAMD_LAUNCH_CHECK();
+  if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[2], stream));
   if (ws.P > 1) {
     hipLaunchKernelGGL((spmm_fixup_kernel<T, RED>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
                        stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
     TSAMD_LAUNCH_CHECK();
   }
+  if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[3], stream));
   return TSAMD_OK;
 }
 
 template <typename T>
 int dispatch_spmm(int reduce, bool vec_ok, const int64_t *rowptr, const int64_t *col,
                   const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
-                  int64_t M, int64_t N, int64_t K, int64_t E, Workspace ws, hipStream_t stream) {
+                  int64_t M, int64_t N, int64_t K, int64_t E, Workspace ws, hipStream_t stream,
+                  hipEvent_t *ev) {
   constexpr int kVec = 16 / (int)sizeof(T);
   const T *v = reinterpret_cast<const T *>(value);
   const T *x = reinterpret_cast<const T *>(mat);
   T *o = reinterpret_cast<T *>(out);
   const bool mean = reduce == TSAMD_MEAN;
 #define TSAMD_SPMM_GO(VEC, RED) \
-  return launch_spmm<T, VEC, RED>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream)
+  return launch_spmm<T, VEC, RED>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev)
   if (vec_ok) {
     if (reduce == TSAMD_MIN) TSAMD_SPMM_GO(kVec, RED_MIN);
     if (reduce == TSAMD_MAX) TSAMD_SPMM_GO(kVec, RED_MAX);
@@ -506,11 +511,10 @@ extern "C" size_t tsamd_spmm_workspace_bytes(int dtype, int reduce, int64_t B, i
   return carve(nullptr, dtype, reduce, B, M, K, E, nullptr);
 }
 
-extern "C" int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
-                          const void *value, const void *mat, void *out, int64_t *arg_out,
-                          int64_t B, int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
-                          size_t workspace_bytes_given, void *stream_) {
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
+                      const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
+                      int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
+                      size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev) {
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
@@ -530,6 +534,36 @@ extern "C" int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const in
 
   return TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
     return dispatch_spmm<scalar_t>(reduce, vec_ok, rowptr, col, value, mat, out, arg_out, B, M, N,
-                                   K, E, ws, stream);
+                                   K, E, ws, stream, ev);
   });
+}
+
+extern "C" int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
+                          const void *value, const void *mat, void *out, int64_t *arg_out,
+                          int64_t B, int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
+                          size_t workspace_bytes_given, void *stream_) {
+  return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, workspace,
+                    workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr);
+}
+
+extern "C" int tsamd_spmm_profiled(int dtype, int reduce, const int64_t *rowptr,
+                                   const int64_t *col, const void *value, const void *mat,
+                                   void *out, int64_t *arg_out, int64_t B, int64_t M, int64_t N,
+                                   int64_t K, int64_t E, void *workspace,
+                                   size_t workspace_bytes_given, void *stream_,
+                                   float *kernel_ms_host) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!kernel_ms_host) return TSAMD_ERR_INVALID;
+  hipEvent_t ev[4];
+  for (int i = 0; i < 4; ++i) TSAMD_HIP_TRY(hipEventCreate(&ev[i]));
+  kernel_ms_host[0] = kernel_ms_host[1] = kernel_ms_host[2] = 0.f;
+  int st = spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E,
+                      workspace, workspace_bytes_given, stream, ev);
+  if (st == TSAMD_OK && B * M * K > 0) {
+    TSAMD_HIP_TRY(hipEventSynchronize(ev[3]));
+    for (int i = 0; i < 3; ++i)
+      TSAMD_HIP_TRY(hipEventElapsedTime(&kernel_ms_host[i], ev[i], ev[i + 1]));
+  }
+  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+  return st;
 }

@@ -1,0 +1,76 @@
+"""Condense gpurun_out/<tag>/ (scripts/profile_round.sh) into profiles/<tag>_*.{md,csv,json}."""
+import csv, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+workload = sys.argv[2] if len(sys.argv) > 2 else 'ns'
+src = os.path.join(ROOT, 'gpurun_out', tag)
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+def short(n):
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'^void ', '', n)
+    return n.split('(')[0]
+
+# 1. kernel stats (all kernels, short names) -> csv
+rows = list(csv.DictReader(open(os.path.join(src, 'trace', 'bench_kernel_stats.csv'))))
+with open(os.path.join(dst, '%s_kernel_stats.csv' % tag), 'w') as f:
+    w = csv.writer(f)
+    w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'pct', 'min_ns', 'max_ns'])
+    for r in rows:
+        w.writerow([short(r['Name'])[:120], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+ts = {short(r['Name']): r for r in rows if 'tsamd' in r['Name']}
+
+# 2. PMC passes
+pmc = {}
+for C in ('FETCH_SIZE', 'WRITE_SIZE'):
+    p = os.path.join(src, 'pmc_%s' % C, 'pmc_counter_collection.csv')
+    if not os.path.exists(p):
+        continue
+    for r in csv.DictReader(open(p)):
+        k = short(r['Kernel_Name'])
+        pmc.setdefault(k, {}).setdefault(C, []).append(float(r['Counter_Value']))
+bench = None
+bj = os.path.join(src, 'bench.json')
+if os.path.exists(bj):
+    for line in open(bj):
+        if line.startswith('{'):
+            bench = json.loads(line)
+
+merge = [k for k in pmc if 'spmm_merge_kernel' in k]
+traffic = None
+lines = ['# %s profile summary (%s workload)' % (tag, workload), '',
+         'Source: `scripts/profile_round.sh %s` on one MI355X (gpurun); raw CSVs were under `gpurun_out/%s/`.' % (tag, tag), '',
+         '## rocprofv3 --kernel-trace --stats  (`python bench.py --steps 20 --no-cpu-baseline`)', '',
+         '| kernel | calls | avg us | total us | % of GPU time |', '|---|---|---|---|---|']
+for k, r in ts.items():
+    lines.append('| `%s` | %s | %.2f | %.1f | %s |' % (k, r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e3, r['Percentage']))
+lines += ['', '(the remaining GPU time of that run is ATen input generation: R-MAT sampling, sort/unique, randn)', '']
+lines += ['## PMC passes (separate runs, `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, 3 SpMM launches each)', '',
+          'Units: FETCH_SIZE / WRITE_SIZE are KiB at the L2<->fabric boundary (Infinity-Cache hits included).',
+          'gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of the bytes of 16 B/lane',
+          'reads, which is what the gather and the (col,value) stream use => fetch bytes = 2 * FETCH_SIZE * 1024.',
+          'WRITE_SIZE is uncalibrated on gfx950; it is reported as-is (x1024).', '',
+          '| kernel | FETCH_SIZE (KiB, avg) | corrected fetch bytes | WRITE_SIZE (KiB, avg) | write bytes |', '|---|---|---|---|---|']
+for k, d in pmc.items():
+    f_ = sum(d.get('FETCH_SIZE', [0])) / max(1, len(d.get('FETCH_SIZE', [0])))
+    w_ = sum(d.get('WRITE_SIZE', [0])) / max(1, len(d.get('WRITE_SIZE', [0])))
+    lines.append('| `%s` | %.0f | %.3e | %.0f | %.3e |' % (k, f_, 2 * f_ * 1024, w_, w_ * 1024))
+    if 'spmm_merge_kernel' in k:
+        traffic = dict(kernel=k, fetch_size_kib=f_, write_size_kib=w_, fetch_bytes_corrected=2 * f_ * 1024,
+                       write_bytes=w_ * 1024, hbm_bytes_per_launch=int(2 * f_ * 1024 + w_ * 1024),
+                       note='L2<->fabric bytes per launch; FETCH_SIZE doubled per the gfx950 correction, Infinity-Cache hits are included')
+if bench:
+    rf = bench['roofline']
+    lines += ['', '## bench.py line of the same box', '', '```', json.dumps(bench), '```', '',
+              'merge kernel: HIP-event average %.4f ms (bench.py) vs rocprofv3 average %.4f ms.' % (
+                  rf['kernel_ms'], float([r for k, r in ts.items() if 'spmm_merge' in k][0]['AverageNs']) / 1e6),
+              'algorithmic bytes per launch %.3e -> %.0f GB/s = %.1f %% of the 8 TB/s HBM peak.' % (
+                  rf['algorithmic_bytes_per_launch'], rf['achieved'], 100 * rf['frac'])]
+    if traffic:
+        lines.append('measured fabric traffic per launch %.3e B = %.0f %% of the algorithmic bytes (the rest is L2 reuse of hub columns).' % (
+            traffic['hbm_bytes_per_launch'], 100.0 * traffic['hbm_bytes_per_launch'] / rf['algorithmic_bytes_per_launch']))
+open(os.path.join(dst, '%s_summary.md' % tag), 'w').write('\n'.join(lines) + '\n')
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, 'traffic_%s.json' % workload), 'w'), indent=1)
+print('\n'.join(lines))
