@@ -144,6 +144,86 @@ int tsamd_ind2ptr(const int64_t *ind, int64_t M, int64_t E, int64_t *out,
 int tsamd_ptr2ind(const int64_t *ptr, int64_t M, int64_t E, int64_t *out,
                   void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * COO ordering / sorting / coalescing.  Replace the Python + ATen +
+ * torch_scatter compositions of SparseStorage (torch_sparse/storage.py):
+ *
+ *   tsamd_coo_order      the `(idx[1:] < idx[:-1]).any()` / `mask.all()` probes
+ *                        (storage.py:150-154, 431-441): counts_out[0] = number of
+ *                        positions where key decreases, counts_out[1] = number of
+ *                        adjacent duplicates, key = row * N + col.  counts_out is
+ *                        a DEVICE int64[2]; reading it is the caller's one sync.
+ *   tsamd_sort_coo       sort-on-construct (storage.py:149-162, utils.py:14-21):
+ *                        stable radix sort by row * N + col; writes the sorted
+ *                        row / col (either may be NULL) and the permutation.
+ *                        Called with (col, row, E, N, M, NULL, NULL, perm) it
+ *                        yields csr2csc (storage.py:407-416).
+ *   tsamd_coalesce_index adjacent-duplicate compaction of SORTED (row, col)
+ *                        (storage.py:436-447): unique pairs to row_out/col_out
+ *                        (capacity E), seg_ptr[j] = first input position of
+ *                        unique pair j, seg_ptr[nnz] = E (capacity E + 1),
+ *                        *nnz_out (device) = number of unique pairs.
+ *   tsamd_segment_reduce torch_scatter.segment_csr (storage.py:448-451):
+ *                        out[j, :] = REDUCE_{i in [seg_ptr[j], seg_ptr[j+1])}
+ *                        value[perm ? perm[i] : i, :], value is [*, D] row-major.
+ *                        MEAN on integer types floors, like torch_scatter.
+ * ------------------------------------------------------------------------ */
+int tsamd_coo_order(const int64_t *row, const int64_t *col, int64_t E, int64_t N,
+                    int64_t *counts_out, void *stream);
+size_t tsamd_sort_coo_workspace_bytes(int64_t E);
+int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
+                   int64_t N, int64_t *row_out, int64_t *col_out, int64_t *perm_out,
+                   void *workspace, size_t workspace_bytes, void *stream);
+size_t tsamd_coalesce_workspace_bytes(int64_t E);
+int tsamd_coalesce_index(const int64_t *row, const int64_t *col, int64_t E,
+                         int64_t *row_out, int64_t *col_out, int64_t *seg_ptr,
+                         int64_t *nnz_out, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int tsamd_segment_reduce(int dtype, int reduce, const void *value, const int64_t *perm,
+                         const int64_t *seg_ptr, int64_t nseg, int64_t D, void *out,
+                         void *stream);
+
+/* Device-wide exclusive scan of int64 (building block, exported for tests and hosts):
+ * out[i] = sum_{j<i} in[j]; in == out allowed; *total (device, nullable) = sum of all. */
+size_t tsamd_exclusive_scan_workspace_bytes(int64_t n);
+int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *total,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * SpSpMM  C = A * B  (CSR x CSR -> CSR, sum).  Replaces the torch.sparse.mm
+ * call behind spspmm_sum (torch_sparse/matmul.py:94-111) and therefore the
+ * functional spspmm (torch_sparse/spspmm.py:6-33).  Result contract = what the
+ * reference relies on (matmul.py:104-111): every row of C sorted by column,
+ * duplicates summed, explicit zeros kept.  fp32 / fp64 only (torch.sparse.mm
+ * rejects the other dtypes too).  The host allocates between the stages:
+ *
+ *   1. tsamd_spspmm_plan   prodptr[M+1] = exclusive scan of the per-row product
+ *        counts (prodptr[M] = P), bins[3*M] = row ids by size class
+ *        (small | medium | large, M slots each), stats (DEVICE int64[8]):
+ *        [0]=P  [1]=#small  [2]=#medium  [3]=#large  [4]=products in large rows.
+ *        --> host reads stats (sync), allocates colT[P], valT[P], nnzC[M].
+ *   2. tsamd_spspmm_rows   fills each row's slot colT/valT[prodptr[i] ...] with
+ *        its sorted, compressed entries and nnzC[i] with their number.
+ *        valA / valB may be NULL (all ones); valT may be NULL (structure only).
+ *   3. host: rowptrC = exclusive scan of nnzC (tsamd_exclusive_scan_i64),
+ *        rowC = tsamd_ptr2ind(rowptrC), allocates colC/valC[nnz(C)].
+ *   4. tsamd_spspmm_compact copies the slots to their final dense position.
+ * ------------------------------------------------------------------------ */
+size_t tsamd_spspmm_plan_workspace_bytes(int64_t M);
+int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
+                      int64_t M, int64_t *prodptr, int64_t *bins, int64_t *stats,
+                      void *workspace, size_t workspace_bytes, void *stream);
+size_t tsamd_spspmm_rows_workspace_bytes(int dtype, int64_t n_large, int64_t P_large);
+int tsamd_spspmm_rows(int dtype, const int64_t *rowptrA, const int64_t *colA, const void *valA,
+                      const int64_t *rowptrB, const int64_t *colB, const void *valB, int64_t M,
+                      int64_t N, const int64_t *prodptr, const int64_t *bins, int64_t n_small,
+                      int64_t n_medium, int64_t n_large, int64_t P_large, int64_t *colT,
+                      void *valT, int64_t *nnzC, void *workspace, size_t workspace_bytes,
+                      void *stream);
+int tsamd_spspmm_compact(int dtype, const int64_t *rowC, const int64_t *rowptrC,
+                         const int64_t *prodptr, const int64_t *colT, const void *valT,
+                         int64_t nnz, int64_t *colC, void *valC, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

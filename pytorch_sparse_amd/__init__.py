@@ -1,0 +1,52 @@
+"""pytorch_sparse_amd -- the sparse-matmul hot path of rusty1s/pytorch_sparse, built from scratch
+for AMD MI355X (gfx950).
+
+Drop-in surface (same names and argument meaning as ``torch_sparse``):
+
+    SparseStorage, SparseTensor, matmul, spmm, spspmm, coalesce, transpose, t
+    torch.ops.torch_sparse.{spmm_sum, spmm_mean, spmm_min, spmm_max, ind2ptr, ptr2ind, cuda_version}
+
+Everything computes in hand-written HIP kernels (``lib/libtsamd.so``, C-ABI in ``include/tsamd.h``)
+reached through the torch operator library ``lib/_tsamd_ops.so``.  There is no CPU compute path:
+importing without the built libraries, or calling with CPU tensors, raises.
+"""
+import os
+
+import torch
+
+__version__ = '0.1.0'
+
+_LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib')
+_OPS = os.path.join(_LIBDIR, '_tsamd_ops.so')
+_ops_loaded = False
+
+
+def load_ops():
+    """Load the torch operator library once (registers ``torch_sparse::*`` and ``tsamd::*``)."""
+    global _ops_loaded
+    if _ops_loaded:
+        return
+    if not os.path.exists(_OPS) or not os.path.exists(os.path.join(_LIBDIR, 'libtsamd.so')):
+        raise ImportError(
+            "pytorch_sparse_amd: native libraries not found in %s. Build them with "
+            "`python -m pytorch_sparse_amd.build` (hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback." % _LIBDIR)
+    torch.ops.load_library(_OPS)
+    _ops_loaded = True
+
+
+load_ops()
+hip_version = torch.ops.torch_sparse.cuda_version()
+
+from .storage import SparseStorage  # noqa: E402
+from .tensor import SparseTensor  # noqa: E402
+from .transpose import t, transpose  # noqa: E402
+from .matmul import matmul, spmm_sum, spmm_mean, spmm_min, spmm_max, spspmm_sum  # noqa: E402
+from .coalesce import coalesce  # noqa: E402
+from .spmm import spmm  # noqa: E402
+from .spspmm import spspmm  # noqa: E402
+
+__all__ = [
+    'SparseStorage', 'SparseTensor', 't', 'transpose', 'matmul', 'coalesce', 'spmm', 'spspmm',
+    '__version__',
+]

@@ -19,6 +19,11 @@ SYMBOLS = [
     'tsamd_spmm_value_bw',
     'tsamd_spmm_minmax_bw_workspace_bytes', 'tsamd_spmm_minmax_bw',
     'tsamd_ind2ptr', 'tsamd_ptr2ind',
+    'tsamd_coo_order', 'tsamd_sort_coo_workspace_bytes', 'tsamd_sort_coo',
+    'tsamd_coalesce_workspace_bytes', 'tsamd_coalesce_index', 'tsamd_segment_reduce',
+    'tsamd_exclusive_scan_workspace_bytes', 'tsamd_exclusive_scan_i64',
+    'tsamd_spspmm_plan_workspace_bytes', 'tsamd_spspmm_plan', 'tsamd_spspmm_rows_workspace_bytes',
+    'tsamd_spspmm_rows', 'tsamd_spspmm_compact',
 ]
 
 DTYPES = {

@@ -23,7 +23,8 @@ LIBDIR = os.path.join(PKG, 'lib')
 OBJDIR = os.path.join(ROOT, 'build', 'obj')
 ARCH = 'gfx950'
 
-HIP_SOURCES = ['api.hip', 'spmm.hip', 'spmm_bw.hip', 'convert.hip']
+HIP_SOURCES = ['api.hip', 'spmm.hip', 'spmm_bw.hip', 'convert.hip', 'scan.hip', 'sort.hip',
+               'coalesce.hip', 'spspmm.hip']
 OPS_SOURCES = ['torch_ops.cpp']
 
 

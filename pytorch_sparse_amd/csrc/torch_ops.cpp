@@ -1,0 +1,472 @@
+// torch operator boundary of the MI355X sparse-matmul hot path.
+//
+// Registers the reference's operator names with the reference's schemas
+// (csrc/spmm.cpp:344-348, csrc/convert.cpp:46-48, csrc/version.cpp:40-41 of
+// rusty1s/pytorch_sparse) on top of the C-ABI in include/tsamd.h:
+//
+//   torch_sparse::spmm_sum (Tensor? row, Tensor rowptr, Tensor col, Tensor? value,
+//                           Tensor? colptr, Tensor? csr2csc, Tensor mat) -> Tensor
+//   torch_sparse::spmm_mean(Tensor? row, Tensor rowptr, Tensor col, Tensor? value,
+//                           Tensor? rowcount, Tensor? colptr, Tensor? csr2csc, Tensor mat) -> Tensor
+//   torch_sparse::spmm_min / spmm_max(Tensor rowptr, Tensor col, Tensor? value, Tensor mat)
+//                                                                      -> (Tensor, Tensor)
+//   torch_sparse::ind2ptr(Tensor ind, int M) / ptr2ind(Tensor ptr, int E) -> Tensor
+//   torch_sparse::cuda_version() -> int
+//
+// Like the reference, autograd lives inside the op (torch::autograd::Function) and the
+// kernels run on the current stream without synchronising.  Unlike the reference there is
+// no CPU branch: tensors must live on the GPU, anything else raises.
+#include <ATen/hip/HIPContext.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/script.h>
+#include <torch/torch.h>
+
+#include "tsamd.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+using OptTensor = std::optional<Tensor>;
+
+int dtype_code(const Tensor &t) {
+  switch (t.scalar_type()) {
+    case at::kFloat: return TSAMD_F32;
+    case at::kDouble: return TSAMD_F64;
+    case at::kHalf: return TSAMD_F16;
+    case at::kBFloat16: return TSAMD_BF16;
+    case at::kInt: return TSAMD_I32;
+    case at::kLong: return TSAMD_I64;
+    default:
+      TORCH_CHECK(false, "pytorch_sparse_amd: unsupported dtype ", t.scalar_type(),
+                  " (supported: float32, float64, float16, bfloat16, int32, int64)");
+  }
+}
+
+void check_status(int st, const char *what) {
+  if (st == TSAMD_OK) return;
+  if (st == TSAMD_ERR_HIP)
+    TORCH_CHECK(false, what, " failed: HIP runtime error ", tsamd_last_hip_error());
+  TORCH_CHECK(false, what, " failed: ", tsamd_status_string(st));
+}
+
+void check_gpu(const Tensor &t, const char *name) {
+  TORCH_CHECK(t.device().is_cuda(), name,
+              " must be a GPU (HIP) tensor: pytorch_sparse_amd has no CPU implementation");
+}
+
+void *current_stream(const Tensor &t) {
+  return reinterpret_cast<void *>(c10::hip::getCurrentHIPStream(t.get_device()).stream());
+}
+
+Tensor workspace(size_t bytes, const Tensor &like) {
+  return torch::empty({(int64_t)(bytes > 256 ? bytes : 256)},
+                      like.options().dtype(torch::kUInt8).requires_grad(false));
+}
+
+const void *ptr_or_null(const OptTensor &t) { return t.has_value() ? t.value().data_ptr() : nullptr; }
+
+int reduce_code(const std::string &r) {
+  if (r == "sum" || r == "add") return TSAMD_SUM;
+  if (r == "mean") return TSAMD_MEAN;
+  if (r == "min") return TSAMD_MIN;
+  if (r == "max") return TSAMD_MAX;
+  TORCH_CHECK(false, "unknown reduce '", r, "'");
+}
+
+// Forward launch: mirrors the argument checks of spmm_cpu.cpp:12-24 / spmm_cuda.cu:96-109.
+std::tuple<Tensor, OptTensor> spmm_fw(const Tensor &rowptr, const Tensor &col,
+                                      const OptTensor &opt_value, Tensor mat,
+                                      const std::string &reduce) {
+  check_gpu(rowptr, "rowptr");
+  check_gpu(col, "col");
+  if (opt_value.has_value()) check_gpu(opt_value.value(), "value");
+  check_gpu(mat, "mat");
+  TORCH_CHECK(rowptr.dim() == 1 && col.dim() == 1, "Input mismatch");
+  TORCH_CHECK(rowptr.scalar_type() == at::kLong && col.scalar_type() == at::kLong,
+              "rowptr and col must be int64");
+  if (opt_value.has_value()) {
+    TORCH_CHECK(opt_value.value().dim() == 1, "Input mismatch");
+    TORCH_CHECK(opt_value.value().size(0) == col.size(0), "Input mismatch");
+    TORCH_CHECK(opt_value.value().scalar_type() == mat.scalar_type(), "expected scalar type ",
+                mat.scalar_type(), " but found ", opt_value.value().scalar_type());
+  }
+  TORCH_CHECK(mat.dim() >= 2, "Input mismatch");
+  c10::hip::HIPGuard guard(rowptr.get_device());
+
+  mat = mat.contiguous();
+  Tensor rp = rowptr.contiguous(), c = col.contiguous();
+  OptTensor value = opt_value.has_value() ? OptTensor(opt_value.value().contiguous()) : std::nullopt;
+  auto sizes = mat.sizes().vec();
+  const int64_t M = rp.numel() - 1, E = c.numel();
+  const int64_t N = mat.size(-2), K = mat.size(-1);
+  const int64_t B = (N * K) > 0 ? mat.numel() / (N * K) : 1;
+  sizes[mat.dim() - 2] = M;
+  Tensor out = torch::empty(sizes, mat.options().requires_grad(false));
+  const int red = reduce_code(reduce);
+  OptTensor arg_out = std::nullopt;
+  int64_t *arg_ptr = nullptr;
+  if (red == TSAMD_MIN || red == TSAMD_MAX) {
+    arg_out = torch::empty(sizes, rp.options());
+    arg_ptr = arg_out.value().data_ptr<int64_t>();
+  }
+  const int dt = dtype_code(mat);
+  const size_t need = tsamd_spmm_workspace_bytes(dt, red, B, M, K, E);
+  Tensor ws = workspace(need, mat);
+  check_status(tsamd_spmm(dt, red, rp.data_ptr<int64_t>(), c.data_ptr<int64_t>(),
+                          ptr_or_null(value), mat.data_ptr(), out.data_ptr(), arg_ptr, B, M, N, K,
+                          E, ws.data_ptr(), (size_t)ws.numel(), current_stream(mat)),
+               "tsamd_spmm");
+  return std::make_tuple(out, arg_out);
+}
+
+Tensor spmm_value_bw(const Tensor &row, const Tensor &rowptr, const Tensor &col, Tensor mat,
+                     Tensor grad, const std::string &reduce) {
+  check_gpu(rowptr, "rowptr");
+  check_gpu(mat, "mat");
+  check_gpu(grad, "grad");
+  c10::hip::HIPGuard guard(rowptr.get_device());
+  mat = mat.contiguous();
+  grad = grad.contiguous();
+  const int64_t M = grad.size(-2), N = mat.size(-2), K = mat.size(-1), E = col.numel();
+  const int64_t B = (N * K) > 0 ? mat.numel() / (N * K) : 1;
+  Tensor out = torch::empty({E}, grad.options().requires_grad(false));
+  check_status(tsamd_spmm_value_bw(dtype_code(mat), reduce_code(reduce), row.data_ptr<int64_t>(),
+                                   rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                                   mat.data_ptr(), grad.data_ptr(), out.data_ptr(), B, M, N, K, E,
+                                   current_stream(mat)),
+               "tsamd_spmm_value_bw");
+  return out;
+}
+
+bool needs_grad(const Tensor &t) { return torch::autograd::any_variable_requires_grad({t}); }
+
+// ---- sum / mean ---------------------------------------------------------------------------
+// One Function serves both: `mean` selects the divisor handling in both directions.
+// Saved tensors: row, rowptr, col, value, rowcount, colptr, csr2csc, mat.
+class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
+ public:
+  static variable_list forward(AutogradContext *ctx, OptTensor opt_row, Tensor rowptr, Tensor col,
+                               Tensor value, OptTensor opt_rowcount, OptTensor opt_colptr,
+                               OptTensor opt_csr2csc, Tensor mat, bool has_value, bool mean) {
+    if (has_value && needs_grad(value)) TORCH_CHECK(opt_row.has_value(), "Argument `row` is missing");
+    if (needs_grad(mat)) {
+      TORCH_CHECK(opt_row.has_value(), "Argument `row` is missing");
+      if (mean) TORCH_CHECK(opt_rowcount.has_value(), "Argument `rowcount` is missing");
+      TORCH_CHECK(opt_colptr.has_value(), "Argument `colptr` is missing");
+      TORCH_CHECK(opt_csr2csc.has_value(), "Argument `csr2csc` is missing");
+    }
+    OptTensor v = has_value ? OptTensor(value) : std::nullopt;
+    Tensor out = std::get<0>(spmm_fw(rowptr, col, v, mat, mean ? "mean" : "sum"));
+    ctx->saved_data["has_value"] = has_value;
+    ctx->saved_data["mean"] = mean;
+    // absent optionals are parked as `col` (any tensor will do; they are never read then)
+    ctx->save_for_backward({opt_row.value_or(col), rowptr, col, value, opt_rowcount.value_or(col),
+                            opt_colptr.value_or(col), opt_csr2csc.value_or(col), mat});
+    return {out};
+  }
+
+  static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+    const bool has_value = ctx->saved_data["has_value"].toBool();
+    const bool mean = ctx->saved_data["mean"].toBool();
+    Tensor grad_out = grad_outs[0];
+    auto s = ctx->get_saved_variables();
+    Tensor row = s[0], rowptr = s[1], col = s[2], value = s[3], rowcount = s[4], colptr = s[5],
+           csr2csc = s[6], mat = s[7];
+
+    Tensor grad_value, grad_mat;
+    if (has_value && needs_grad(value))
+      grad_value = spmm_value_bw(row, rowptr, col, mat, grad_out, mean ? "mean" : "sum");
+
+    if (needs_grad(mat)) {
+      // grad_mat = A^T * grad_out: the CSC arrays are the CSR of A^T; per-edge weights are
+      // value (sum) or value / max(deg(row), 1) (mean), both permuted into CSC order.
+      Tensor row_t = row.index_select(0, csr2csc);
+      OptTensor w = std::nullopt;
+      if (mean) {
+        Tensor cnt = rowcount.index_select(0, row_t).to(mat.scalar_type()).clamp_min_(1);
+        w = has_value ? value.detach().index_select(0, csr2csc).div_(cnt) : cnt.reciprocal_();
+      } else if (has_value) {
+        w = value.detach().index_select(0, csr2csc);
+      }
+      grad_mat = std::get<0>(spmm_fw(colptr, row_t, w, grad_out, "sum"));
+    }
+    return {Tensor(), Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_mat,
+            Tensor(), Tensor()};
+  }
+};
+
+// ---- min / max ----------------------------------------------------------------------------
+class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> {
+ public:
+  static variable_list forward(AutogradContext *ctx, Tensor rowptr, Tensor col, Tensor value,
+                               Tensor mat, bool has_value, bool is_max) {
+    OptTensor v = has_value ? OptTensor(value) : std::nullopt;
+    auto res = spmm_fw(rowptr, col, v, mat, is_max ? "max" : "min");
+    Tensor out = std::get<0>(res), arg_out = std::get<1>(res).value();
+    ctx->saved_data["has_value"] = has_value;
+    ctx->save_for_backward({col, value, mat, arg_out});
+    ctx->mark_non_differentiable({arg_out});
+    return {out, arg_out};
+  }
+
+  static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+    const bool has_value = ctx->saved_data["has_value"].toBool();
+    Tensor grad_out = grad_outs[0].contiguous();
+    auto s = ctx->get_saved_variables();
+    Tensor col = s[0], value = s[1], mat = s[2].contiguous(), arg_out = s[3];
+    const bool want_value = has_value && needs_grad(value);
+    const bool want_mat = needs_grad(mat);
+    Tensor grad_value, grad_mat;
+    if (want_value || want_mat) {
+      c10::hip::HIPGuard guard(mat.get_device());
+      const int64_t N = mat.size(-2), K = mat.size(-1), M = grad_out.size(-2), E = col.numel();
+      const int64_t B = (N * K) > 0 ? mat.numel() / (N * K) : 1;
+      if (want_value) grad_value = torch::empty({E}, mat.options().requires_grad(false));
+      if (want_mat) grad_mat = torch::empty_like(mat, mat.options().requires_grad(false));
+      const int dt = dtype_code(mat);
+      Tensor ws = workspace(tsamd_spmm_minmax_bw_workspace_bytes(dt, B, N, K, E), mat);
+      check_status(
+          tsamd_spmm_minmax_bw(dt, col.data_ptr<int64_t>(), has_value ? value.data_ptr() : nullptr,
+                               mat.data_ptr(), grad_out.data_ptr(), arg_out.data_ptr<int64_t>(),
+                               want_value ? grad_value.data_ptr() : nullptr,
+                               want_mat ? grad_mat.data_ptr() : nullptr, B, M, N, K, E,
+                               ws.data_ptr(), (size_t)ws.numel(), current_stream(mat)),
+          "tsamd_spmm_minmax_bw");
+    }
+    return {Tensor(), Tensor(), grad_value, grad_mat, Tensor(), Tensor()};
+  }
+};
+
+// ---- registered entry points (reference signatures) -----------------------------------------
+Tensor spmm_sum(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_value,
+                OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat) {
+  Tensor value = opt_value.value_or(col);
+  return SpmmAddFunction::apply(opt_row, rowptr, col, value, std::nullopt, opt_colptr, opt_csr2csc,
+                                mat, opt_value.has_value(), false)[0];
+}
+
+Tensor spmm_mean(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_value,
+                 OptTensor opt_rowcount, OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat) {
+  Tensor value = opt_value.value_or(col);
+  return SpmmAddFunction::apply(opt_row, rowptr, col, value, opt_rowcount, opt_colptr, opt_csr2csc,
+                                mat, opt_value.has_value(), true)[0];
+}
+
+std::tuple<Tensor, Tensor> spmm_min(Tensor rowptr, Tensor col, OptTensor opt_value, Tensor mat) {
+  auto r = SpmmMinMaxFunction::apply(rowptr, col, opt_value.value_or(col), mat,
+                                     opt_value.has_value(), false);
+  return std::make_tuple(r[0], r[1]);
+}
+
+std::tuple<Tensor, Tensor> spmm_max(Tensor rowptr, Tensor col, OptTensor opt_value, Tensor mat) {
+  auto r = SpmmMinMaxFunction::apply(rowptr, col, opt_value.value_or(col), mat,
+                                     opt_value.has_value(), true);
+  return std::make_tuple(r[0], r[1]);
+}
+
+Tensor ind2ptr(Tensor ind, int64_t M) {
+  check_gpu(ind, "ind");
+  TORCH_CHECK(ind.scalar_type() == at::kLong, "ind must be int64");
+  c10::hip::HIPGuard guard(ind.get_device());
+  ind = ind.contiguous();
+  Tensor out = torch::empty({M + 1}, ind.options());
+  check_status(tsamd_ind2ptr(ind.data_ptr<int64_t>(), M, ind.numel(), out.data_ptr<int64_t>(),
+                             current_stream(ind)),
+               "tsamd_ind2ptr");
+  return out;
+}
+
+Tensor ptr2ind(Tensor ptr, int64_t E) {
+  check_gpu(ptr, "ptr");
+  TORCH_CHECK(ptr.scalar_type() == at::kLong, "ptr must be int64");
+  c10::hip::HIPGuard guard(ptr.get_device());
+  ptr = ptr.contiguous();
+  Tensor out = torch::empty({E}, ptr.options());
+  check_status(tsamd_ptr2ind(ptr.data_ptr<int64_t>(), ptr.numel() - 1, E, out.data_ptr<int64_t>(),
+                             current_stream(ptr)),
+               "tsamd_ptr2ind");
+  return out;
+}
+
+int64_t cuda_version() { return tsamd_hip_version(); }
+
+// ---- fused storage ops (no reference op of the same name: they replace Python/ATen
+//      compositions of torch_sparse/storage.py, see include/tsamd.h) --------------------------
+void check_index(const Tensor &t, const char *name) {
+  check_gpu(t, name);
+  TORCH_CHECK(t.scalar_type() == at::kLong && t.dim() == 1, name, " must be a 1-D int64 tensor");
+}
+
+// -> int64[2] on the device: {#descents, #adjacent duplicates} of key = row * N + col
+Tensor coo_order(Tensor row, Tensor col, int64_t N) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  Tensor counts = torch::empty({2}, row.options());
+  check_status(tsamd_coo_order(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), row.numel(), N,
+                               counts.data_ptr<int64_t>(), current_stream(row)),
+               "tsamd_coo_order");
+  return counts;
+}
+
+// stable sort by row * N + col -> (row_sorted, col_sorted, perm); with index=false only perm
+std::tuple<Tensor, Tensor, Tensor> sort_coo(Tensor row, Tensor col, int64_t M, int64_t N,
+                                            bool index) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  Tensor perm = torch::empty({E}, row.options());
+  Tensor row_s = index ? torch::empty({E}, row.options()) : torch::empty({0}, row.options());
+  Tensor col_s = index ? torch::empty({E}, row.options()) : torch::empty({0}, row.options());
+  Tensor ws = workspace(tsamd_sort_coo_workspace_bytes(E), row);
+  check_status(tsamd_sort_coo(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N,
+                              index ? row_s.data_ptr<int64_t>() : nullptr,
+                              index ? col_s.data_ptr<int64_t>() : nullptr, perm.data_ptr<int64_t>(),
+                              ws.data_ptr(), (size_t)ws.numel(), current_stream(row)),
+               "tsamd_sort_coo");
+  return std::make_tuple(row_s, col_s, perm);
+}
+
+// sorted (row, col) -> (row_u[E], col_u[E], seg_ptr[E+1], nnz[1]); only the first nnz (+1)
+// entries are meaningful, nnz lives on the device.
+std::tuple<Tensor, Tensor, Tensor, Tensor> coalesce_index(Tensor row, Tensor col) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  Tensor row_u = torch::empty({E}, row.options()), col_u = torch::empty({E}, row.options());
+  Tensor seg = torch::empty({E + 1}, row.options()), nnz = torch::empty({1}, row.options());
+  Tensor ws = workspace(tsamd_coalesce_workspace_bytes(E), row);
+  check_status(tsamd_coalesce_index(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E,
+                                    row_u.data_ptr<int64_t>(), col_u.data_ptr<int64_t>(),
+                                    seg.data_ptr<int64_t>(), nnz.data_ptr<int64_t>(), ws.data_ptr(),
+                                    (size_t)ws.numel(), current_stream(row)),
+               "tsamd_coalesce_index");
+  return std::make_tuple(row_u, col_u, seg, nnz);
+}
+
+// out[j] = REDUCE_{i in [seg_ptr[j], seg_ptr[j+1])} value[perm ? perm[i] : i]   (dim 0)
+Tensor segment_reduce(Tensor value, OptTensor perm, Tensor seg_ptr, int64_t nseg,
+                      std::string reduce) {
+  check_gpu(value, "value");
+  check_index(seg_ptr, "seg_ptr");
+  if (perm.has_value()) check_index(perm.value(), "perm");
+  TORCH_CHECK(value.dim() >= 1, "value must have at least one dimension");
+  c10::hip::HIPGuard guard(value.get_device());
+  value = value.contiguous();
+  seg_ptr = seg_ptr.contiguous();
+  auto sizes = value.sizes().vec();
+  const int64_t D = value.size(0) > 0 ? value.numel() / value.size(0) : 1;
+  sizes[0] = nseg;
+  Tensor out = torch::empty(sizes, value.options().requires_grad(false));
+  Tensor p = perm.has_value() ? perm.value().contiguous() : Tensor();
+  check_status(tsamd_segment_reduce(dtype_code(value), reduce_code(reduce), value.data_ptr(),
+                                    perm.has_value() ? p.data_ptr<int64_t>() : nullptr,
+                                    seg_ptr.data_ptr<int64_t>(), nseg, D, out.data_ptr(),
+                                    current_stream(value)),
+               "tsamd_segment_reduce");
+  return out;
+}
+
+// C = A * B on CSR operands -> (rowptrC, colC, valueC); valueC is empty unless with_value.
+// Two host syncs (product count, nnz(C)) because the output size is data dependent.
+std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor valA,
+                                          Tensor rowptrB, Tensor colB, OptTensor valB, int64_t N,
+                                          bool with_value) {
+  check_index(rowptrA, "rowptrA");
+  check_index(colA, "colA");
+  check_index(rowptrB, "rowptrB");
+  check_index(colB, "colB");
+  c10::hip::HIPGuard guard(rowptrA.get_device());
+  rowptrA = rowptrA.contiguous();
+  colA = colA.contiguous();
+  rowptrB = rowptrB.contiguous();
+  colB = colB.contiguous();
+  auto vdtype = valA.has_value() ? valA.value().scalar_type()
+                                 : (valB.has_value() ? valB.value().scalar_type() : at::kFloat);
+  TORCH_CHECK(vdtype == at::kFloat || vdtype == at::kDouble,
+              "spspmm: only float32 and float64 values are supported (got ", vdtype, ")");
+  if (valA.has_value() && valB.has_value())
+    TORCH_CHECK(valA.value().scalar_type() == valB.value().scalar_type(), "spspmm: dtype mismatch");
+  Tensor va = valA.has_value() ? valA.value().contiguous() : Tensor();
+  Tensor vb = valB.has_value() ? valB.value().contiguous() : Tensor();
+  const int dt = vdtype == at::kFloat ? TSAMD_F32 : TSAMD_F64;
+  const int64_t M = rowptrA.numel() - 1;
+  TORCH_CHECK(rowptrB.numel() - 1 >= 0 && M >= 0, "spspmm: bad rowptr");
+  auto iopt = rowptrA.options();
+  auto vopt = iopt.dtype(vdtype);
+  void *stream = current_stream(rowptrA);
+
+  Tensor prodptr = torch::empty({M + 1}, iopt), bins = torch::empty({3 * M + 1}, iopt);
+  Tensor stats = torch::empty({8}, iopt);
+  Tensor ws0 = workspace(tsamd_spspmm_plan_workspace_bytes(M), rowptrA);
+  check_status(tsamd_spspmm_plan(rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
+                                 rowptrB.data_ptr<int64_t>(), M, prodptr.data_ptr<int64_t>(),
+                                 bins.data_ptr<int64_t>(), stats.data_ptr<int64_t>(), ws0.data_ptr(),
+                                 (size_t)ws0.numel(), stream),
+               "tsamd_spspmm_plan");
+  Tensor h = stats.cpu();  // sync 1
+  const int64_t *hs = h.data_ptr<int64_t>();
+  const int64_t P = hs[0], n_small = hs[1], n_medium = hs[2], n_large = hs[3], P_large = hs[4];
+
+  Tensor colT = torch::empty({P}, iopt);
+  Tensor valT = with_value ? torch::empty({P}, vopt) : Tensor();
+  Tensor rowptrC = torch::zeros({M + 1}, iopt);  // nnzC in [0, M), scanned in place below
+  Tensor ws1 = workspace(tsamd_spspmm_rows_workspace_bytes(dt, n_large, P_large), rowptrA);
+  check_status(
+      tsamd_spspmm_rows(dt, rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
+                        valA.has_value() ? va.data_ptr() : nullptr, rowptrB.data_ptr<int64_t>(),
+                        colB.data_ptr<int64_t>(), valB.has_value() ? vb.data_ptr() : nullptr, M, N,
+                        prodptr.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_small, n_medium,
+                        n_large, P_large, colT.data_ptr<int64_t>(),
+                        with_value ? valT.data_ptr() : nullptr, rowptrC.data_ptr<int64_t>(),
+                        ws1.data_ptr(), (size_t)ws1.numel(), stream),
+      "tsamd_spspmm_rows");
+  Tensor total = torch::empty({1}, iopt);
+  Tensor ws2 = workspace(tsamd_exclusive_scan_workspace_bytes(M + 1), rowptrA);
+  check_status(tsamd_exclusive_scan_i64(rowptrC.data_ptr<int64_t>(), rowptrC.data_ptr<int64_t>(),
+                                        M + 1, total.data_ptr<int64_t>(), ws2.data_ptr(),
+                                        (size_t)ws2.numel(), stream),
+               "tsamd_exclusive_scan_i64");
+  const int64_t nnz = total.item<int64_t>();  // sync 2
+  Tensor rowC = torch::empty({nnz}, iopt), colC = torch::empty({nnz}, iopt);
+  Tensor valC = with_value ? torch::empty({nnz}, vopt) : torch::empty({0}, vopt);
+  check_status(tsamd_ptr2ind(rowptrC.data_ptr<int64_t>(), M, nnz, rowC.data_ptr<int64_t>(), stream),
+               "tsamd_ptr2ind");
+  check_status(tsamd_spspmm_compact(dt, rowC.data_ptr<int64_t>(), rowptrC.data_ptr<int64_t>(),
+                                    prodptr.data_ptr<int64_t>(), colT.data_ptr<int64_t>(),
+                                    with_value ? valT.data_ptr() : nullptr, nnz,
+                                    colC.data_ptr<int64_t>(), with_value ? valC.data_ptr() : nullptr,
+                                    stream),
+               "tsamd_spspmm_compact");
+  return std::make_tuple(rowptrC, colC, valC);
+}
+
+}  // namespace
+
+static auto registry = torch::RegisterOperators()
+                           .op("torch_sparse::spmm_sum", &spmm_sum)
+                           .op("torch_sparse::spmm_mean", &spmm_mean)
+                           .op("torch_sparse::spmm_min", &spmm_min)
+                           .op("torch_sparse::spmm_max", &spmm_max)
+                           .op("torch_sparse::ind2ptr", &ind2ptr)
+                           .op("torch_sparse::ptr2ind", &ptr2ind)
+                           .op("torch_sparse::cuda_version", &cuda_version)
+                           .op("tsamd::coo_order", &coo_order)
+                           .op("tsamd::sort_coo", &sort_coo)
+                           .op("tsamd::coalesce_index", &coalesce_index)
+                           .op("tsamd::segment_reduce", &segment_reduce)
+                           .op("tsamd::spspmm", &spspmm);

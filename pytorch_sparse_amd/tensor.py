@@ -1,0 +1,408 @@
+"""SparseTensor: the object API over SparseStorage (reference: torch_sparse/tensor.py).
+
+Covers construction, format views (coo/csr/csc), caches, dtype/device plumbing, dense and
+torch.sparse conversions, and -- patched in by the sibling modules -- ``matmul/spmm/spspmm/@``,
+``t()`` and ``coalesce()``.  Indexing, slicing, concatenation, diagonal edits, samplers and
+partitioners of the reference are outside this package's scope and raise
+``NotImplementedError``.
+"""
+from typing import Any, List, Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from .storage import SparseStorage, get_layout
+
+
+class SparseTensor(object):
+    storage: SparseStorage
+
+    def __init__(self, row: Optional[Tensor] = None, rowptr: Optional[Tensor] = None,
+                 col: Optional[Tensor] = None, value: Optional[Tensor] = None,
+                 sparse_sizes: Optional[Tuple[Optional[int], Optional[int]]] = None,
+                 is_sorted: bool = False, trust_data: bool = False):
+        self.storage = SparseStorage(row=row, rowptr=rowptr, col=col, value=value,
+                                     sparse_sizes=sparse_sizes, is_sorted=is_sorted,
+                                     trust_data=trust_data)
+
+    # ---- constructors ------------------------------------------------------------------------
+    @classmethod
+    def from_storage(cls, storage: SparseStorage):
+        out = cls.__new__(cls)
+        out.storage = storage
+        return out
+
+    @classmethod
+    def from_edge_index(cls, edge_index: Tensor, edge_attr: Optional[Tensor] = None,
+                        sparse_sizes: Optional[Tuple[Optional[int], Optional[int]]] = None,
+                        is_sorted: bool = False, trust_data: bool = False):
+        return cls(row=edge_index[0], col=edge_index[1], value=edge_attr, sparse_sizes=sparse_sizes,
+                   is_sorted=is_sorted, trust_data=trust_data)
+
+    @classmethod
+    def from_dense(cls, mat: Tensor, has_value: bool = True):
+        if mat.dim() > 2:
+            index = mat.abs().sum([i for i in range(2, mat.dim())]).nonzero()
+        else:
+            index = mat.nonzero()
+        index = index.t()
+        row, col = index[0], index[1]
+        value = mat[row, col] if has_value else None
+        return cls(row=row, col=col, value=value, sparse_sizes=(mat.size(0), mat.size(1)),
+                   is_sorted=True, trust_data=True)
+
+    @classmethod
+    def from_torch_sparse_coo_tensor(cls, mat: Tensor, has_value: bool = True):
+        mat = mat.coalesce()
+        index = mat._indices()
+        value = mat._values() if has_value else None
+        return cls(row=index[0], col=index[1], value=value,
+                   sparse_sizes=(mat.size(0), mat.size(1)), is_sorted=True, trust_data=True)
+
+    @classmethod
+    def from_torch_sparse_csr_tensor(cls, mat: Tensor, has_value: bool = True):
+        value = mat.values() if has_value else None
+        return cls(rowptr=mat.crow_indices(), col=mat.col_indices(), value=value,
+                   sparse_sizes=(mat.size(0), mat.size(1)), is_sorted=True, trust_data=True)
+
+    @classmethod
+    def eye(cls, M: int, N: Optional[int] = None, has_value: bool = True,
+            dtype: Optional[torch.dtype] = None, device: Optional[torch.device] = None,
+            fill_cache: bool = False):
+        N = M if N is None else N
+        k = min(M, N)
+        idx = torch.arange(k, device=device)
+        rowptr = torch.cat([torch.arange(k + 1, device=device),
+                            torch.full((M - k, ), k, dtype=torch.long, device=device)])
+        value = torch.ones(k, dtype=dtype, device=device) if has_value else None
+        storage = SparseStorage(row=idx, rowptr=rowptr, col=idx, value=value, sparse_sizes=(M, N),
+                                is_sorted=True, trust_data=True)
+        out = cls.from_storage(storage)
+        if fill_cache:
+            out.storage.fill_cache_()
+        return out
+
+    # ---- views -------------------------------------------------------------------------------
+    def copy(self):
+        return self.from_storage(self.storage)
+
+    def clone(self):
+        return self.from_storage(self.storage.clone())
+
+    def coo(self) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        return self.storage.row(), self.storage.col(), self.storage.value()
+
+    def csr(self) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        return self.storage.rowptr(), self.storage.col(), self.storage.value()
+
+    def csc(self) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        perm = self.storage.csr2csc()
+        value = self.storage.value()
+        if value is not None:
+            value = value[perm]
+        return self.storage.colptr(), self.storage.row()[perm], value
+
+    def has_value(self) -> bool:
+        return self.storage.has_value()
+
+    def set_value_(self, value: Optional[Tensor], layout: Optional[str] = None):
+        self.storage.set_value_(value, layout)
+        return self
+
+    def set_value(self, value: Optional[Tensor], layout: Optional[str] = None):
+        return self.from_storage(self.storage.set_value(value, layout))
+
+    def fill_value_(self, fill_value: float, dtype: Optional[torch.dtype] = None):
+        value = torch.full((self.nnz(), ), fill_value, dtype=dtype, device=self.device())
+        return self.set_value_(value, layout='coo')
+
+    def fill_value(self, fill_value: float, dtype: Optional[torch.dtype] = None):
+        value = torch.full((self.nnz(), ), fill_value, dtype=dtype, device=self.device())
+        return self.set_value(value, layout='coo')
+
+    # ---- sizes -------------------------------------------------------------------------------
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self.storage.sparse_sizes()
+
+    def sparse_size(self, dim: int) -> int:
+        return self.storage.sparse_sizes()[dim]
+
+    def sparse_resize(self, sparse_sizes: Tuple[int, int]):
+        return self.from_storage(self.storage.sparse_resize(sparse_sizes))
+
+    def sparse_reshape(self, num_rows: int, num_cols: int):
+        return self.from_storage(self.storage.sparse_reshape(num_rows, num_cols))
+
+    def sizes(self) -> List[int]:
+        sizes = list(self.sparse_sizes())
+        value = self.storage.value()
+        if value is not None:
+            sizes += list(value.size())[1:]
+        return sizes
+
+    def size(self, dim: int) -> int:
+        return self.sizes()[dim]
+
+    def dim(self) -> int:
+        return len(self.sizes())
+
+    def nnz(self) -> int:
+        return self.storage.col().numel()
+
+    def numel(self) -> int:
+        value = self.storage.value()
+        return value.numel() if value is not None else self.nnz()
+
+    def density(self) -> float:
+        M, N = self.sparse_sizes()
+        return 0.0 if M == 0 or N == 0 else self.nnz() / (M * N)
+
+    def sparsity(self) -> float:
+        return 1 - self.density()
+
+    def avg_row_length(self) -> float:
+        return self.nnz() / self.sparse_size(0)
+
+    def avg_col_length(self) -> float:
+        return self.nnz() / self.sparse_size(1)
+
+    def is_quadratic(self) -> bool:
+        return self.sparse_size(0) == self.sparse_size(1)
+
+    def is_symmetric(self) -> bool:
+        if not self.is_quadratic():
+            return False
+        rowptr, col, value1 = self.csr()
+        colptr, row, value2 = self.csc()
+        if (rowptr != colptr).any() or (col != row).any():
+            return False
+        if value1 is None or value2 is None:
+            return True
+        return bool((value1 == value2).all())
+
+    def to_symmetric(self, reduce: str = 'sum'):
+        """A + A^T with duplicates merged (reference tensor.py:404-437), via the fused sort/coalesce."""
+        N = max(self.sparse_size(0), self.sparse_size(1))
+        row, col, value = self.coo()
+        storage = SparseStorage(row=torch.cat([row, col]), col=torch.cat([col, row]),
+                                value=None if value is None else torch.cat([value, value]),
+                                sparse_sizes=(N, N), is_sorted=False, trust_data=True)
+        return self.from_storage(storage.coalesce(reduce=reduce))
+
+    # ---- coalescing / caches -------------------------------------------------------------------
+    def is_coalesced(self) -> bool:
+        return self.storage.is_coalesced()
+
+    def coalesce(self, reduce: str = 'sum'):
+        return self.from_storage(self.storage.coalesce(reduce))
+
+    def fill_cache_(self):
+        self.storage.fill_cache_()
+        return self
+
+    def clear_cache_(self):
+        self.storage.clear_cache_()
+        return self
+
+    def __eq__(self, other) -> bool:
+        if not isinstance(other, self.__class__) or self.sizes() != other.sizes():
+            return False
+        rowptr1, col1, value1 = self.csr()
+        rowptr2, col2, value2 = other.csr()
+        if (value1 is None) != (value2 is None):
+            return False
+        if rowptr1.numel() != rowptr2.numel() or col1.numel() != col2.numel():
+            return False
+        if not (torch.equal(rowptr1, rowptr2) and torch.equal(col1, col2)):
+            return False
+        return value1 is None or torch.equal(value1, value2)
+
+    __hash__ = None
+
+    # ---- autograd / device / dtype -------------------------------------------------------------
+    def detach_(self):
+        value = self.storage.value()
+        if value is not None:
+            value.detach_()
+        return self
+
+    def detach(self):
+        value = self.storage.value()
+        return self.set_value(value.detach() if value is not None else None, layout='coo')
+
+    def requires_grad(self) -> bool:
+        value = self.storage.value()
+        return value.requires_grad if value is not None else False
+
+    def requires_grad_(self, requires_grad: bool = True, dtype: Optional[torch.dtype] = None):
+        if requires_grad and not self.has_value():
+            self.fill_value_(1., dtype)
+        value = self.storage.value()
+        if value is not None:
+            value.requires_grad_(requires_grad)
+        return self
+
+    def pin_memory(self):
+        return self.from_storage(self.storage.pin_memory())
+
+    def is_pinned(self) -> bool:
+        return self.storage.is_pinned()
+
+    def share_memory_(self):
+        self.storage.share_memory_()
+        return self
+
+    def is_shared(self) -> bool:
+        return self.storage.is_shared()
+
+    def device(self):
+        return self.storage.col().device
+
+    def is_cuda(self) -> bool:
+        return self.storage.col().is_cuda
+
+    def dtype(self):
+        value = self.storage.value()
+        return value.dtype if value is not None else torch.float
+
+    def is_floating_point(self) -> bool:
+        value = self.storage.value()
+        return torch.is_floating_point(value) if value is not None else True
+
+    def type(self, dtype: torch.dtype, non_blocking: bool = False):
+        value = self.storage.value()
+        if value is None or dtype == value.dtype:
+            return self
+        return self.from_storage(self.storage.type(dtype, non_blocking))
+
+    def type_as(self, tensor: Tensor, non_blocking: bool = False):
+        return self.type(tensor.dtype, non_blocking)
+
+    def to_device(self, device: torch.device, non_blocking: bool = False):
+        if device == self.device():
+            return self
+        return self.from_storage(self.storage.to_device(device, non_blocking))
+
+    def device_as(self, tensor: Tensor, non_blocking: bool = False):
+        return self.to_device(tensor.device, non_blocking)
+
+    def to(self, *args, **kwargs):
+        device, dtype, non_blocking = torch._C._nn._parse_to(*args, **kwargs)[:3]
+        out = self
+        if dtype is not None:
+            out = out.type(dtype, non_blocking)
+        if device is not None:
+            out = out.to_device(device, non_blocking)
+        return out
+
+    def cpu(self):
+        return self.to_device(torch.device('cpu'))
+
+    def cuda(self, device: Optional[Union[int, str]] = None, non_blocking: bool = False):
+        return self.to_device(torch.device('cuda' if device is None else device), non_blocking)
+
+    def bfloat16(self):
+        return self.type(torch.bfloat16)
+
+    def half(self):
+        return self.type(torch.half)
+
+    def float(self):
+        return self.type(torch.float)
+
+    def double(self):
+        return self.type(torch.double)
+
+    def int(self):
+        return self.type(torch.int)
+
+    def long(self):
+        return self.type(torch.long)
+
+    def bool(self):
+        return self.type(torch.bool)
+
+    def byte(self):
+        return self.type(torch.uint8)
+
+    def char(self):
+        return self.type(torch.int8)
+
+    def short(self):
+        return self.type(torch.short)
+
+    # ---- conversions ---------------------------------------------------------------------------
+    def to_dense(self, dtype: Optional[torch.dtype] = None) -> Tensor:
+        row, col, value = self.coo()
+        if value is not None:
+            mat = torch.zeros(self.sizes(), dtype=value.dtype, device=self.device())
+            mat[row, col] = value
+        else:
+            mat = torch.zeros(self.sizes(), dtype=dtype, device=self.device())
+            mat[row, col] = torch.ones(self.nnz(), dtype=mat.dtype, device=mat.device)
+        return mat
+
+    def to_torch_sparse_coo_tensor(self, dtype: Optional[torch.dtype] = None) -> Tensor:
+        row, col, value = self.coo()
+        if value is None:
+            value = torch.ones(self.nnz(), dtype=dtype, device=self.device())
+        return torch.sparse_coo_tensor(torch.stack([row, col], dim=0), value, self.sizes())
+
+    def to_torch_sparse_csr_tensor(self, dtype: Optional[torch.dtype] = None) -> Tensor:
+        rowptr, col, value = self.csr()
+        if value is None:
+            value = torch.ones(self.nnz(), dtype=dtype, device=self.device())
+        return torch.sparse_csr_tensor(rowptr, col, value, self.sizes())
+
+    def to_torch_sparse_csc_tensor(self, dtype: Optional[torch.dtype] = None) -> Tensor:
+        colptr, row, value = self.csc()
+        if value is None:
+            value = torch.ones(self.nnz(), dtype=dtype, device=self.device())
+        return torch.sparse_csc_tensor(colptr, row, value, self.sizes())
+
+    @classmethod
+    def from_scipy(cls, mat, has_value: bool = True):
+        colptr = None
+        if mat.format == 'csc':
+            colptr = torch.from_numpy(mat.indptr).to(torch.long)
+        mat = mat.tocsr()
+        rowptr = torch.from_numpy(mat.indptr).to(torch.long)
+        mat = mat.tocoo()
+        row = torch.from_numpy(mat.row).to(torch.long)
+        col = torch.from_numpy(mat.col).to(torch.long)
+        value = torch.from_numpy(mat.data) if has_value else None
+        storage = SparseStorage(row=row, rowptr=rowptr, col=col, value=value,
+                                sparse_sizes=tuple(mat.shape), colptr=colptr, is_sorted=True,
+                                trust_data=True)
+        return cls.from_storage(storage)
+
+    def to_scipy(self, layout: Optional[str] = None, dtype: Optional[torch.dtype] = None):
+        import scipy.sparse
+        assert self.dim() == 2
+        layout = get_layout(layout)
+        ones = lambda: torch.ones(self.nnz(), dtype=dtype)  # noqa: E731
+        if layout == 'coo':
+            row, col, value = self.coo()
+            value = ones() if value is None else value.detach().cpu()
+            return scipy.sparse.coo_matrix((value, (row.cpu(), col.cpu())), self.sizes())
+        if layout == 'csr':
+            rowptr, col, value = self.csr()
+            value = ones() if value is None else value.detach().cpu()
+            return scipy.sparse.csr_matrix((value, col.cpu(), rowptr.cpu()), self.sizes())
+        colptr, row, value = self.csc()
+        value = ones() if value is None else value.detach().cpu()
+        return scipy.sparse.csc_matrix((value, row.cpu(), colptr.cpu()), self.sizes())
+
+    # ---- out of scope --------------------------------------------------------------------------
+    def __getitem__(self, index: Any):
+        raise NotImplementedError('SparseTensor indexing/slicing is outside the accelerated hot path '
+                                  '(SURVEY.md section 8); use torch_sparse for it')
+
+    def __repr__(self) -> str:
+        row, col, value = self.coo()
+        lines = ['row=%s' % row, 'col=%s' % col]
+        if value is not None:
+            lines.append('val=%s' % value)
+        lines.append('size=%s, nnz=%d, density=%.2f%%' % (tuple(self.sizes()), self.nnz(),
+                                                          100 * self.density()))
+        return '%s(%s)' % (self.__class__.__name__, ',\n             '.join(lines))

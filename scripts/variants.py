@@ -3,7 +3,7 @@ import os, subprocess, sys, concurrent.futures as cf
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'pytorch_sparse_amd', 'csrc')
 OUT = os.path.join(ROOT, 'build', 'variants')
-def build(name, defs, sources=('api.hip', 'spmm.hip', 'convert.hip')):
+def build(name, defs, sources=('api.hip', 'spmm.hip', 'spmm_bw.hip', 'convert.hip')):
     os.makedirs(OUT, exist_ok=True)
     so = os.path.join(OUT, name + '.so')
     cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]

@@ -1,0 +1,281 @@
+"""The reference's own test vectors and the reference-generated fixtures, run through the Python
+API (SparseTensor / matmul / coalesce / transpose / spmm / spspmm) on the GPU, plus larger
+randomized parity runs against the numpy oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as oc
+from oracle import np_oracle as no
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def ts(dev):
+    import pytorch_sparse_amd
+    return pytorch_sparse_amd
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dev) if dtype is None else t.to(dev, dtype)
+
+
+# ---- literals from the reference's tests ----------------------------------------------------------
+def test_reference_storage_vectors(ts, dev):
+    # test/test_storage.py:10-24, 46-92
+    assert torch.ops.torch_sparse.ind2ptr(torch.tensor([2, 2, 4, 5, 5, 6], device=dev), 8).tolist() == \
+        [0, 0, 0, 2, 2, 3, 5, 6, 6]
+    row = torch.tensor([0, 0, 1, 1], device=dev)
+    col = torch.tensor([0, 1, 0, 1], device=dev)
+    st = ts.SparseStorage(row=row, col=col)
+    assert st.rowcount().tolist() == [2, 2] and st.rowptr().tolist() == [0, 2, 4]
+    assert st.colcount().tolist() == [2, 2] and st.colptr().tolist() == [0, 2, 4]
+    assert st.csr2csc().tolist() == [0, 2, 1, 3] and st.csc2csr().tolist() == [0, 2, 1, 3]
+    assert st.num_cached_keys() == 5
+    # test/test_storage.py:27-43: sort on construct
+    row = torch.tensor([0, 1, 0, 1], device=dev)
+    col = torch.tensor([1, 0, 0, 1], device=dev)
+    val = torch.tensor([1., 2., 3., 4.], device=dev)
+    st = ts.SparseStorage(row=row, col=col, value=val)
+    assert st.row().tolist() == [0, 0, 1, 1] and st.col().tolist() == [0, 1, 0, 1]
+    assert st.value().tolist() == [3, 1, 2, 4]
+    # test/test_storage.py:125-141: coalesce
+    row = torch.tensor([0, 0, 0, 1, 1], device=dev)
+    col = torch.tensor([0, 1, 1, 0, 1], device=dev)
+    st = ts.SparseStorage(row=row, col=col, value=torch.tensor([1., 1, 1, 3, 4], device=dev))
+    assert not st.is_coalesced()
+    st = st.coalesce()
+    assert st.is_coalesced()
+    assert st.row().tolist() == [0, 0, 1, 1] and st.col().tolist() == [0, 1, 0, 1]
+    assert st.value().tolist() == [1, 2, 3, 4]
+
+
+def test_reference_coalesce_transpose_vectors(ts, dev):
+    # test/test_coalesce.py:5-33 == README.md:132-152
+    index = torch.tensor([[1, 0, 1, 0, 2, 1], [0, 1, 1, 1, 0, 0]], device=dev)
+    value = torch.tensor([[1, 2], [2, 3], [3, 4], [4, 5], [5, 6], [6, 7]], device=dev)
+    i, v = ts.coalesce(index, value, m=3, n=2)
+    assert i.tolist() == [[0, 1, 1, 2], [1, 0, 1, 0]]
+    assert v.tolist() == [[6, 8], [7, 9], [3, 4], [5, 6]]
+    i, v = ts.coalesce(index, value, m=3, n=2, op='max')
+    assert i.tolist() == [[0, 1, 1, 2], [1, 0, 1, 0]]
+    assert v.tolist() == [[4, 5], [6, 7], [3, 4], [5, 6]]
+    i, v = ts.coalesce(index, None, m=3, n=2)
+    assert i.tolist() == [[0, 1, 1, 2], [1, 0, 1, 0]] and v is None
+    # test/test_transpose.py:10-32 == README.md:177-197
+    for dtype in (torch.half, torch.bfloat16, torch.float, torch.double, torch.int, torch.long):
+        index = torch.tensor([[1, 0, 1, 0, 2, 1], [0, 1, 1, 1, 0, 0]], device=dev)
+        value = torch.tensor([[1, 2], [2, 3], [3, 4], [4, 5], [5, 6], [6, 7]], dtype=dtype, device=dev)
+        i, v = ts.transpose(index, value, m=3, n=2)
+        assert i.tolist() == [[0, 0, 1, 1], [1, 2, 0, 1]]
+        assert v.tolist() == [[7, 9], [5, 6], [6, 8], [3, 4]]
+        index = torch.tensor([[1, 0, 1, 0], [0, 1, 1, 2]], device=dev)  # no duplicates
+        i, v = ts.transpose(index, torch.tensor([1, 2, 3, 4], dtype=dtype, device=dev), m=2, n=3)
+        assert i.tolist() == [[0, 1, 1, 2], [1, 0, 1, 0]] and v.tolist() == [1, 2, 3, 4]
+
+
+def test_reference_spmm_spspmm_vectors(ts, dev):
+    # test/test_spmm.py:10-19 == README.md:225-238
+    index = torch.tensor([[0, 0, 1, 2, 2], [0, 2, 1, 0, 1]], device=dev)
+    for dtype in (torch.half, torch.bfloat16, torch.float, torch.double, torch.int, torch.long):
+        value = torch.tensor([1, 2, 4, 1, 3], dtype=dtype, device=dev)
+        x = torch.tensor([[1, 4], [2, 5], [3, 6]], dtype=dtype, device=dev)
+        assert ts.spmm(index, value, 3, 3, x).tolist() == [[7, 16], [8, 20], [7, 19]]
+    # test/test_spspmm.py:10-22 == README.md:271-286
+    for dtype in (torch.float, torch.double):
+        iA = torch.tensor([[0, 0, 1, 2, 2], [1, 2, 0, 0, 1]], device=dev)
+        vA = torch.tensor([1, 2, 3, 4, 5], dtype=dtype, device=dev)
+        iB = torch.tensor([[0, 2], [1, 0]], device=dev)
+        vB = torch.tensor([2, 4], dtype=dtype, device=dev)
+        iC, vC = ts.spspmm(iA, vA, iB, vB, 3, 3, 2)
+        assert iC.tolist() == [[0, 1, 2], [0, 1, 1]] and vC.tolist() == [8, 6, 8]
+    # test/test_matmul.py:54-79: I @ I with / without values
+    src = ts.SparseTensor.from_dense(torch.eye(3, device=dev))
+    out = ts.matmul(src, src)
+    assert out.sizes() == [3, 3] and out.has_value()
+    rowptr, col, value = out.csr()
+    assert rowptr.tolist() == [0, 1, 2, 3] and col.tolist() == [0, 1, 2] and value.tolist() == [1, 1, 1]
+    src.set_value_(None)
+    out = ts.matmul(src, src)
+    assert not out.has_value() and out.csr()[1].tolist() == [0, 1, 2]
+    # test/test_spspmm.py:25-51: orthonormal rows, x @ x^T == I through SpMM and through t() + SpSpMM
+    for dtype in (torch.float, torch.double):
+        x = ts.SparseTensor(
+            row=torch.tensor([0, 1, 1, 1, 2, 3, 4, 5, 5, 6, 6, 7, 7, 7, 8, 8, 9, 9], device=dev),
+            col=torch.tensor([0, 5, 10, 15, 1, 2, 3, 7, 13, 6, 9, 5, 10, 15, 11, 14, 5, 15], device=dev),
+            value=torch.tensor([1, 3**-0.5, 3**-0.5, 3**-0.5, 1, 1, 1, -2**-0.5, -2**-0.5, -2**-0.5,
+                                -2**-0.5, 6**-0.5, -6**0.5 / 3, 6**-0.5, -2**-0.5, -2**-0.5, 2**-0.5,
+                                -2**-0.5], dtype=dtype, device=dev))
+        expected = torch.eye(10, device=dev, dtype=dtype)
+        assert torch.allclose(x @ x.to_dense().t(), expected, atol=1e-2)
+        assert torch.allclose((x @ x.t()).to_dense(), expected, atol=1e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.half, torch.bfloat16, torch.float, torch.double])
+@pytest.mark.parametrize('reduce', ['sum', 'add', 'mean', 'min', 'max'])
+def test_reference_matmul_autograd(ts, dev, dtype, reduce):
+    """test/test_matmul.py:12-51 with an independent expected value: dense gather + scatter_reduce."""
+    torch.manual_seed(0)
+    src = torch.randn(10, 8, dtype=dtype, device=dev)
+    src[2:4, :] = 0
+    src[:, 2:4] = 0
+    src = ts.SparseTensor.from_dense(src).requires_grad_()
+    row, col, value = src.coo()
+    other = torch.randn(2, 8, 2, dtype=dtype, device=dev, requires_grad=True)
+    src_col = other.index_select(-2, col) * value.unsqueeze(-1)
+    r = {'sum': 'sum', 'add': 'sum', 'mean': 'mean', 'min': 'amin', 'max': 'amax'}[reduce]
+    idx = row.view(1, -1, 1).expand_as(src_col)
+    expected = torch.zeros(2, 10, 2, dtype=dtype, device=dev).scatter_reduce(1, idx, src_col, r, include_self=False)
+    grad_out = torch.randn_like(expected)
+    expected.backward(grad_out)
+    eg_value, eg_other = value.grad, other.grad
+    value.grad = None
+    other.grad = None
+    out = ts.matmul(src, other, reduce)
+    out.backward(grad_out)
+    atol = 1e-1 if dtype in (torch.half, torch.bfloat16) else (1e-5 if dtype == torch.float else 1e-7)
+    assert torch.allclose(expected, out, atol=atol)
+    assert torch.allclose(eg_value, value.grad, atol=atol)
+    assert torch.allclose(eg_other, other.grad, atol=atol)
+
+
+# ---- fixtures generated by the reference's own Python ---------------------------------------------
+def test_reference_python_fixtures(ts, dev):
+    n = 0
+    for f in sorted(glob.glob(os.path.join(GOLDEN, 'py_coalesce_*.npz'))):
+        z = np.load(f)
+        value = T(z['value'], dev) if 'value' in z.files else None
+        op = str(z['op']) if 'op' in z.files else 'add'
+        i, v = ts.coalesce(T(z['index'], dev), value, int(z['m']), int(z['n']), op=op)
+        assert np.array_equal(i.cpu().numpy(), z['out_index']), f
+        if value is not None:
+            assert np.array_equal(v.cpu().numpy(), z['out_value']), f
+        n += 1
+    for f in sorted(glob.glob(os.path.join(GOLDEN, 'py_transpose_*.npz'))):
+        z = np.load(f)
+        i, v = ts.transpose(T(z['index'], dev), T(z['value'], dev), int(z['m']), int(z['n']))
+        assert np.array_equal(i.cpu().numpy(), z['out_index']) and np.array_equal(v.cpu().numpy(), z['out_value']), f
+        n += 1
+    z = np.load(os.path.join(GOLDEN, 'py_storage.npz'))
+    A = ts.SparseTensor(row=T(z['row'], dev), col=T(z['col'], dev), value=T(z['value'], dev),
+                        sparse_sizes=(int(z['m']), int(z['n'])))
+    r, c, v = A.coo()
+    assert np.array_equal(r.cpu().numpy(), z['s_row']) and np.array_equal(c.cpu().numpy(), z['s_col'])
+    assert np.array_equal(v.cpu().numpy(), z['s_value'])
+    st = A.storage
+    for key, fn in (('rowptr', st.rowptr), ('colptr', st.colptr), ('csr2csc', st.csr2csc),
+                    ('csc2csr', st.csc2csr), ('rowcount', st.rowcount), ('colcount', st.colcount)):
+        assert np.array_equal(fn().cpu().numpy(), z[key]), key
+    tr, tc, tv = A.t().coo()
+    assert np.array_equal(tr.cpu().numpy(), z['t_row']) and np.array_equal(tc.cpu().numpy(), z['t_col'])
+    assert np.array_equal(tv.cpu().numpy(), z['t_value'])
+    assert A.t().t() == A
+    for f in sorted(glob.glob(os.path.join(GOLDEN, 'py_spspmm_*.npz'))):
+        z = np.load(f)
+        m, k, nn = int(z['m']), int(z['k']), int(z['n'])
+        if 'vA' in z.files:
+            iC, vC = ts.spspmm(T(z['iA'], dev), T(z['vA'], dev), T(z['iB'], dev), T(z['vB'], dev), m, k, nn)
+            assert np.array_equal(iC.cpu().numpy(), z['iC']), f
+            assert np.allclose(vC.cpu().numpy(), z['vC'], rtol=1e-6, atol=1e-6), f
+        else:
+            A = ts.SparseTensor(row=T(z['iA'][0], dev), col=T(z['iA'][1], dev), sparse_sizes=(m, k))
+            B = ts.SparseTensor(row=T(z['iB'][0], dev), col=T(z['iB'][1], dev), sparse_sizes=(k, nn))
+            C = A @ B
+            assert not C.has_value()
+            rr, cc, _ = C.coo()
+            assert np.array_equal(torch.stack([rr, cc]).cpu().numpy(), z['iC']), f
+        n += 1
+    z = np.load(os.path.join(GOLDEN, 'py_legacy_spmm.npz'))
+    out = ts.spmm(T(z['index'], dev), T(z['value'], dev), int(z['m']), int(z['n']), T(z['mat'], dev))
+    assert np.allclose(out.cpu().numpy(), z['out'], rtol=1e-5, atol=1e-5)
+    for reduce in ('sum', 'mean', 'min', 'max'):
+        z = np.load(os.path.join(GOLDEN, 'py_matmul_%s.npz' % reduce))
+        value = T(z['value'], dev).requires_grad_()
+        x = T(z['mat'], dev).requires_grad_()
+        A = ts.SparseTensor(row=T(z['row'], dev), col=T(z['col'], dev), value=value,
+                            sparse_sizes=(int(z['m']), int(z['n'])))
+        out = ts.matmul(A, x, reduce)
+        out.backward(T(z['grad_out'], dev))
+        assert np.allclose(out.detach().cpu().numpy(), z['out'], rtol=1e-12, atol=1e-12), reduce
+        assert np.allclose(value.grad.cpu().numpy(), z['grad_value'], rtol=1e-10, atol=1e-12), reduce
+        assert np.allclose(x.grad.cpu().numpy(), z['grad_mat'], rtol=1e-10, atol=1e-12), reduce
+        n += 1
+    assert n > 30
+
+
+# ---- randomized parity at larger sizes ------------------------------------------------------------
+@pytest.mark.parametrize('n,m,ncols', [(0, 5, 5), (1, 1, 1), (1000, 7, 3), (300000, 5000, 4000),
+                                       (3000000, 1 << 20, 1 << 20), (50000, 1 << 31, 1 << 30)])
+def test_sort_coo_bit_exact(dev, n, m, ncols):
+    g = torch.Generator().manual_seed(n % 97)
+    row = torch.randint(0, m, (n, ), generator=g)
+    col = torch.randint(0, ncols, (n, ), generator=g)
+    if n >= 1000:  # force duplicates so that stability is exercised
+        row[: n // 4] = row[n // 4: 2 * (n // 4)]
+        col[: n // 4] = col[n // 4: 2 * (n // 4)]
+    rs, cs, perm = torch.ops.tsamd.sort_coo(row.to(dev), col.to(dev), m, ncols, True)
+    er, ec, ep = no.sort_coo(row.numpy(), col.numpy(), m, ncols)
+    assert np.array_equal(perm.cpu().numpy(), ep)  # stable => the permutation itself is pinned
+    assert np.array_equal(rs.cpu().numpy(), er) and np.array_equal(cs.cpu().numpy(), ec)
+    counts = torch.ops.tsamd.coo_order(rs, cs, ncols).tolist()
+    assert counts[0] == 0
+    key = er.astype(np.int64) * ncols + ec
+    assert counts[1] == int((key[1:] == key[:-1]).sum())
+
+
+@pytest.mark.parametrize('op', ['add', 'mean', 'min', 'max'])
+def test_coalesce_large(ts, dev, op):
+    g = torch.Generator().manual_seed(3)
+    m, ncols, n = 20000, 300, 400000
+    index = torch.stack([torch.randint(0, m, (n, ), generator=g), torch.randint(0, ncols, (n, ), generator=g)])
+    for value in (torch.randint(-50, 50, (n, 3), generator=g), torch.randint(-64, 64, (n, ), generator=g).float() / 8,
+                  torch.randint(-64, 64, (n, ), generator=g).double() / 8):
+        i, v = ts.coalesce(index.to(dev), value.to(dev), m, ncols, op=op)
+        er, ec, ev = no.coalesce(index[0].numpy(), index[1].numpy(), value.numpy(), m, ncols, op)
+        assert np.array_equal(i.cpu().numpy(), np.stack([er, ec]))
+        assert np.array_equal(v.cpu().numpy(), ev)  # dyadic values: every op is exact
+
+
+def test_spspmm_vs_torch_sparse_mm(ts, dev):
+    """Oracle = torch.sparse.mm on CPU, the very function behind the reference's spspmm."""
+    g = torch.Generator().manual_seed(5)
+    for (m, k, n, nA, nB, hub) in ((2000, 1500, 1800, 30000, 25000, False), (3000, 3000, 3000, 40000, 40000, True)):
+        kA = torch.randperm(m * k, generator=g)[:nA].sort().values
+        kB = torch.randperm(k * n, generator=g)[:nB].sort().values
+        rA, cA, rB, cB = kA // k, kA % k, kB // n, kB % n
+        if hub:  # a dense row of A and a dense row of B => rows beyond the LDS capacity
+            rA = torch.cat([rA, torch.full((k, ), 7)]); cA = torch.cat([cA, torch.arange(k)])
+            rB = torch.cat([rB, torch.full((n, ), 11)]); cB = torch.cat([cB, torch.arange(n)])
+        for dtype in (torch.float32, torch.float64):
+            vA = torch.randint(-4, 5, (rA.numel(), ), generator=g).to(dtype) / 2
+            vB = torch.randint(-4, 5, (rB.numel(), ), generator=g).to(dtype) / 2
+            A = torch.sparse_coo_tensor(torch.stack([rA, cA]), vA, (m, k)).coalesce()
+            B = torch.sparse_coo_tensor(torch.stack([rB, cB]), vB, (k, n)).coalesce()
+            C = torch.sparse.mm(A, B)
+            iC, vC = ts.spspmm(A._indices().to(dev), A._values().to(dev), B._indices().to(dev),
+                               B._values().to(dev), m, k, n)
+            assert torch.equal(iC.cpu(), C._indices())
+            assert torch.equal(vC.cpu(), C._values())  # half-integers: sums are exact in any order
+
+
+def test_csr2csc_and_t_large(ts, dev):
+    from pytorch_sparse_amd import synth
+    rp, c = synth.rmat_csr(16, 12, seed=9, device=dev)
+    A = ts.SparseTensor(rowptr=rp, col=c, value=synth.values(c.numel(), device=dev),
+                        sparse_sizes=(1 << 16, 1 << 16), is_sorted=True, trust_data=True)
+    row, col, val = A.coo()
+    p = no.csr2csc(row.cpu().numpy(), col.cpu().numpy(), 1 << 16, 1 << 16)
+    assert np.array_equal(A.storage.csr2csc().cpu().numpy(), p)
+    At = A.t()
+    assert np.array_equal(At.storage.row().cpu().numpy(), col.cpu().numpy()[p])
+    assert torch.equal(At.storage.rowptr(), A.storage.colptr())
+    x = synth.features(1 << 16, 32, device=dev)
+    dense_check = (At @ x)  # A^T x through the forward kernel on the transposed storage
+    ref = torch.zeros_like(x).index_add_(0, col, val[:, None] * x[row])
+    assert torch.allclose(dense_check, ref, rtol=1e-4, atol=1e-4)

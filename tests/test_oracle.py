@@ -143,3 +143,46 @@ def test_golden_fixtures():
         assert np.array_equal(out, z['out']), f
         if arg is not None:
             assert np.array_equal(arg, z['arg_out']), f
+
+
+def test_np_oracle_matches_reference_python_fixtures():
+    """coalesce / transpose / storage / spspmm restatements vs outputs of the reference's own
+    Python package (tests/golden/py_*.npz, written by make_golden.py)."""
+    from oracle import np_oracle as no
+    n_checked = 0
+    for f in sorted(glob.glob(os.path.join(GOLDEN, 'py_coalesce_*.npz'))):
+        z = np.load(f)
+        value = z['value'] if 'value' in z.files else None
+        op = str(z['op']) if 'op' in z.files else 'add'
+        r, c, v = no.coalesce(z['index'][0], z['index'][1], value, int(z['m']), int(z['n']), op)
+        assert np.array_equal(np.stack([r, c]), z['out_index']), f
+        if value is not None:
+            assert np.array_equal(v, z['out_value']), f
+        n_checked += 1
+    for f in sorted(glob.glob(os.path.join(GOLDEN, 'py_transpose_*.npz'))):
+        z = np.load(f)
+        r, c, v = no.transpose(z['index'][0], z['index'][1], z['value'], int(z['m']), int(z['n']))
+        assert np.array_equal(np.stack([r, c]), z['out_index']) and np.array_equal(v, z['out_value']), f
+        n_checked += 1
+    z = np.load(os.path.join(GOLDEN, 'py_storage.npz'))
+    m, n = int(z['m']), int(z['n'])
+    r, c, perm = no.sort_coo(z['row'], z['col'], m, n)
+    assert np.array_equal(r, z['s_row']) and np.array_equal(c, z['s_col'])
+    assert np.array_equal(z['value'][perm], z['s_value'])
+    assert np.array_equal(oc.ind2ptr(r, m), z['rowptr'])
+    p = no.csr2csc(r, c, m, n)
+    assert np.array_equal(p, z['csr2csc'])
+    assert np.array_equal(np.argsort(p, kind='stable'), z['csc2csr'])
+    assert np.array_equal(oc.ind2ptr(c[p], n), z['colptr'])
+    assert np.array_equal(c[p], z['t_row']) and np.array_equal(r[p], z['t_col'])
+    for f in sorted(glob.glob(os.path.join(GOLDEN, 'py_spspmm_*.npz'))):
+        z = np.load(f)
+        vA = z['vA'] if 'vA' in z.files else None
+        vB = z['vB'] if 'vB' in z.files else None
+        r, c, v = no.spspmm(z['iA'][0], z['iA'][1], vA, z['iB'][0], z['iB'][1], vB, int(z['m']),
+                            int(z['k']), int(z['n']))
+        assert np.array_equal(np.stack([r, c]), z['iC']), f
+        if vA is not None:
+            assert np.allclose(v, z['vC'], rtol=1e-6, atol=1e-6), f
+        n_checked += 1
+    assert n_checked > 20
