@@ -1,0 +1,110 @@
+"""world_size-2 gloo tests of the row-sharded SpMM path (sharding, all-gather, reduce-scatter
+logic).  The local multiply is injected: the C oracle for the forward parity check, a
+differentiable torch formulation for the backward check.  CPU only."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import c_oracle as oc
+from pytorch_sparse_amd import synth
+from pytorch_sparse_amd.parallel import narrow_rows, partition_rows
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def oracle_spmm(rowptr, col, value, x, reduce):
+    o, _ = oc.spmm(oc.F32, reduce, rowptr.numpy(), col.numpy(), None if value is None else value.numpy(),
+                   x.detach().numpy())
+    return torch.from_numpy(o)
+
+
+def torch_spmm_sum(rowptr, col, value, x, reduce):
+    assert reduce == 'sum'
+    row = torch.repeat_interleave(torch.arange(rowptr.numel() - 1), rowptr[1:] - rowptr[:-1])
+    return torch.zeros(rowptr.numel() - 1, x.size(1), dtype=x.dtype).index_add_(0, row, value[:, None] * x[col])
+
+
+def _worker(rank, world, port, balance, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pytorch_sparse_amd.parallel import shard_matrix
+        rp, c = synth.rmat_csr(9, 8, seed=1)
+        n = 1 << 9
+        v = synth.values(c.numel())
+        x = synth.features(n, 12)
+        # forward parity for every reduction, local multiply = C oracle
+        op, (s, e) = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=oracle_spmm)
+        sizes = op.x_sizes
+        xs = sum(sizes[:rank])
+        x_local = x[xs:xs + sizes[rank]].clone()
+        res = {}
+        for reduce in ('sum', 'mean', 'min', 'max'):
+            out_local = op(x_local, reduce)
+            full, _ = oc.spmm(oc.F32, reduce, rp.numpy(), c.numpy(), v.numpy(), x.numpy())
+            res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]))
+        # backward: grad of x must be reduce-scattered to the owning rank
+        opd, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=torch_spmm_sum)
+        xl = x_local.clone().requires_grad_()
+        gout = synth.features(n, 12, seed=5)[s:e]
+        opd(xl, 'sum').backward(gout)
+        xg = x.clone().requires_grad_()
+        torch_spmm_sum(rp, c, v, xg, 'sum').backward(synth.features(n, 12, seed=5))
+        res['grad'] = bool(torch.allclose(xl.grad, xg.grad[xs:xs + sizes[rank]], rtol=1e-5, atol=1e-5))
+        res['range'] = (s, e)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('balance', ['nnz', 'rows'])
+def test_row_sharded_spmm_gloo_world2(balance):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, balance, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results.items():
+        for k in ('sum', 'mean', 'min', 'max', 'grad'):
+            assert res[k], (rank, k)
+    (s0, e0), (s1, e1) = results[0]['range'], results[1]['range']
+    assert s0 == 0 and e0 == s1 and e1 == 1 << 9
+
+
+def test_partition_and_narrow():
+    rp, c = synth.rmat_csr(10, 8, seed=2)
+    E = c.numel()
+    for parts in (1, 2, 4, 8):
+        for balance in ('nnz', 'rows'):
+            ranges = partition_rows(rp, parts, balance)
+            assert ranges[0][0] == 0 and ranges[-1][1] == 1 << 10
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(parts - 1))
+            nnz = [int(rp[e] - rp[s]) for s, e in ranges]
+            assert sum(nnz) == E
+            if balance == 'nnz' and parts > 1:
+                maxdeg = int((rp[1:] - rp[:-1]).max())
+                assert max(nnz) <= E / parts + maxdeg  # balanced up to one row
+    # narrow == the reference's narrow(dim=0) definition (narrow.py:15-42)
+    s, e = 100, 700
+    lrp, lc, lv = narrow_rows(rp, c, None, s, e)
+    assert lrp[0] == 0 and lrp.numel() == e - s + 1 and int(lrp[-1]) == lc.numel()
+    assert torch.equal(lc, c[int(rp[s]):int(rp[e])])
+    # degenerate: more parts than rows with entries
+    rp2 = torch.tensor([0, 0, 5, 5])
+    assert partition_rows(rp2, 4, 'nnz')[-1][1] == 3
