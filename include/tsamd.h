@@ -79,7 +79,7 @@ const char *tsamd_status_string(int status);
  * to the narrow type exactly as the reference does.
  * ------------------------------------------------------------------------ */
 size_t tsamd_spmm_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M,
-                                  int64_t K, int64_t E);
+                                  int64_t N, int64_t K, int64_t E);
 int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
                const void *value, const void *mat, void *out, int64_t *arg_out,
                int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,

@@ -119,7 +119,7 @@ def spmm(rowptr, col, value, mat, reduce, out=None, profile=None):
     if red >= 2:
         arg = torch.empty(sizes, dtype=torch.int64, device=mat.device)
     L = lib()
-    nb = L.tsamd_spmm_workspace_bytes(dt, red, _i64(B), _i64(M), _i64(K), _i64(E))
+    nb = L.tsamd_spmm_workspace_bytes(dt, red, _i64(B), _i64(M), _i64(N), _i64(K), _i64(E))
     ws = workspace(nb, mat.device)
     with torch.cuda.device(mat.device):
         args = (dt, red, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(out), _ptr(arg),

@@ -34,6 +34,8 @@
 // Deterministic: the partition only depends on rowptr, every combine order is fixed.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace tsamd {
 namespace {
 
@@ -75,7 +77,76 @@ struct Workspace {
   int64_t *tail_arg;
   int64_t P;
   int64_t items;  // (row, edge) items per partition
+  // channel-camping avoidance (see "relabel" below)
+  int relabel_mode;   // host decision: 0 off, 1 on, 2 = decide on the device from the sample
+  int *relabel_flag;  // device int[4]: sample counters (see use_relabel)
+  void *xperm;        // [B][N][K] copy of mat with rows at hashed positions
+  uint32_t hash_bits, hash_mul, hash_shift;
 };
+
+// ---------------------------------------------------------------------------
+// 0. relabel: Kronecker / R-MAT style graphs put their hub columns at indices with few set
+//    bits; with a 512-byte row pitch those rows share their low address bits and camp on a few
+//    memory channels (measured on MI355X: the same graph runs 1.42x faster when the column ids
+//    are relabelled at random).  When a sample of `col` shows that skew, `mat` is copied once
+//    with its rows at hashed positions and the gather uses the hashed ids.  The hash is a
+//    bijection on [0, N): multiply by an odd constant and fold the high half into the low half
+//    on ceil(log2 N) bits, cycle-walking until the value is < N.  Sums are bit-identical with
+//    and without it (only addresses change).  TSAMD_SPMM_RELABEL=0|1 forces it off|on.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash_row(uint32_t c, uint32_t N, uint32_t bits, uint32_t mul,
+                                             uint32_t shift) {
+  const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+  do {
+    c = (c * mul) & mask;
+    c ^= c >> shift;
+  } while (c >= N);
+  return c;
+}
+
+// counters: [1] #sampled ids with 3 low zero
+// bits, [2] with 6 low zero bits, [3] #samples.  Uniform ids give 1/8 and 1/64 of the samples.
+__device__ __forceinline__ bool use_relabel(int mode, const int *f) {
+  if (mode != 2) return mode == 1;
+  const int n = f[3];
+  return n >= 4096 && (f[1] * 4 > n || f[2] * 16 > n);
+}
+
+constexpr int kProbeBlocks = 64;
+
+__global__ void spmm_probe_kernel(const int64_t *__restrict__ col, int64_t E, int *__restrict__ flag) {
+  const int64_t samples = (int64_t)kProbeBlocks * blockDim.x;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t pos = (i * E) / samples;  // evenly spread over the edge list
+  const uint64_t c = (uint64_t)col[pos];
+  const unsigned long long m3 = __ballot((c & 7u) == 0), m6 = __ballot((c & 63u) == 0);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&flag[1], __popcll(m3));
+    atomicAdd(&flag[2], __popcll(m6));
+    atomicAdd(&flag[3], 64);
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void spmm_permute_rows_kernel(const T *__restrict__ mat,
+                                                               T *__restrict__ xperm, int64_t BN,
+                                                               uint32_t N, uint32_t K,
+                                                               Workspace ws) {
+  if (!use_relabel(ws.relabel_mode, ws.relabel_flag)) return;
+  using P = Pack<T, VEC>;
+  const uint32_t slots = K / VEC;
+  const int64_t total = BN * slots;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / slots;
+    const uint32_t sl = (uint32_t)(t - r * slots);
+    const int64_t b = r / N;
+    const uint32_t i = (uint32_t)(r - b * N);
+    const uint32_t j = hash_row(i, N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
+    reinterpret_cast<P *>(xperm)[((uint64_t)b * N + j) * slots + sl] =
+        reinterpret_cast<const P *>(mat)[(uint64_t)r * slots + sl];
+  }
+}
 
 // ---------------------------------------------------------------------------
 // 1. merge-path partition: list A = row ends rowptr[1..M], list B = edge ids
@@ -259,7 +330,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
   const int kl = lane & (lpr - 1);
   const uint32_t k0 = (kt * 64u + (uint32_t)kl) * VEC;
   const bool kok = k0 < K;
-  const T *matk = mat + (uint64_t)b * N * K + (kok ? k0 : 0u);
+  const bool relabel = use_relabel(ws.relabel_mode, ws.relabel_flag);  // wave-uniform
+  const T *src = relabel ? reinterpret_cast<const T *>(ws.xperm) : mat;
+  const T *matk = src + (uint64_t)b * N * K + (kok ? k0 : 0u);
   const uint64_t out_b = (uint64_t)b * M * K + k0;
   const bool writer = g == 0 && kok;
   const uint64_t carry_off = ((uint64_t)b * ws.P + (uint64_t)p) * K + k0;  // [b][p][K]
@@ -277,6 +350,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
     w_l = A(1);
     if (e < e1) {
       c_l = (uint32_t)col[e];
+      if (relabel) c_l = hash_row(c_l, (uint32_t)N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
       if (value != nullptr) w_l = Traits<T>::to_acc(value[e]);
     }
   };
@@ -420,8 +494,13 @@ void plan_partition(int64_t M, int64_t E, int64_t *P, int64_t *items) {
   *P = ceil_div(total, it);
 }
 
-size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t K, int64_t E,
-             Workspace *ws) {
+// The relabelled copy only pays off for big problems whose rows are 16-byte packets.
+bool relabel_possible(int dtype, int64_t N, int64_t K, int64_t E) {
+  return E >= (1 << 20) && N >= 4096 && N < ((int64_t)1 << 32) && (K * (int64_t)dtype_size(dtype)) % 16 == 0;
+}
+
+size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,
+             int64_t E, Workspace *ws) {
   int64_t P, items;
   plan_partition(M, E, &P, &items);
   const bool minmax = reduce == TSAMD_MIN || reduce == TSAMD_MAX;
@@ -442,6 +521,13 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t K,
   w.tail_val = take(acc_size(dtype) * plane);
   w.head_arg = reinterpret_cast<int64_t *>(minmax ? take(sizeof(int64_t) * plane) : nullptr);
   w.tail_arg = reinterpret_cast<int64_t *>(minmax ? take(sizeof(int64_t) * plane) : nullptr);
+  w.relabel_mode = 0;
+  w.relabel_flag = reinterpret_cast<int *>(take(256));
+  w.xperm = relabel_possible(dtype, N, K, E) ? take(dtype_size(dtype) * (size_t)B * N * K) : nullptr;
+  w.hash_bits = 1;
+  while (w.hash_bits < 32 && ((uint64_t)1 << w.hash_bits) < (uint64_t)(N > 1 ? N : 2)) ++w.hash_bits;
+  w.hash_mul = 0x9E3779B1u;  // odd (golden-ratio) multiplier
+  w.hash_shift = w.hash_bits > 1 ? w.hash_bits / 2 : 1;
   if (ws) *ws = w;
   return off;
 }
@@ -457,6 +543,25 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   const unsigned int threads = kWavesPerBlock * kWave;
 
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[0], stream));
+  {
+    int mode = 0;
+    if (ws.xperm != nullptr && VEC > 1) {
+      const char *env = getenv("TSAMD_SPMM_RELABEL");
+      mode = env ? (env[0] == '1' ? 1 : (env[0] == '0' ? 0 : 2)) : 2;
+    }
+    ws.relabel_mode = mode;
+    if (mode == 2) {
+      TSAMD_HIP_TRY(hipMemsetAsync(ws.relabel_flag, 0, 4 * sizeof(int), stream));
+      hipLaunchKernelGGL(spmm_probe_kernel, dim3(kProbeBlocks), dim3(256), 0, stream, col, E,
+                         ws.relabel_flag);
+      TSAMD_LAUNCH_CHECK();
+    }
+    if (mode != 0) {
+      hipLaunchKernelGGL((spmm_permute_rows_kernel<T, VEC>), dim3(4096), dim3(256), 0, stream, mat,
+                         reinterpret_cast<T *>(ws.xperm), B * N, (uint32_t)N, (uint32_t)K, ws);
+      TSAMD_LAUNCH_CHECK();
+    }
+  }
   hipLaunchKernelGGL(spmm_partition_kernel, dim3((unsigned int)ceil_div(ws.P + 1, 256)), dim3(256),
                      0, stream, rowptr, M, E, ws);
   TSAMD_LAUNCH_CHECK();
@@ -506,9 +611,9 @@ int dispatch_spmm(int reduce, bool vec_ok, const int64_t *rowptr, const int64_t 
 using namespace tsamd;
 
 extern "C" size_t tsamd_spmm_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M,
-                                             int64_t K, int64_t E) {
-  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || K < 0 || E < 0) return 0;
-  return carve(nullptr, dtype, reduce, B, M, K, E, nullptr);
+                                             int64_t N, int64_t K, int64_t E) {
+  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
+  return carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr);
 }
 
 static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
@@ -523,11 +628,11 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   if (B * M * K == 0) return TSAMD_OK;  // nothing to write
   if (!rowptr || !out || (E > 0 && (!col || !mat)) || (minmax && !arg_out))
     return TSAMD_ERR_INVALID;
-  const size_t need = carve(nullptr, dtype, reduce, B, M, K, E, nullptr);
+  const size_t need = carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr);
   if (!workspace || workspace_bytes_given < need) return TSAMD_ERR_WORKSPACE;
   if ((uintptr_t)workspace % 256 != 0) return TSAMD_ERR_WORKSPACE;
   Workspace ws;
-  carve(workspace, dtype, reduce, B, M, K, E, &ws);
+  carve(workspace, dtype, reduce, B, M, N, K, E, &ws);
   const size_t es = dtype_size(dtype);
   const bool vec_ok = (K * es) % 16 == 0 && ((uintptr_t)mat % 16 == 0) &&
                       ((uintptr_t)out % 16 == 0) && (!minmax || (uintptr_t)arg_out % 64 == 0);

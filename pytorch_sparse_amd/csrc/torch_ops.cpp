@@ -113,7 +113,7 @@ std::tuple<Tensor, OptTensor> spmm_fw(const Tensor &rowptr, const Tensor &col,
     arg_ptr = arg_out.value().data_ptr<int64_t>();
   }
   const int dt = dtype_code(mat);
-  const size_t need = tsamd_spmm_workspace_bytes(dt, red, B, M, K, E);
+  const size_t need = tsamd_spmm_workspace_bytes(dt, red, B, M, N, K, E);
   Tensor ws = workspace(need, mat);
   check_status(tsamd_spmm(dt, red, rp.data_ptr<int64_t>(), c.data_ptr<int64_t>(),
                           ptr_or_null(value), mat.data_ptr(), out.data_ptr(), arg_ptr, B, M, N, K,

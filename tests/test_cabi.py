@@ -33,10 +33,9 @@ def test_version_and_status_strings():
     assert L.tsamd_status_string(0) == b'ok'
     assert b'workspace' in L.tsamd_status_string(4)
     # workspace query is host-only arithmetic
-    assert L.tsamd_spmm_workspace_bytes(0, 0, ctypes.c_int64(1), ctypes.c_int64(10),
-                                        ctypes.c_int64(16), ctypes.c_int64(100)) > 0
-    assert L.tsamd_spmm_workspace_bytes(99, 0, ctypes.c_int64(1), ctypes.c_int64(10),
-                                        ctypes.c_int64(16), ctypes.c_int64(100)) == 0
+    i64 = ctypes.c_int64
+    assert L.tsamd_spmm_workspace_bytes(0, 0, i64(1), i64(10), i64(10), i64(16), i64(100)) > 0
+    assert L.tsamd_spmm_workspace_bytes(99, 0, i64(1), i64(10), i64(10), i64(16), i64(100)) == 0
 
 
 def test_no_cpu_fallback():
