@@ -264,7 +264,10 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
       for (int j = 0; j < VEC; ++j) val[j] = val[j] / d;
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o.v[j] = Traits<T>::from_acc(val[j]);
+    for (int j = 0; j < VEC; ++j) {
+      asm volatile("" : "+v"(val[j]));  // keep the mean / non-mean paths from splitting the 16-byte store
+      o.v[j] = Traits<T>::from_acc(val[j]);
+    }
     *reinterpret_cast<Pack<T, VEC> *>(outk) = o;
   } else {
     Pack<int64_t, VEC> a;
@@ -361,60 +364,80 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
   int64_t rp_base = r0;
   auto load_rowends = [&](int64_t base) -> int64_t {
     const int64_t r = base + 1 + lane;
-    return rowptr[r <= M ? r : M];
+    int64_t v = rowptr[r <= M ? r : M];
+    // Consume the value here: otherwise the compiler keeps it "pending" across the row loop and
+    // puts an s_waitcnt vmcnt(0) at the top of EVERY row iteration (draining the previous row's
+    // store and the prefetched window) instead of once per 64 rows.
+    uint32_t lo = (uint32_t)(uint64_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
   };
   int64_t rp_l = load_rowends(rp_base);
 
   int64_t e = e0;
   A val[VEC];
   int64_t arg[VEC];
+  init_acc<T, VEC, RED>(val, arg);
 
-  // accumulate edges [e, end) of the current row, advancing windows as needed
-  auto run_segment = [&](int64_t end) {
-    while (e < end) {
-      if (e >= wbase + kWave) {  // uniform: advance the window, request the next
-        wbase += kWave;
-        c_cur = c_nxt;
-        w_cur = w_nxt;
-        load_window(wbase + kWave, c_nxt, w_nxt);
+  // Windows alternate between two register sets (A = c_cur/w_cur, B = c_nxt/w_nxt): window k is
+  // consumed from one set while window k+1 is already in flight into the other, and the set just
+  // consumed is refilled with window k+2.  No register is ever renamed, so the compiler waits
+  // for outstanding memory operations once per window -- not once per row, which would also
+  // drain the previous row's store (measured ~10 % on short-row graphs).
+  int64_t r = r0;
+  int64_t estart = e0;  // first edge of the current row that belongs to this partition
+  int64_t trow = -1;
+  // rows (or row pieces) inside the window [wbase, wbase + 64); true when the partition is done
+  auto process_window = [&](const uint32_t c_w, const A w_w) __attribute__((always_inline)) -> bool {
+    const int64_t wend_raw = wbase + kWave;
+    const int64_t wend = wend_raw < e1 ? wend_raw : e1;
+    for (;;) {
+      const bool tail = r >= r1;  // the unfinished last row (or nothing, if r1 == M)
+      int64_t rend = e1;
+      if (!tail) {
+        int j = (int)(r - rp_base);
+        if (j == kWave) {
+          rp_base = r;
+          rp_l = load_rowends(rp_base);
+          j = 0;
+        }
+        // j is wave-uniform: v_readlane keeps the row end (and the loop control) in SGPRs
+        rend = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)rp_l >> 32), j) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)rp_l, j));
       }
-      const int64_t wend = wbase + kWave;
-      const int64_t stop = end < wend ? end : wend;
-      accumulate_window<T, VEC, RED>((int)(e - wbase), (int)(stop - wbase), wbase, c_cur, w_cur,
-                                     matk, K, lgG, g, val, arg);
-      e = stop;
+      const int64_t stop = rend < wend ? rend : wend;
+      if (e < stop) {
+        accumulate_window<T, VEC, RED>((int)(e - wbase), (int)(stop - wbase), wbase, c_w, w_w, matk,
+                                       K, lgG, g, val, arg);
+        e = stop;
+      }
+      if (e < rend) return false;  // window exhausted inside the row
+      if (tail) return true;
+      // row r ends here
+      if (estart < rend) reduce_groups<A, VEC, RED>(lgG, val, arg);
+      if (writer) {
+        if (incoming && r == r0) {  // head of a cut row: the fix-up kernel finishes it
+          write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg);
+        } else {
+          const uint64_t o = out_b + (uint64_t)r * K;
+          write_row<T, VEC, RED>(out + o, arg_out + o, val, arg, rend - estart, mean, E);
+        }
+      }
+      init_acc<T, VEC, RED>(val, arg);
+      ++r;
+      estart = e;
     }
   };
-
-  for (int64_t r = r0; r < r1; ++r) {
-    int j = (int)(r - rp_base);
-    if (j == kWave) {
-      rp_base = r;
-      rp_l = load_rowends(rp_base);
-      j = 0;
-    }
-    const int64_t rend = lane_read(rp_l, j);  // uniform
-    const int64_t estart = e;                 // == rowptr[r] unless the row is cut
-    init_acc<T, VEC, RED>(val, arg);
-    if (e < rend) {
-      run_segment(rend);
-      reduce_groups<A, VEC, RED>(lgG, val, arg);
-    }
-    if (writer) {
-      if (incoming && r == r0) {  // head of a cut row: the fix-up kernel finishes it
-        write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg);
-      } else {
-        const uint64_t o = out_b + (uint64_t)r * K;
-        write_row<T, VEC, RED>(out + o, arg_out + o, val, arg, rend - estart, mean, E);
-      }
-    }
+  for (;;) {
+    if (process_window(c_cur, w_cur)) break;
+    load_window(wbase + 2 * kWave, c_cur, w_cur);
+    wbase += kWave;
+    if (process_window(c_nxt, w_nxt)) break;
+    load_window(wbase + 2 * kWave, c_nxt, w_nxt);
+    wbase += kWave;
   }
-
-  // tail: the unfinished row r1 (if any of its edges fall into this partition)
-  int64_t trow = -1;
-  if (r1 < M && e < e1) {
-    init_acc<T, VEC, RED>(val, arg);
-    run_segment(e1);
+  // tail: the piece of the unfinished row r1 that falls into this partition
+  if (r1 < M && estart < e1) {
     reduce_groups<A, VEC, RED>(lgG, val, arg);
     if (writer) write_carry<T, VEC, RED>(ws.tail_val, ws.tail_arg, carry_off, val, arg);
     trow = r1;
