@@ -170,26 +170,28 @@ __global__ void spmm_partition_kernel(const int64_t *__restrict__ rowptr, int64_
 // ---------------------------------------------------------------------------
 // accumulation helpers
 // ---------------------------------------------------------------------------
-template <typename T, int VEC, int RED>
-__device__ __forceinline__ void init_acc(typename Traits<T>::acc_t (&val)[VEC],
-                                         int64_t (&arg)[VEC]) {
+constexpr uint32_t kNoArg32 = 0xFFFFFFFFu;  // in-kernel args are 32-bit offsets from the partition's first edge
+
+template <typename T, int VEC, int RED, typename ARG>
+__device__ __forceinline__ void init_acc(typename Traits<T>::acc_t (&val)[VEC], ARG (&arg)[VEC]) {
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     if constexpr (RED == RED_ADD) val[j] = 0;
     else if constexpr (RED == RED_MIN) val[j] = Traits<T>::max_init();
     else val[j] = Traits<T>::lowest_init();
-    arg[j] = kNoArg;
+    arg[j] = (ARG)(sizeof(ARG) == 4 ? (int64_t)kNoArg32 : kNoArg);
   }
 }
 
-// Accumulate window entries [lo, hi) (window-relative, 0..64) of one row.
+// Accumulate window entries [lo, hi) (window-relative, 0..64) of one row.  `wrel` is the window's
+// offset from the partition's first edge (min/max args are kept as 32-bit offsets).
 // c_l / w_l hold the window's column ids / weights, one per lane.  All lanes
 // stay active; slots past `hi` re-read the last valid entry and are masked.
 template <typename T, int VEC, int RED>
 __device__ __forceinline__ void accumulate_window(
-    int lo, int hi, int64_t wbase, uint32_t c_l, typename Traits<T>::acc_t w_l,
+    int lo, int hi, uint32_t wrel, uint32_t c_l, typename Traits<T>::acc_t w_l, bool has_value,
     const T *__restrict__ matk, uint32_t K, int lgG, int g,
-    typename Traits<T>::acc_t (&val)[VEC], int64_t (&arg)[VEC]) {
+    typename Traits<T>::acc_t (&val)[VEC], uint32_t (&arg)[VEC]) {
   using A = typename Traits<T>::acc_t;
   using P = Pack<T, VEC>;
   const int n = hi - lo;
@@ -216,11 +218,12 @@ __device__ __forceinline__ void accumulate_window(
           const A p = w[u] * xv;
           val[j] += ok ? p : A(0);
         } else {
-          const A p = Traits<T>::round_acc(w[u] * xv);
+          // without values the candidate is the stored element itself (no product to round)
+          const A p = has_value ? Traits<T>::round_acc(w[u] * xv) : xv;
           const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
           if (ok && better) {
             val[j] = p;
-            arg[j] = wbase + idx[u];
+            arg[j] = wrel + (uint32_t)idx[u];
           }
         }
       }
@@ -229,8 +232,8 @@ __device__ __forceinline__ void accumulate_window(
 }
 
 // Butterfly over the G groups; afterwards every lane holds the combined result.
-template <typename A, int VEC, int RED>
-__device__ __forceinline__ void reduce_groups(int lgG, A (&val)[VEC], int64_t (&arg)[VEC]) {
+template <typename A, int VEC, int RED, typename ARG>
+__device__ __forceinline__ void reduce_groups(int lgG, A (&val)[VEC], ARG (&arg)[VEC]) {
   for (int off = 32; off >= (64 >> lgG); off >>= 1) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -238,7 +241,7 @@ __device__ __forceinline__ void reduce_groups(int lgG, A (&val)[VEC], int64_t (&
       if constexpr (RED == RED_ADD) {
         val[j] += o;
       } else {
-        const int64_t oa = lane_xor(arg[j], off);
+        const ARG oa = lane_xor(arg[j], off);
         const bool better = RED == RED_MIN ? (o < val[j]) : (o > val[j]);
         if (better || (o == val[j] && oa < arg[j])) {
           val[j] = o;
@@ -376,8 +379,14 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
 
   int64_t e = e0;
   A val[VEC];
-  int64_t arg[VEC];
+  uint32_t arg[VEC];    // offsets from e0
+  int64_t arg64[VEC];   // absolute edge ids, only materialised when a row is written
   init_acc<T, VEC, RED>(val, arg);
+  const bool has_value = value != nullptr;
+  auto widen_args = [&]() {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) arg64[j] = arg[j] == kNoArg32 ? kNoArg : e0 + (int64_t)arg[j];
+  };
 
   // Windows alternate between two register sets (A = c_cur/w_cur, B = c_nxt/w_nxt): window k is
   // consumed from one set while window k+1 is already in flight into the other, and the set just
@@ -407,8 +416,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
       }
       const int64_t stop = rend < wend ? rend : wend;
       if (e < stop) {
-        accumulate_window<T, VEC, RED>((int)(e - wbase), (int)(stop - wbase), wbase, c_w, w_w, matk,
-                                       K, lgG, g, val, arg);
+        accumulate_window<T, VEC, RED>((int)(e - wbase), (int)(stop - wbase), (uint32_t)(wbase - e0),
+                                       c_w, w_w, has_value, matk, K, lgG, g, val, arg);
         e = stop;
       }
       if (e < rend) return false;  // window exhausted inside the row
@@ -416,11 +425,12 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
       // row r ends here
       if (estart < rend) reduce_groups<A, VEC, RED>(lgG, val, arg);
       if (writer) {
+        if constexpr (RED != RED_ADD) widen_args();
         if (incoming && r == r0) {  // head of a cut row: the fix-up kernel finishes it
-          write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg);
+          write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg64);
         } else {
           const uint64_t o = out_b + (uint64_t)r * K;
-          write_row<T, VEC, RED>(out + o, arg_out + o, val, arg, rend - estart, mean, E);
+          write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, rend - estart, mean, E);
         }
       }
       init_acc<T, VEC, RED>(val, arg);
@@ -439,7 +449,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
   // tail: the piece of the unfinished row r1 that falls into this partition
   if (r1 < M && estart < e1) {
     reduce_groups<A, VEC, RED>(lgG, val, arg);
-    if (writer) write_carry<T, VEC, RED>(ws.tail_val, ws.tail_arg, carry_off, val, arg);
+    if constexpr (RED != RED_ADD) widen_args();
+    if (writer) write_carry<T, VEC, RED>(ws.tail_val, ws.tail_arg, carry_off, val, arg64);
     trow = r1;
   }
   if (y == 0 && lane == 0) ws.tail_row[p] = trow;

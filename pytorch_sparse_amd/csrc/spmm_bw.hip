@@ -113,6 +113,16 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_value_bw_kernel(
 // ---------------------------------------------------------------------------
 // min/max backward: one thread per output element (b, m, k).
 // ---------------------------------------------------------------------------
+template <typename ACC>
+__device__ inline ACC wave_sum(ACC v) {
+  for (int off = 32; off > 0; off >>= 1) v += lane_xor(v, off);
+  return v;
+}
+
+// One thread per output element (b, m, k).  grad_mat targets are distinct within a wave
+// (same row, consecutive k), so they go out as plain atomics.  grad_value targets repeat a lot
+// (the same neighbour usually wins many features of a row): equal targets are summed inside
+// the wave first, one atomic per distinct edge, instead of up to 64 same-address atomics.
 template <typename T, typename ACC>
 __global__ void spmm_minmax_bw_kernel(const int64_t *__restrict__ col, const T *__restrict__ value,
                                       const T *__restrict__ mat, const T *__restrict__ grad_out,
@@ -120,18 +130,34 @@ __global__ void spmm_minmax_bw_kernel(const int64_t *__restrict__ col, const T *
                                       ACC *__restrict__ gmat, int64_t M, int64_t N, int64_t K,
                                       int64_t E, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int64_t a = arg_out[i];
-  if (a == E) return;  // empty row / no winner: masked out (spmm.cpp:210)
-  const int64_t k = i % K;
-  const int64_t b = i / (M * K);
-  const int64_t c = col[a];
-  const ACC g = (ACC)Traits<T>::to_acc(grad_out[i]);
-  const uint64_t xoff = ((uint64_t)b * N + c) * K + k;
-  if (gval != nullptr) atomicAdd(&gval[a], (ACC)Traits<T>::to_acc(mat[xoff]) * g);
-  if (gmat != nullptr) {
-    const ACC v = value != nullptr ? (ACC)Traits<T>::to_acc(value[a]) : ACC(1);
-    atomicAdd(&gmat[xoff], v * g);
+  const int lane = (int)(threadIdx.x & 63);
+  int64_t a = E;
+  if (i < total) a = arg_out[i];
+  const bool valid = a != E;  // empty row / no winner: masked out (spmm.cpp:210)
+  ACC contrib = ACC(0);
+  if (valid) {
+    const int64_t k = i % K;
+    const int64_t b = i / (M * K);
+    const int64_t c = col[a];
+    const ACC g = (ACC)Traits<T>::to_acc(grad_out[i]);
+    const uint64_t xoff = ((uint64_t)b * N + c) * K + k;
+    if (gval != nullptr) contrib = (ACC)Traits<T>::to_acc(mat[xoff]) * g;
+    if (gmat != nullptr) {
+      const ACC v = value != nullptr ? (ACC)Traits<T>::to_acc(value[a]) : ACC(1);
+      atomicAdd(&gmat[xoff], v * g);
+    }
+  }
+  if (gval == nullptr) return;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {  // wave-uniform loop over the distinct targets
+    const int leader = __ffsll((long long)todo) - 1;
+    const int64_t a0 = lane_read(a, leader);
+    const bool mine = valid && a == a0;
+    const unsigned long long same = __ballot(mine);
+    ACC s = contrib;
+    if (__popcll(same) > 1) s = wave_sum<ACC>(mine ? contrib : ACC(0));
+    if (lane == leader) atomicAdd(&gval[a0], s);
+    todo &= ~same;
   }
 }
 
