@@ -35,20 +35,25 @@ __global__ void decode_keys_kernel(const int64_t *__restrict__ keys, int64_t n, 
 }
 
 // counts[0] += #{i : key[i] < key[i-1]}, counts[1] += #{i : key[i] == key[i-1]}
-__global__ void order_probe_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
-                                   int64_t n, int64_t ncols, unsigned long long *counts) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool desc = false, dup = false;
-  if (i > 0 && i < n) {
+// grid-stride with per-thread counters: one pair of atomics per wave at the very end
+__global__ __launch_bounds__(256) void order_probe_kernel(const int64_t *__restrict__ row,
+                                                         const int64_t *__restrict__ col, int64_t n,
+                                                         int64_t ncols, unsigned long long *counts) {
+  unsigned int desc = 0, dup = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t a = row[i - 1] * ncols + col[i - 1];
     const int64_t b = row[i] * ncols + col[i];
-    desc = b < a;
-    dup = b == a;
+    desc += b < a;
+    dup += b == a;
   }
-  const unsigned long long md = __ballot(desc), mu = __ballot(dup);
+  for (int off = 32; off > 0; off >>= 1) {
+    desc += lane_xor(desc, off);
+    dup += lane_xor(dup, off);
+  }
   if ((threadIdx.x & 63) == 0) {
-    if (md) atomicAdd(&counts[0], (unsigned long long)__popcll(md));
-    if (mu) atomicAdd(&counts[1], (unsigned long long)__popcll(mu));
+    if (desc) atomicAdd(&counts[0], (unsigned long long)desc);
+    if (dup) atomicAdd(&counts[1], (unsigned long long)dup);
   }
 }
 
@@ -161,8 +166,9 @@ extern "C" int tsamd_coo_order(const int64_t *row, const int64_t *col, int64_t E
   TSAMD_HIP_TRY(hipMemsetAsync(counts_out, 0, 2 * sizeof(int64_t), stream));
   if (E <= 1) return TSAMD_OK;
   if (!row || !col) return TSAMD_ERR_INVALID;
-  hipLaunchKernelGGL(order_probe_kernel, dim3((unsigned int)ceil_div(E, 256)), dim3(256), 0, stream,
-                     row, col, E, N, reinterpret_cast<unsigned long long *>(counts_out));
+  const int64_t nblk = ceil_div(E, 256);
+  hipLaunchKernelGGL(order_probe_kernel, dim3((unsigned int)(nblk < 2048 ? nblk : 2048)), dim3(256), 0,
+                     stream, row, col, E, N, reinterpret_cast<unsigned long long *>(counts_out));
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }

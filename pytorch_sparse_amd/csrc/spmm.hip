@@ -194,14 +194,16 @@ __device__ __forceinline__ void accumulate_window(
     typename Traits<T>::acc_t (&val)[VEC], uint32_t (&arg)[VEC]) {
   using A = typename Traits<T>::acc_t;
   using P = Pack<T, VEC>;
+  // min/max carry (value, arg) per element: fewer gathers in flight keep the VGPR count down
+  constexpr int kU = RED == RED_ADD ? kUnroll : (kUnroll > 2 ? 2 : kUnroll);
   const int n = hi - lo;
   const int nsteps = (n + (1 << lgG) - 1) >> lgG;
-  for (int s = 0; s < nsteps; s += kUnroll) {
-    P x[kUnroll];
-    A w[kUnroll];
-    int idx[kUnroll];
+  for (int s = 0; s < nsteps; s += kU) {
+    P x[kU];
+    A w[kU];
+    int idx[kU];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < kU; ++u) {
       idx[u] = lo + ((s + u) << lgG) + g;
       const int src = idx[u] < hi ? idx[u] : hi - 1;
       const uint32_t c = lane_read(c_l, src);
@@ -209,7 +211,7 @@ __device__ __forceinline__ void accumulate_window(
       x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
     }
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
+    for (int u = 0; u < kU; ++u) {
       const bool ok = idx[u] < hi;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -529,8 +531,12 @@ void plan_partition(int64_t M, int64_t E, int64_t *P, int64_t *items) {
 }
 
 // The relabelled copy only pays off for big problems whose rows are 16-byte packets.
+// Cost: one read + one write of mat (2 * N rows); gain: ~30 % of the time to gather E rows.
+// It therefore needs E >= ~7 N; 8 N is used (a row-sharded block with few edges per column of
+// the gathered X -- the multi-GPU case -- does not qualify).
 bool relabel_possible(int dtype, int64_t N, int64_t K, int64_t E) {
-  return E >= (1 << 20) && N >= 4096 && N < ((int64_t)1 << 32) && (K * (int64_t)dtype_size(dtype)) % 16 == 0;
+  return E >= (1 << 20) && N >= 4096 && N < ((int64_t)1 << 32) && E >= 8 * N &&
+         (K * (int64_t)dtype_size(dtype)) % 16 == 0;
 }
 
 size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,

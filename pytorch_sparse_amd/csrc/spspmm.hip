@@ -39,8 +39,7 @@ enum { ST_P = 0, ST_NSMALL = 1, ST_NMEDIUM = 2, ST_NLARGE = 3, ST_PLARGE = 4, ST
 
 __global__ __launch_bounds__(256) void spspmm_count_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
-    const int64_t *__restrict__ rowptrB, int64_t M, int64_t *__restrict__ prod,
-    int64_t *__restrict__ bins, unsigned long long *stats) {
+    const int64_t *__restrict__ rowptrB, int64_t M, int64_t *__restrict__ prod) {
   const int lane = (int)(threadIdx.x & 63);
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= M) return;
@@ -51,14 +50,29 @@ __global__ __launch_bounds__(256) void spspmm_count_kernel(
     p += rowptrB[c + 1] - rowptrB[c];
   }
   for (int off = 32; off > 0; off >>= 1) p += lane_xor(p, off);
-  if (lane == 0) {
-    prod[i] = p;
-    if (p > 0) {
-      const int b = p <= kSmallCap ? 0 : (p <= kMediumCap ? 1 : 2);
-      const unsigned long long slot = atomicAdd(&stats[ST_NSMALL + b], 1ull);
-      bins[(int64_t)b * M + (int64_t)slot] = i;
-      if (b == 2) atomicAdd(&stats[ST_PLARGE], (unsigned long long)p);
-    }
+  if (lane == 0) prod[i] = p;
+}
+
+// Bin rows by product count.  One thread per row; a wave reserves its slots in each bin with a
+// single atomic (ballot + popcount) instead of one atomic per row on three hot counters.
+__global__ __launch_bounds__(256) void spspmm_bin_kernel(const int64_t *__restrict__ prod, int64_t M,
+                                                        int64_t *__restrict__ bins,
+                                                        unsigned long long *stats) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p = i < M ? prod[i] : 0;
+  const int b = p == 0 ? -1 : (p <= kSmallCap ? 0 : (p <= kMediumCap ? 1 : 2));
+  for (int bin = 0; bin < 3; ++bin) {
+    const unsigned long long m = __ballot(b == bin);
+    if (m == 0) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&stats[ST_NSMALL + bin], (unsigned long long)__popcll(m));
+    base = (unsigned long long)lane_read((int64_t)base, 0);
+    if (b == bin) bins[(int64_t)bin * M + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+  }
+  if (b == 2) {
+    int64_t pl = p;  // products in large rows (few rows: per-row atomics are fine)
+    atomicAdd(&stats[ST_PLARGE], (unsigned long long)pl);
   }
 }
 
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void spspmm_row_kernel(
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = tid; t < (n2 >> 1); t += BLOCK) {
-        const int a = ((t / j) * 2 * j) + (t % j);
+        const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two
         const int b = a + j;
         const bool up = (a & k) == 0;
         const uint32_t ca = scol[a], cb = scol[b];
@@ -379,8 +393,10 @@ extern "C" int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA,
   if (!rowptrA || !rowptrB || !bins) return TSAMD_ERR_INVALID;
   if (!workspace || workspace_bytes < scan_workspace_bytes(M + 1)) return TSAMD_ERR_WORKSPACE;
   hipLaunchKernelGGL(spspmm_count_kernel, dim3((unsigned int)ceil_div(M, 4)), dim3(256), 0, stream,
-                     rowptrA, colA, rowptrB, M, prodptr, bins,
-                     reinterpret_cast<unsigned long long *>(stats));
+                     rowptrA, colA, rowptrB, M, prodptr);
+  TSAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(spspmm_bin_kernel, dim3((unsigned int)ceil_div(M, 256)), dim3(256), 0, stream,
+                     (const int64_t *)prodptr, M, bins, reinterpret_cast<unsigned long long *>(stats));
   TSAMD_LAUNCH_CHECK();
   // prodptr[0..M) holds counts, prodptr[M] = 0: the scan over M + 1 entries leaves the total there
   return exclusive_scan_i64(prodptr, prodptr, M + 1, stats + ST_P, workspace, stream);
