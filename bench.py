@@ -58,13 +58,13 @@ def local_block(scale, edge_factor, world, rank, device):
     m = 1 << scale
     n = m * world
     row, col = synth.rmat_edges(scale, edge_factor, seed=1000 * rank, device=device)
-    if extra:  # extra high column bits, drawn from the R-MAT column marginal (a + c = 0.76)
+    if extra:
         g = torch.Generator(device=device)
         g.manual_seed(77 + rank)
-        hi = torch.zeros_like(col)
-        for _ in range(extra):
-            bit = (torch.rand(col.numel(), generator=g, device=device) >= 0.76).to(torch.int64)
-            hi = (hi << 1) | bit
+        # owner of each referenced column: uniform over the ranks (vertices are assumed to be
+        # partitioned at random, the usual practice), the position inside the owner's block keeps
+        # the R-MAT skew
+        hi = torch.randint(0, world, (col.numel(), ), generator=g, device=device)
         col = hi * m + col
     rowptr, col = synth.to_csr(row, col, m, n)
     return rowptr, col, m, n
@@ -142,6 +142,8 @@ def main():
     ap.add_argument('--workload', default='ns', choices=sorted(WORKLOADS))
     ap.add_argument('--reduce', default='sum', choices=['sum', 'mean', 'min', 'max'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--exchange', default='halo', choices=['halo', 'allgather'],
+                    help='N > 1: move only the rows of X a rank references (all_to_all) or all of X (all_gather)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -166,19 +168,30 @@ def main():
     E = col.numel()
     value = synth.values(E, seed=1 + rank, device=dev)
     x_local = synth.features(m_local, F, seed=2 + rank, device=dev)
-    x_full = torch.empty(n_global, F, device=dev) if world > 1 else x_local
-
     import pytorch_sparse_amd  # noqa: F401  (registers torch.ops.torch_sparse.*)
-    op = {'sum': lambda: torch.ops.torch_sparse.spmm_sum(None, rowptr, col, value, None, None, x_full),
-          'mean': lambda: torch.ops.torch_sparse.spmm_mean(None, rowptr, col, value, None, None, None, x_full),
-          'min': lambda: torch.ops.torch_sparse.spmm_min(rowptr, col, value, x_full)[0],
-          'max': lambda: torch.ops.torch_sparse.spmm_max(rowptr, col, value, x_full)[0]}[args.reduce]
+    from pytorch_sparse_amd.parallel import HaloShardedSpMM, RowShardedSpMM
+
+    def op_spmm(rp, c, v, x, reduce):
+        # the drop-in path: the reference's own operator names, served by the HIP kernels
+        if reduce == 'sum':
+            return torch.ops.torch_sparse.spmm_sum(None, rp, c, v, None, None, x)
+        if reduce == 'mean':
+            return torch.ops.torch_sparse.spmm_mean(None, rp, c, v, None, None, None, x)
+        if reduce == 'min':
+            return torch.ops.torch_sparse.spmm_min(rp, c, v, x)[0]
+        return torch.ops.torch_sparse.spmm_max(rp, c, v, x)[0]
+
+    x_sizes = [m_local] * world
+    cls = HaloShardedSpMM if (world > 1 and args.exchange == 'halo') else RowShardedSpMM
+    sharded = cls(rowptr, col, value, x_sizes, None, op_spmm)  # plans the exchange once (setup)
+    comm_rows = getattr(sharded, 'n_needed', n_global) if world > 1 else 0
 
     def step():
-        # the drop-in path: the reference's own operator name, served by the HIP kernels
-        if world > 1:
-            dist.all_gather_into_tensor(x_full, x_local)
-        return op()
+        with torch.no_grad():
+            return sharded(x_local, args.reduce)  # (RCCL exchange of X rows,) then the local SpMM
+
+    x_full = sharded.gather(x_local) if isinstance(sharded, RowShardedSpMM) else sharded.exchange(x_local)
+    col_k = sharded.col  # column ids as the kernel sees them (compacted for the halo exchange)
 
     for _ in range(args.warmup):
         step()
@@ -213,7 +226,7 @@ def main():
         prof = []
         merge_ms = []
         for _ in range(10):
-            nat.spmm(rowptr, col, value, x_full, args.reduce, profile=prof)
+            nat.spmm(rowptr, col_k, value, x_full, args.reduce, profile=prof)
             merge_ms.append(prof[1])
         merge_ms.sort()
         k_ms = sum(merge_ms) / len(merge_ms)
@@ -238,14 +251,14 @@ def main():
                     config=dict(workload=wl['desc'], reduce=args.reduce, rows_per_gpu=m_local,
                                 cols=n_global, edges_per_gpu=E, features=F,
                                 graph='R-MAT(0.57,0.19,0.19,0.05) scale %d edge factor %d, coalesced' % (scale, ef),
-                                parallelism='row-sharded x%d%s' % (world, ', RCCL all-gather of X' if world > 1 else '')),
+                                parallelism='row-sharded x%d%s' % (world, (', RCCL %s of X rows (%d rows in per rank)' % ('all_to_all' if args.exchange == 'halo' else 'all_gather', comm_rows)) if world > 1 else '')),
                     roofline=roofline)
         if world == 1:
-            worst = parity_sample(rowptr, col, value, x_full, out, args.reduce) if not minmax else None
+            worst = parity_sample(rowptr, col_k, value, x_full, out, args.reduce) if not minmax else None
             line['parity'] = dict(rows_checked=50, max_err_over_l1=worst, tol=1e-5,
                                   ok=(worst is None or worst <= 1e-5))
             if not args.no_cpu_baseline:
-                line['cpu_baseline'] = cpu_baseline(rowptr, col, value, x_full, args.reduce)
+                line['cpu_baseline'] = cpu_baseline(rowptr, col_k, value, x_full, args.reduce)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

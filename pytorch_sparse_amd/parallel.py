@@ -4,9 +4,11 @@ The reference has no distributed code; its slicing primitive ``narrow(src, 0, st
 (torch_sparse/narrow.py:15-42) defines what a row shard is: ``rowptr[start:start+length+1] -
 rowptr[start]`` with the matching slices of ``col`` / ``value`` and *global* column ids.
 
-Path per step (BASELINE.json north_star):
+Path per step (BASELINE.json north_star), class ``RowShardedSpMM``:
     X_full = all_gather(X_local)           RCCL, the only data-path collective
     out_local = A_local @ X_full           tsamd_spmm on the local row block
+``HaloShardedSpMM`` is the same computation with the collective reduced to the rows of X the local
+block references (all_to_all_single with uneven splits, planned once per matrix).
 The output stays row-sharded, so there is no reduce step in the forward.  In the backward the
 gradient of X is a partial sum on every rank and is reduce-scattered to its owners; the gradient
 of the sparse values is local.
@@ -116,8 +118,91 @@ class RowShardedSpMM(object):
         return self.spmm_fn(self.rowptr, self.col, self.value, self.gather(x_local), reduce)
 
 
+class _ExchangeRows(torch.autograd.Function):
+    """all_to_all of the feature rows each rank asked for; backward routes the gradient of every
+    received row back to its owner and adds it up there."""
+
+    @staticmethod
+    def forward(ctx, x_local: Tensor, serve_idx: Tensor, send_counts, recv_counts, group):
+        ctx.group, ctx.send_counts, ctx.recv_counts = group, list(send_counts), list(recv_counts)
+        ctx.save_for_backward(serve_idx)
+        ctx.n_local = x_local.size(0)
+        send = x_local.index_select(0, serve_idx)  # rows packed by requesting rank
+        recv = x_local.new_empty((sum(recv_counts), ) + tuple(x_local.shape[1:]))
+        dist.all_to_all_single(recv, send, output_split_sizes=ctx.recv_counts,
+                               input_split_sizes=ctx.send_counts, group=group)
+        return recv
+
+    @staticmethod
+    def backward(ctx, grad_recv: Tensor):
+        (serve_idx, ) = ctx.saved_tensors
+        grad_recv = grad_recv.contiguous()
+        back = grad_recv.new_empty((sum(ctx.send_counts), ) + tuple(grad_recv.shape[1:]))
+        dist.all_to_all_single(back, grad_recv, output_split_sizes=ctx.send_counts,
+                               input_split_sizes=ctx.recv_counts, group=ctx.group)
+        grad_local = grad_recv.new_zeros((ctx.n_local, ) + tuple(grad_recv.shape[1:]))
+        grad_local.index_add_(0, serve_idx, back)
+        return grad_local, None, None, None, None
+
+
+class HaloShardedSpMM(object):
+    """Row-sharded SpMM that moves only the rows of X a rank's block actually references.
+
+    An all-gather ships (P-1)/P of X to every rank although a row block with E_local entries
+    touches at most E_local (on power-law graphs far fewer) distinct columns; its cost grows with
+    the number of ranks while the compute per rank stays constant.  Here the set of referenced
+    columns is computed once per matrix (``unique(col)``), each owner learns which of its rows every
+    other rank needs (one index all_to_all at setup), and a step is
+
+        packed = X_local[serve_idx]                  (gather kernel)
+        X_need = all_to_all_single(packed)           (RCCL, uneven splits, the only collective)
+        out_local = A_local' @ X_need                (A_local' = A_local with compacted column ids)
+
+    Same result as ``RowShardedSpMM``: the compaction is a relabelling of columns.
+    """
+
+    def __init__(self, rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
+                 group=None, spmm_fn: Optional[Callable] = None):
+        self.group = group
+        self.spmm_fn = spmm_fn or _default_spmm
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert len(x_sizes) == self.world
+        self.rowptr, self.value = rowptr, value
+        self.x_sizes = list(x_sizes)
+        if self.world == 1:
+            self.col = col
+            return
+        dev = col.device
+        needed = torch.unique(col)  # sorted global column ids this block touches
+        bounds = torch.tensor([0] + list(torch.tensor(self.x_sizes).cumsum(0).tolist()), device=dev)
+        cuts = torch.searchsorted(needed, bounds)  # needed[cuts[r]:cuts[r+1]] live on rank r
+        self.recv_counts = (cuts[1:] - cuts[:-1]).tolist()
+        # tell every owner how many rows we want, then which ones (owner-local row ids)
+        want = torch.tensor(self.recv_counts, dtype=torch.int64, device=dev)
+        serve = torch.empty_like(want)
+        dist.all_to_all_single(serve, want, group=group)
+        self.send_counts = serve.tolist()
+        owner_base = torch.repeat_interleave(bounds[:-1], want)
+        req_local = needed - owner_base
+        self.serve_idx = torch.empty(sum(self.send_counts), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(self.serve_idx, req_local, output_split_sizes=self.send_counts,
+                               input_split_sizes=self.recv_counts, group=group)
+        self.col = torch.searchsorted(needed, col)  # compact ids = positions in X_need
+        self.n_needed = needed.numel()
+
+    def exchange(self, x_local: Tensor) -> Tensor:
+        if self.world == 1:
+            return x_local
+        return _ExchangeRows.apply(x_local, self.serve_idx, self.send_counts, self.recv_counts,
+                                   self.group)
+
+    def __call__(self, x_local: Tensor, reduce: str = 'sum') -> Tensor:
+        return self.spmm_fn(self.rowptr, self.col, self.value, self.exchange(x_local), reduce)
+
+
 def shard_matrix(rowptr: Tensor, col: Tensor, value: Optional[Tensor], n_cols: int, group=None,
-                 balance: str = 'nnz', spmm_fn: Optional[Callable] = None) -> Tuple[RowShardedSpMM, Tuple[int, int]]:
+                 balance: str = 'nnz', spmm_fn: Optional[Callable] = None, exchange: str = 'allgather'):
     """Convenience for a replicated global CSR: every rank cuts out its own row block.  X is
     sharded by the same row ranges when the matrix is square (GNN layers chain that way),
     otherwise in equal blocks of columns."""
@@ -131,4 +216,5 @@ def shard_matrix(rowptr: Tensor, col: Tensor, value: Optional[Tensor], n_cols: i
         x_sizes = [(n_cols * (p + 1)) // world - (n_cols * p) // world for p in range(world)]
     s, e = ranges[rank]
     rp, c, v = narrow_rows(rowptr, col, value, s, e)
-    return RowShardedSpMM(rp, c, v, x_sizes, group, spmm_fn), (s, e)
+    cls = {'allgather': RowShardedSpMM, 'halo': HaloShardedSpMM}[exchange]
+    return cls(rp, c, v, x_sizes, group, spmm_fn), (s, e)

@@ -35,7 +35,7 @@ def torch_spmm_sum(rowptr, col, value, x, reduce):
     return torch.zeros(rowptr.numel() - 1, x.size(1), dtype=x.dtype).index_add_(0, row, value[:, None] * x[col])
 
 
-def _worker(rank, world, port, balance, q):
+def _worker(rank, world, port, balance, q, exchange='allgather'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -45,7 +45,7 @@ def _worker(rank, world, port, balance, q):
         v = synth.values(c.numel())
         x = synth.features(n, 12)
         # forward parity for every reduction, local multiply = C oracle
-        op, (s, e) = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=oracle_spmm)
+        op, (s, e) = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=oracle_spmm, exchange=exchange)
         sizes = op.x_sizes
         xs = sum(sizes[:rank])
         x_local = x[xs:xs + sizes[rank]].clone()
@@ -55,7 +55,7 @@ def _worker(rank, world, port, balance, q):
             full, _ = oc.spmm(oc.F32, reduce, rp.numpy(), c.numpy(), v.numpy(), x.numpy())
             res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]))
         # backward: grad of x must be reduce-scattered to the owning rank
-        opd, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=torch_spmm_sum)
+        opd, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=torch_spmm_sum, exchange=exchange)
         xl = x_local.clone().requires_grad_()
         gout = synth.features(n, 12, seed=5)[s:e]
         opd(xl, 'sum').backward(gout)
@@ -68,12 +68,13 @@ def _worker(rank, world, port, balance, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('balance', ['nnz', 'rows'])
-def test_row_sharded_spmm_gloo_world2(balance):
+@pytest.mark.parametrize('balance,exchange', [('nnz', 'allgather'), ('rows', 'allgather'),
+                                              ('nnz', 'halo'), ('rows', 'halo')])
+def test_row_sharded_spmm_gloo_world2(balance, exchange):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, balance, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, balance, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=240) for _ in procs)
@@ -108,3 +109,22 @@ def test_partition_and_narrow():
     # degenerate: more parts than rows with entries
     rp2 = torch.tensor([0, 0, 5, 5])
     assert partition_rows(rp2, 4, 'nnz')[-1][1] == 3
+
+
+def test_halo_exchange_gloo_world4():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, 'nnz', q, 'halo')) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results.items():
+        for k in ('sum', 'mean', 'min', 'max', 'grad'):
+            assert res[k], (rank, k)
+    ends = sorted(results[r]['range'] for r in range(4))
+    assert ends[0][0] == 0 and ends[-1][1] == 1 << 9
+    assert all(ends[i][1] == ends[i + 1][0] for i in range(3))
