@@ -273,7 +273,18 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
       asm volatile("" : "+v"(val[j]));  // keep the mean / non-mean paths from splitting the 16-byte store
       o.v[j] = Traits<T>::from_acc(val[j]);
     }
+#if !defined(TSAMD_NO_NT_STORE)
+    // output rows are written once and never re-read by this kernel: a non-temporal store keeps
+    // them from evicting gathered rows of `mat` from L2 (+1.5-2 % measured)
+    if constexpr (sizeof(Pack<T, VEC>) == 16) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(*reinterpret_cast<u32x4 *>(&o), reinterpret_cast<u32x4 *>(outk));
+    } else {
+      *reinterpret_cast<Pack<T, VEC> *>(outk) = o;
+    }
+#else
     *reinterpret_cast<Pack<T, VEC> *>(outk) = o;
+#endif
   } else {
     Pack<int64_t, VEC> a;
 #pragma unroll
@@ -357,7 +368,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
     c_l = 0;
     w_l = A(1);
     if (e < e1) {
+#if defined(TSAMD_NT_LOAD)
+      c_l = (uint32_t)__builtin_nontemporal_load(col + e);
+#else
       c_l = (uint32_t)col[e];
+#endif
       if (relabel) c_l = hash_row(c_l, (uint32_t)N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
       if (value != nullptr) w_l = Traits<T>::to_acc(value[e]);
     }
