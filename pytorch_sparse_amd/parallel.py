@@ -178,6 +178,19 @@ class HaloShardedSpMM(object):
         bounds = torch.tensor([0] + list(torch.tensor(self.x_sizes).cumsum(0).tolist()), device=dev)
         cuts = torch.searchsorted(needed, bounds)  # needed[cuts[r]:cuts[r+1]] live on rank r
         self.recv_counts = (cuts[1:] - cuts[:-1]).tolist()
+        # The order of the rows inside each owner's chunk of X_need is ours to choose, and compact
+        # column ids are just positions in X_need.  A seeded random order per chunk scatters the hub
+        # columns of Kronecker-like graphs over the memory channels for free (what tsamd_spmm's
+        # "relabel" copy buys on a single GPU) -- results do not depend on it.
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x5eed + self.rank)
+        owner = torch.repeat_interleave(torch.arange(self.world, device=dev),
+                                        torch.tensor(self.recv_counts, device=dev))
+        order = torch.argsort(owner.double() + torch.rand(needed.numel(), generator=g, device=dev).double())
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=dev)
+        sorted_needed = needed
+        needed = needed[order]  # chunked by owner, shuffled inside each chunk
         # tell every owner how many rows we want, then which ones (owner-local row ids)
         want = torch.tensor(self.recv_counts, dtype=torch.int64, device=dev)
         serve = torch.empty_like(want)
@@ -188,7 +201,7 @@ class HaloShardedSpMM(object):
         self.serve_idx = torch.empty(sum(self.send_counts), dtype=torch.int64, device=dev)
         dist.all_to_all_single(self.serve_idx, req_local, output_split_sizes=self.send_counts,
                                input_split_sizes=self.recv_counts, group=group)
-        self.col = torch.searchsorted(needed, col)  # compact ids = positions in X_need
+        self.col = inv[torch.searchsorted(sorted_needed, col)]  # compact ids = positions in X_need
         self.n_needed = needed.numel()
 
     def exchange(self, x_local: Tensor) -> Tensor:

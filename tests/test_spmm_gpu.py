@@ -262,3 +262,30 @@ def test_full_size_properties(dev, config):
             prod = v[ai] * x[c[ai], torch.arange(K, device=dev)[None, :]]
             assert torch.equal(torch.where(valid, prod, torch.zeros_like(prod)), o)
             assert ((ai >= rp[:-1, None]) & (ai < rp[1:, None]) | ~valid).all()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float64])
+def test_relabel_path_is_bit_identical(dev, dtype, monkeypatch):
+    """The channel-camping avoidance (hashed-row copy of mat) only changes addresses:
+    forced on and forced off must give bit-identical results, batched input included, and the
+    N that is not a power of two exercises the cycle-walking hash."""
+    n, m, K = 9001, 5000, 8
+    g = torch.Generator().manual_seed(11)
+    E = 1300000
+    row, col = torch.randint(0, m, (E, ), generator=g), torch.randint(0, n, (E, ), generator=g)
+    col[::3] &= ~7  # low-bit skew, as the probe looks for
+    rp, c = synth.to_csr(row, col, m, n)
+    v, x = make_inputs(rp, c, n, K, dtype, True, batch=(2, ))
+    res = {}
+    for mode in ('0', '1', 'auto'):
+        monkeypatch.setenv('TSAMD_SPMM_RELABEL', mode)
+        for reduce in ('sum', 'max'):
+            out, arg = run_gpu(dev, rp, c, v, x, reduce)
+            res[(mode, reduce)] = (out.cpu(), None if arg is None else arg.cpu())
+    for reduce in ('sum', 'max'):
+        for mode in ('1', 'auto'):
+            assert bits_equal(res[('0', reduce)][0], res[(mode, reduce)][0]), (mode, reduce)
+        if reduce == 'max':
+            assert torch.equal(res[('0', reduce)][1], res[('1', reduce)][1])
+    check_spmm(res[('1', 'max')][0], res[('1', 'max')][1], rp, c, v, x, 'max')
+    check_spmm(res[('1', 'sum')][0], None, rp, c, v, x, 'sum')
