@@ -45,8 +45,11 @@ from .matmul import matmul, spmm_sum, spmm_mean, spmm_min, spmm_max, spspmm_sum 
 from .coalesce import coalesce  # noqa: E402
 from .spmm import spmm  # noqa: E402
 from .spspmm import spspmm  # noqa: E402
+from .reduce import sum, mean, min, max  # noqa: E402,A004
+from .mul import mul, mul_nnz, add  # noqa: E402
 
 __all__ = [
     'SparseStorage', 'SparseTensor', 't', 'transpose', 'matmul', 'coalesce', 'spmm', 'spspmm',
+    'sum', 'mean', 'min', 'max', 'mul', 'mul_nnz', 'add',
     '__version__',
 ]

@@ -82,7 +82,7 @@ __global__ void compact_heads_kernel(const int64_t *__restrict__ row, const int6
   }
 }
 
-constexpr int SEG_SUM = 0, SEG_MEAN = 1, SEG_MIN = 2, SEG_MAX = 3;
+constexpr int SEG_MEAN = 1, SEG_MIN = 2, SEG_MAX = 3;  // sum = 0
 
 template <typename T>
 __global__ void segment_reduce_kernel(const T *__restrict__ value, const int64_t *__restrict__ perm,
@@ -93,6 +93,10 @@ __global__ void segment_reduce_kernel(const T *__restrict__ value, const int64_t
   if (t >= nseg * D) return;
   const int64_t j = t / D, d = t - j * D;
   const int64_t s = seg_ptr[j], e = seg_ptr[j + 1];
+  if (s >= e) {  // empty segment -> 0 (torch_scatter's convention for segment_csr)
+    out[t] = Traits<T>::from_acc(A(0));
+    return;
+  }
   A acc = Traits<T>::to_acc(value[(perm ? perm[s] : s) * D + d]);
   for (int64_t i = s + 1; i < e; ++i) {
     const A v = Traits<T>::to_acc(value[(perm ? perm[i] : i) * D + d]);

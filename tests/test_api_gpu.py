@@ -279,3 +279,39 @@ def test_csr2csc_and_t_large(ts, dev):
     dense_check = (At @ x)  # A^T x through the forward kernel on the transposed storage
     ref = torch.zeros_like(x).index_add_(0, col, val[:, None] * x[row])
     assert torch.allclose(dense_check, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_reductions_and_broadcast_mul(ts, dev):
+    """reduce.py / mul.py against dense torch results; GCN normalisation."""
+    g = torch.Generator().manual_seed(2)
+    m, n = 700, 900
+    dense = torch.randn(m, n, generator=g) * (torch.rand(m, n, generator=g) < 0.02)
+    dense[100:140] = 0   # empty rows
+    dense[:, 5:60] = 0   # empty columns
+    A = ts.SparseTensor.from_dense(dense.to(dev))
+    mask = dense != 0
+    big = 1e30
+    assert torch.allclose(A.sum(dim=1).cpu(), dense.sum(1), atol=1e-5)
+    assert torch.allclose(A.sum(dim=0).cpu(), dense.sum(0), atol=1e-5)
+    cnt1, cnt0 = mask.sum(1).clamp(min=1), mask.sum(0).clamp(min=1)
+    assert torch.allclose(A.mean(dim=1).cpu(), dense.sum(1) / cnt1, atol=1e-5)
+    assert torch.allclose(A.mean(dim=0).cpu(), dense.sum(0) / cnt0, atol=1e-5)
+    mx1 = torch.where(mask, dense, torch.full_like(dense, -big)).max(1)[0]
+    mn0 = torch.where(mask, dense, torch.full_like(dense, big)).min(0)[0]
+    assert torch.equal(A.max(dim=1).cpu(), torch.where(mask.any(1), mx1, torch.zeros(m)))
+    assert torch.equal(A.min(dim=0).cpu(), torch.where(mask.any(0), mn0, torch.zeros(n)))
+    assert torch.allclose(A.sum().cpu(), dense.sum(), atol=1e-3)
+    P = A.set_value(None)
+    assert torch.equal(P.sum(dim=1).cpu(), mask.sum(1).float()) and torch.equal(P.sum(dim=0).cpu(), mask.sum(0).float())
+    # D^-1/2 A D^-1/2 through mul(row-wise) and mul(col-wise), then SpMM
+    Pn = P.fill_value(1.)
+    deg = Pn.sum(dim=1)
+    dinv = deg.clamp(min=1).pow(-0.5)
+    Asq = ts.SparseTensor.from_dense((mask[:, :m]).float().to(dev))
+    d = Asq.sum(dim=1).clamp(min=1).pow(-0.5)
+    norm = ts.mul(ts.mul(Asq, d.view(-1, 1)), d.view(1, -1))
+    ref = d.cpu()[:, None] * mask[:, :m].float() * d.cpu()[None, :]
+    assert torch.allclose(norm.to_dense().cpu(), ref, atol=1e-6)
+    x = torch.randn(m, 16, generator=g)
+    assert torch.allclose((norm @ x.to(dev)).cpu(), ref @ x, atol=1e-4)
+    assert dinv.numel() == m
