@@ -612,7 +612,8 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
       TSAMD_LAUNCH_CHECK();
     }
     if (mode != 0) {
-      hipLaunchKernelGGL((spmm_permute_rows_kernel<T, VEC>), dim3(4096), dim3(256), 0, stream, mat,
+      // the copy always moves 16-byte packets, whatever packet size the reduction kernel uses
+      hipLaunchKernelGGL((spmm_permute_rows_kernel<T, 16 / (int)sizeof(T)>), dim3(4096), dim3(256), 0, stream, mat,
                          reinterpret_cast<T *>(ws.xperm), B * N, (uint32_t)N, (uint32_t)K, ws);
       TSAMD_LAUNCH_CHECK();
     }
@@ -641,7 +642,10 @@ int dispatch_spmm(int reduce, bool vec_ok, const int64_t *rowptr, const int64_t 
                   const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
                   int64_t M, int64_t N, int64_t K, int64_t E, Workspace ws, hipStream_t stream,
                   hipEvent_t *ev) {
-  constexpr int kVec = 16 / (int)sizeof(T);
+  // Packet per lane: 16 bytes for 4/8-byte types; 8 bytes (4 elements) for f16/bf16 -- with 8
+  // elements per lane the per-element state (fp32 accumulator, and the arg for min/max) costs
+  // 80-84 VGPRs = 5 waves/SIMD, with 4 it is 8 waves/SIMD (measured +5...27 %).
+  constexpr int kVec = sizeof(T) == 2 ? 4 : 16 / (int)sizeof(T);
   const T *v = reinterpret_cast<const T *>(value);
   const T *x = reinterpret_cast<const T *>(mat);
   T *o = reinterpret_cast<T *>(out);
@@ -689,8 +693,9 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   Workspace ws;
   carve(workspace, dtype, reduce, B, M, N, K, E, &ws);
   const size_t es = dtype_size(dtype);
-  const bool vec_ok = (K * es) % 16 == 0 && ((uintptr_t)mat % 16 == 0) &&
-                      ((uintptr_t)out % 16 == 0) && (!minmax || (uintptr_t)arg_out % 64 == 0);
+  const size_t pk = es == 2 ? 8 : 16;  // packet bytes per lane (see dispatch_spmm)
+  const bool vec_ok = (K * es) % pk == 0 && ((uintptr_t)mat % pk == 0) &&
+                      ((uintptr_t)out % pk == 0) && (!minmax || (uintptr_t)arg_out % 64 == 0);
 
   return TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
     return dispatch_spmm<scalar_t>(reduce, vec_ok, rowptr, col, value, mat, out, arg_out, B, M, N,

@@ -97,3 +97,17 @@ if 'c4' in which:
         t0 = time.perf_counter(); Cc = torch.sparse.mm(Ac, Bc); res['cpu_torch_sparse_mm_s'] = round(time.perf_counter() - t0, 2)
         res['cpu_nnzC'] = Cc._nnz()
     print(json.dumps(res), flush=True)
+
+if 'narrow' in which:
+    # same graph, several dtypes / widths: B_alg changes with the element size
+    scale = 21
+    rp, c = synth.rmat_csr(scale, 20, seed=0, device=dev); n = 1 << scale; E = c.numel()
+    for dtype, K in ((torch.float32, 128), (torch.bfloat16, 128), (torch.float16, 128), (torch.float32, 64), (torch.bfloat16, 256), (torch.float64, 64), (torch.float32, 32), (torch.float32, 16), (torch.float32, 256), (torch.float32, 512)):
+        v = synth.values(E, dtype=dtype, device=dev); x = synth.features(n, K, dtype=dtype, device=dev)
+        for red in ('sum', 'max'):
+            t = gpu_time(lambda: nat.spmm(rp, c, v, x, red), iters=7)
+            s = x.element_size()
+            balg = E * (8 + s + K * s) + (n + 1) * 8 + n * K * s + (n * K * 8 if red == 'max' else 0)
+            print(json.dumps(dict(bench='spmm_ns_graph', dtype=str(dtype).split('.')[1], F=K, reduce=red, ms=round(t, 3), gedges=round(E / t / 1e6, 2),
+                                  balg_gbs=round(balg / t / 1e6, 1), frac_hbm=round(balg / t / 1e6 / 8000, 3))), flush=True)
+        del v, x
