@@ -7,7 +7,7 @@
 //
 // Pipeline (stages are separate C-ABI calls because the host allocates between them):
 //   plan     wave per row of A: products(i) = sum_{k in A_i} |B_k|; rows are binned
-//            (small <= 256 products, medium <= 4096, large) and an exclusive scan gives
+//            (small <= 1024 products, medium <= 4096, large) and an exclusive scan gives
 //            every row a slot of `products(i)` entries in a temporary (col, val) buffer.
 //   rows     small/medium rows: ONE workgroup (64 / 256 threads) expands the row's products
 //            straight into LDS (they never touch HBM), bitonic-sorts them by column in LDS,
@@ -31,7 +31,7 @@ extern "C" size_t tsamd_coalesce_workspace_bytes(int64_t);
 namespace tsamd {
 namespace {
 
-constexpr int kSmallCap = 256;    // products handled by one wave
+constexpr int kSmallCap = 1024;   // products handled by one wave (no workgroup barriers in its sort)
 constexpr int kMediumCap = 4096;  // products handled by one 256-thread workgroup
 
 // stats layout (device int64[8])
