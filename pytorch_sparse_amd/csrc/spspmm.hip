@@ -7,10 +7,11 @@
 //
 // Pipeline (stages are separate C-ABI calls because the host allocates between them):
 //   plan     wave per row of A: products(i) = sum_{k in A_i} |B_k|; rows are binned
-//            (small <= 1024 products, medium <= 4096, large) and an exclusive scan gives
+//            (small <= 512 products, medium <= 4096, large) and an exclusive scan gives
 //            every row a slot of `products(i)` entries in a temporary (col, val) buffer.
 //   rows     small/medium rows: ONE workgroup (64 / 256 threads) expands the row's products
-//            straight into LDS (they never touch HBM), bitonic-sorts them by column in LDS,
+//            straight into LDS (they never touch HBM), sorts them by column in LDS (one wave: stable
+//            radix sort with ballot ranking; 256 threads: bitonic),
 //            sums equal columns and writes the compressed row into its slot.
 //   large    rows whose products do not fit LDS are expanded to HBM and go through the
 //            global radix sort + coalesce + segmented sum (sort.hip / coalesce.hip).
@@ -31,7 +32,7 @@ extern "C" size_t tsamd_coalesce_workspace_bytes(int64_t);
 namespace tsamd {
 namespace {
 
-constexpr int kSmallCap = 1024;   // products handled by one wave (no workgroup barriers in its sort)
+constexpr int kSmallCap = 512;    // products handled by one wave (LDS radix sort, no workgroup barriers)
 constexpr int kMediumCap = 4096;  // products handled by one 256-thread workgroup
 
 // stats layout (device int64[8])
@@ -104,18 +105,100 @@ __device__ inline int block_exclusive_scan_small(int v, int *smem, int *total) {
   return base + inc - v;
 }
 
-// One workgroup per row: expand into LDS, bitonic sort by column, compress, write.
+// Stable LSD radix sort of n <= 512 (key, value) pairs in LDS by ONE wavefront: 8-bit digits,
+// ranks from 8 ballots per key (same scheme as radix_scatter_kernel in sort.hip), ping-pong
+// between two LDS buffers.  ~10x fewer dependent LDS round trips than a bitonic network.
+template <typename A>
+__device__ inline void wave_radix_sort_lds(uint32_t *&ka, A *&va, uint32_t *&kb, A *&vb, int n,
+                                           int passes, uint32_t *cnt) {
+  const int lane = (int)(threadIdx.x & 63);
+  constexpr int kItems = kSmallCap / 64;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = pass * 8;
+    for (int c = lane; c < 256; c += 64) cnt[c] = 0;
+    __syncthreads();
+    uint32_t key[kItems], lr[kItems];
+    A val[kItems];
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+      key[i] = 0;
+      lr[i] = 0;
+      val[i] = A(0);
+      if (i * 64 < n) {  // wave-uniform
+        const int idx = i * 64 + lane;
+        const bool valid = idx < n;
+        if (valid) {
+          key[i] = ka[idx];
+          val[i] = va[idx];
+        }
+        const uint32_t d = (key[i] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const bool bit = (d >> b) & 1u;
+          const unsigned long long m = __ballot(valid && bit);
+          peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        uint32_t pre = 0;
+        if (valid && lane == leader) {
+          pre = cnt[d];
+          cnt[d] = pre + (uint32_t)__popcll(peers);
+        }
+        pre = lane_read(pre, leader);
+        lr[i] = pre + rank;
+      }
+    }
+    __syncthreads();
+    {  // exclusive scan of the 256 digit counts: 4 digits per lane
+      const uint32_t c0 = cnt[4 * lane], c1 = cnt[4 * lane + 1], c2 = cnt[4 * lane + 2],
+                     c3 = cnt[4 * lane + 3];
+      const uint32_t s = c0 + c1 + c2 + c3;
+      uint32_t incl = s;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = lane_read(incl, lane >= off ? lane - off : lane);
+        if (lane >= off) incl += o;
+      }
+      const uint32_t base = incl - s;
+      cnt[4 * lane] = base;
+      cnt[4 * lane + 1] = base + c0;
+      cnt[4 * lane + 2] = base + c0 + c1;
+      cnt[4 * lane + 3] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+      if (i * 64 + lane < n) {
+        const uint32_t pos = cnt[(key[i] >> shift) & 255u] + lr[i];
+        kb[pos] = key[i];
+        vb[pos] = val[i];
+      }
+    }
+    __syncthreads();
+    uint32_t *tk = ka; ka = kb; kb = tk;
+    A *tv = va; va = vb; vb = tv;
+  }
+}
+
+// One workgroup per row: expand into LDS, sort by column, compress, write.
 template <typename T, int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void spspmm_row_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
     const T *__restrict__ valA, const int64_t *__restrict__ rowptrB,
     const int64_t *__restrict__ colB, const T *__restrict__ valB,
     const int64_t *__restrict__ prodptr, const int64_t *__restrict__ rows,
-    int64_t *__restrict__ colT, T *__restrict__ valT, int64_t *__restrict__ nnzC) {
+    int64_t *__restrict__ colT, T *__restrict__ valT, int64_t *__restrict__ nnzC, int passes) {
   using A = typename Traits<T>::acc_t;
-  __shared__ uint32_t scol[CAP];
-  __shared__ A sval[CAP];
+  __shared__ uint32_t scol_[CAP];
+  __shared__ A sval_[CAP];
+  __shared__ uint32_t scol2_[BLOCK == 64 ? CAP : 1];  // ping-pong buffers of the wave radix sort
+  __shared__ A sval2_[BLOCK == 64 ? CAP : 1];
+  __shared__ uint32_t scnt[BLOCK == 64 ? 256 : 1];
   __shared__ int sscan[8];
+  uint32_t *scol = scol_, *scol2 = scol2_;
+  A *sval = sval_, *sval2 = sval2_;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int64_t i = rows[blockIdx.x];
@@ -125,8 +208,14 @@ __global__ __launch_bounds__(BLOCK) void spspmm_row_kernel(
   int n2 = 2;
   while (n2 < p) n2 <<= 1;
 
-  // ---- expand: every wave walks the A row in 64-entry chunks; the chunk's B rows are
-  //      copied by the whole workgroup, one B row at a time ----
+  // ---- expand: the A row is read in 64-entry chunks (one entry per lane: column, start and
+  //      length of the B row, value); the chunk's products are then a flat index space that the
+  //      whole workgroup strides over, each thread locating its B row by a binary search over the
+  //      chunk's prefix sums in LDS -- independent gathers, several in flight per thread (walking
+  //      the B rows one after the other serialises a global-load latency per A entry) ----
+  __shared__ int s_off[65];
+  __shared__ int64_t s_bs[64];
+  __shared__ A s_av[64];
   int filled = 0;
   for (int64_t e0 = as; e0 < ae; e0 += 64) {
     const int64_t e = e0 + lane;
@@ -139,19 +228,38 @@ __global__ __launch_bounds__(BLOCK) void spspmm_row_kernel(
       d = (int)(rowptrB[c + 1] - bs);
       if (valA != nullptr) av = Traits<T>::to_acc(valA[e]);
     }
-    const int64_t rem = ae - e0;
-    const int nchunk = rem < 64 ? (int)rem : 64;
-    for (int s = 0; s < nchunk; ++s) {
-      const int ds = lane_read(d, s);
-      const int64_t bss = lane_read(bs, s);
-      const A avs = lane_read(av, s);
-      for (int j = tid; j < ds; j += BLOCK) {
-        scol[filled + j] = (uint32_t)colB[bss + j];
-        sval[filled + j] = valB != nullptr ? avs * Traits<T>::to_acc(valB[bss + j]) : avs;
-      }
-      filled += ds;
+    int incl = d;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = lane_read(incl, lane >= off ? lane - off : lane);
+      if (lane >= off) incl += o;
     }
+    if (tid < 64) {  // every wave holds the same chunk; the first one publishes it
+      s_off[lane] = incl - d;
+      s_bs[lane] = bs;
+      s_av[lane] = av;
+      if (lane == 63) s_off[64] = incl;
+    }
+    __syncthreads();
+    const int total = s_off[64];
+#pragma unroll 4
+    for (int q = tid; q < total; q += BLOCK) {
+      int lo = 0, hi = 64;  // last entry whose offset is <= q (zero-length entries are skipped)
+#pragma unroll
+      for (int step = 0; step < 6; ++step) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= q) lo = mid; else hi = mid;
+      }
+      const int64_t src = s_bs[lo] + (q - s_off[lo]);
+      scol[filled + q] = (uint32_t)colB[src];
+      sval[filled + q] = valB != nullptr ? s_av[lo] * Traits<T>::to_acc(valB[src]) : s_av[lo];
+    }
+    filled += total;
+    __syncthreads();
   }
+  if constexpr (BLOCK == 64) {
+    wave_radix_sort_lds<A>(scol, sval, scol2, sval2, p, passes, scnt);
+  } else {
   for (int j = p + tid; j < n2; j += BLOCK) {
     scol[j] = 0xFFFFFFFFu;
     sval[j] = A(0);
@@ -176,6 +284,7 @@ __global__ __launch_bounds__(BLOCK) void spspmm_row_kernel(
       }
       __syncthreads();
     }
+  }
   }
 
   // ---- compress equal columns, write the row into its slot ----
@@ -277,20 +386,23 @@ __global__ void spspmm_compact_kernel(const int64_t *__restrict__ rowC, const in
 template <typename T>
 int run_rows(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
              const int64_t *colB, const void *valB, const int64_t *prodptr, const int64_t *bins,
-             int64_t M, int64_t n_small, int64_t n_medium, int64_t *colT, void *valT, int64_t *nnzC,
-             hipStream_t stream) {
+             int64_t M, int64_t N, int64_t n_small, int64_t n_medium, int64_t *colT, void *valT,
+             int64_t *nnzC, hipStream_t stream) {
+  int bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < N) ++bits;
+  const int passes = (bits + 7) / 8;  // 8-bit radix passes over the column ids
   const T *va = reinterpret_cast<const T *>(valA);
   const T *vb = reinterpret_cast<const T *>(valB);
   T *vt = reinterpret_cast<T *>(valT);
   if (n_small > 0) {
     hipLaunchKernelGGL((spspmm_row_kernel<T, 64, kSmallCap>), dim3((unsigned int)n_small), dim3(64), 0,
-                       stream, rowptrA, colA, va, rowptrB, colB, vb, prodptr, bins, colT, vt, nnzC);
+                       stream, rowptrA, colA, va, rowptrB, colB, vb, prodptr, bins, colT, vt, nnzC, passes);
     TSAMD_LAUNCH_CHECK();
   }
   if (n_medium > 0) {
     hipLaunchKernelGGL((spspmm_row_kernel<T, 256, kMediumCap>), dim3((unsigned int)n_medium), dim3(256),
                        0, stream, rowptrA, colA, va, rowptrB, colB, vb, prodptr, bins + M, colT, vt,
-                       nnzC);
+                       nnzC, passes);
     TSAMD_LAUNCH_CHECK();
   }
   return TSAMD_OK;
@@ -427,10 +539,10 @@ extern "C" int tsamd_spspmm_rows(int dtype, const int64_t *rowptrA, const int64_
     return TSAMD_ERR_WORKSPACE;
   int st;
   if (dtype == TSAMD_F32)
-    st = run_rows<float>(rowptrA, colA, valA, rowptrB, colB, valB, prodptr, bins, M, n_small, n_medium,
+    st = run_rows<float>(rowptrA, colA, valA, rowptrB, colB, valB, prodptr, bins, M, N, n_small, n_medium,
                          colT, valT, nnzC, stream);
   else
-    st = run_rows<double>(rowptrA, colA, valA, rowptrB, colB, valB, prodptr, bins, M, n_small,
+    st = run_rows<double>(rowptrA, colA, valA, rowptrB, colB, valB, prodptr, bins, M, N, n_small,
                           n_medium, colT, valT, nnzC, stream);
   if (st != TSAMD_OK || n_large == 0) return st;
   if (dtype == TSAMD_F32)

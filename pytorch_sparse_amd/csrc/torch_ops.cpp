@@ -20,6 +20,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/script.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/torch.h>
 
 #include "tsamd.h"
@@ -422,6 +423,15 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   const int64_t *hs = h.data_ptr<int64_t>();
   const int64_t P = hs[0], n_small = hs[1], n_medium = hs[2], n_large = hs[3], P_large = hs[4];
 
+  {  // the expand-sort-compress intermediates are data dependent: refuse politely instead of OOM
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const double need = 12.0 * (double)P + (double)tsamd_spspmm_rows_workspace_bytes(dt, n_large, P_large);
+      TORCH_CHECK(need < 0.9 * (double)free_b, "spspmm: ", P, " intermediate products (", P_large,
+                  " of them in rows beyond the LDS capacity) need ~", (int64_t)(need / 1e9),
+                  " GB of scratch, more than the free device memory");
+    }
+  }
   Tensor colT = torch::empty({P}, iopt);
   Tensor valT = with_value ? torch::empty({P}, vopt) : Tensor();
   Tensor rowptrC = torch::zeros({M + 1}, iopt);  // nnzC in [0, M), scanned in place below

@@ -13,4 +13,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-include-regex "spmm_" --output-format csv -d $OUT/pmc_$C -o pmc -- python scripts/prof_spmm.py 21 128 sum 3 > $OUT/pmc_$C.log 2>&1
 done
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --workload c2 --no-cpu-baseline > $OUT/bench_c2.json 2>/dev/null
+python bench.py --workload c5 --no-cpu-baseline --steps 20 > $OUT/bench_c5.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_extra -o extra -- python scripts/bench_extra.py c3 c4 coalesce vbw > $OUT/bench_extra_under_rocprof.log 2>&1
+python scripts/bench_extra.py c3 c4 coalesce vbw narrow 2>/dev/null | grep "^{" > $OUT/bench_extra.jsonl
 ls -R $OUT | head -40

@@ -70,6 +70,19 @@ if bench:
     if traffic:
         lines.append('measured fabric traffic per launch %.3e B = %.0f %% of the algorithmic bytes (the rest is L2 reuse of hub columns).' % (
             traffic['hbm_bytes_per_launch'], 100.0 * traffic['hbm_bytes_per_launch'] / rf['algorithmic_bytes_per_launch']))
+# secondary kernels (sort / coalesce / spspmm / backward) from the bench_extra trace
+pe = os.path.join(src, 'trace_extra', 'extra_kernel_stats.csv')
+if os.path.exists(pe):
+    lines += ['', '## rocprofv3 --kernel-trace --stats  (`python scripts/bench_extra.py c3 c4 coalesce vbw`)', '',
+              '| kernel | calls | avg us | total us |', '|---|---|---|---|']
+    for r in csv.DictReader(open(pe)):
+        if 'tsamd' in r['Name']:
+            lines.append('| `%s` | %s | %.2f | %.1f |' % (short(r['Name'])[:90], r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e3))
+for extra in ('bench_c2.json', 'bench_c5.json', 'bench_extra.jsonl'):
+    pp = os.path.join(src, extra)
+    if os.path.exists(pp):
+        import shutil
+        shutil.copy(pp, os.path.join(dst, '%s_%s' % (tag, extra)))
 open(os.path.join(dst, '%s_summary.md' % tag), 'w').write('\n'.join(lines) + '\n')
 if traffic:
     json.dump(traffic, open(os.path.join(dst, 'traffic_%s.json' % workload), 'w'), indent=1)
