@@ -315,3 +315,25 @@ def test_reductions_and_broadcast_mul(ts, dev):
     x = torch.randn(m, 16, generator=g)
     assert torch.allclose((norm @ x.to(dev)).cpu(), ref @ x, atol=1e-4)
     assert dinv.numel() == m
+
+
+def test_spspmm_rmat_all_size_classes(ts, dev):
+    """A * A^T on an R-MAT graph: hub rows go through the global expand/sort path, mid rows through
+    the 256-thread LDS kernel, the rest through the one-wave radix-sort kernel.  Oracle =
+    torch.sparse.mm on CPU; integer-valued entries keep every sum exact."""
+    from pytorch_sparse_amd import synth
+    rp, c = synth.rmat_csr(13, 8, seed=4, device=dev)
+    n = 1 << 13
+    g = torch.Generator(device=dev).manual_seed(1)
+    val = torch.randint(1, 4, (c.numel(), ), generator=g, device=dev).float()
+    A = ts.SparseTensor(rowptr=rp, col=c, value=val, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    At = A.t()
+    rpB = At.storage.rowptr()
+    prod = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, A.storage.row(), (rpB[1:] - rpB[:-1])[c])
+    assert int((prod <= 512).sum()) > 0 and int(((prod > 512) & (prod <= 4096)).sum()) > 0 and int((prod > 4096).sum()) > 0
+    C = A @ At
+    Cc = torch.sparse.mm(A.cpu().to_torch_sparse_coo_tensor(), At.cpu().to_torch_sparse_coo_tensor())
+    row, col, v = C.coo()
+    assert torch.equal(torch.stack([row, col]).cpu(), Cc._indices())
+    assert torch.equal(v.cpu(), Cc._values())
+    assert C.is_coalesced()
