@@ -127,24 +127,27 @@ __global__ void spmm_probe_kernel(const int64_t *__restrict__ col, int64_t E, in
   }
 }
 
+// lgL = log2(lanes per row); a 256-thread block copies 256 >> lgL rows, 16 bytes per lane and
+// step (no integer division on the packet index).
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void spmm_permute_rows_kernel(const T *__restrict__ mat,
                                                                T *__restrict__ xperm, int64_t BN,
-                                                               uint32_t N, uint32_t K,
+                                                               uint32_t N, uint32_t K, int lgL,
                                                                Workspace ws) {
   if (!use_relabel(ws.relabel_mode, ws.relabel_flag)) return;
   using P = Pack<T, VEC>;
   const uint32_t slots = K / VEC;
-  const int64_t total = BN * slots;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / slots;
-    const uint32_t sl = (uint32_t)(t - r * slots);
-    const int64_t b = r / N;
+  const uint32_t lanes = 1u << lgL;
+  const uint32_t sl0 = threadIdx.x & (lanes - 1);
+  const int64_t rows_per_block = 256 >> lgL;
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> lgL); r < BN;
+       r += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t b = BN == (int64_t)N ? 0 : r / N;
     const uint32_t i = (uint32_t)(r - b * N);
     const uint32_t j = hash_row(i, N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
-    reinterpret_cast<P *>(xperm)[((uint64_t)b * N + j) * slots + sl] =
-        reinterpret_cast<const P *>(mat)[(uint64_t)r * slots + sl];
+    const P *src = reinterpret_cast<const P *>(mat) + (uint64_t)r * slots;
+    P *dst = reinterpret_cast<P *>(xperm) + ((uint64_t)b * N + j) * slots;
+    for (uint32_t sl = sl0; sl < slots; sl += lanes) dst[sl] = src[sl];
   }
 }
 
@@ -497,7 +500,14 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
   const int64_t deg = rowptr[R + 1] - rs;
   // tail records of row R sit in the partitions right before q
   int64_t run = 0;
-  while (run < q && ws.tail_row[q - 1 - run] == R) ++run;
+  for (;;) {  // 64 candidates per step: count the leading matches
+    const int64_t idx = q - 1 - run - lane;
+    const bool ok = idx >= 0 && ws.tail_row[idx] == R;
+    const unsigned long long m = __ballot(ok);
+    const int c = m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
+    run += c;
+    if (c < 64) break;
+  }
 
   const A *head_val = reinterpret_cast<const A *>(ws.head_val);
   const A *tail_val = reinterpret_cast<const A *>(ws.tail_val);
@@ -508,6 +518,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
     val[0] = head_val[(plane + q) * K + k];
     arg[0] = kNoArg;
     if constexpr (RED != RED_ADD) arg[0] = ws.head_arg[(plane + q) * K + k];
+#pragma unroll 4
     for (int64_t i = 0; i < run; ++i) {
       const uint64_t o = (plane + (q - 1 - i)) * K + k;
       const A v = tail_val[o];
@@ -613,8 +624,12 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
     }
     if (mode != 0) {
       // the copy always moves 16-byte packets, whatever packet size the reduction kernel uses
-      hipLaunchKernelGGL((spmm_permute_rows_kernel<T, 16 / (int)sizeof(T)>), dim3(4096), dim3(256), 0, stream, mat,
-                         reinterpret_cast<T *>(ws.xperm), B * N, (uint32_t)N, (uint32_t)K, ws);
+      constexpr int kPV = 16 / (int)sizeof(T);
+      const uint32_t pslots = (uint32_t)(K / kPV);
+      int lgL = 0;
+      while (lgL < 8 && (1u << lgL) < pslots) ++lgL;
+      hipLaunchKernelGGL((spmm_permute_rows_kernel<T, kPV>), dim3(8192), dim3(256), 0, stream, mat,
+                         reinterpret_cast<T *>(ws.xperm), B * N, (uint32_t)N, (uint32_t)K, lgL, ws);
       TSAMD_LAUNCH_CHECK();
     }
   }
