@@ -698,6 +698,7 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
   if (N >= (int64_t)1 << 32 || K >= (int64_t)1 << 31 || B >= 65536) return TSAMD_ERR_UNSUPPORTED;
+  if (B * ceil_div(K, 64) >= 65536) return TSAMD_ERR_UNSUPPORTED;  // gridDim.y = B * feature tiles
   const bool minmax = reduce == TSAMD_MIN || reduce == TSAMD_MAX;
   if (B * M * K == 0) return TSAMD_OK;  // nothing to write
   if (!rowptr || !out || (E > 0 && (!col || !mat)) || (minmax && !arg_out))
