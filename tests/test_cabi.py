@@ -51,3 +51,52 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(nat, 'LIB_PATH', '/nonexistent/libtsamd.so')
     with pytest.raises(ImportError, match='no CPU fallback'):
         nat.lib()
+
+
+def test_argument_validation_returns_status_codes():
+    """Bad arguments are rejected by the C-ABI before any HIP call (so this runs without a GPU)."""
+    L = nat.lib()
+    i64, vp, sz = ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+    fake = vp(0x1000)  # never dereferenced: every call below fails validation first
+    # negative size / unknown reduce / unknown dtype / N too large
+    assert L.tsamd_spmm(0, 0, fake, fake, None, fake, fake, None, i64(1), i64(-1), i64(4), i64(4), i64(4),
+                        fake, sz(1 << 20), None) == 1
+    assert L.tsamd_spmm(0, 7, fake, fake, None, fake, fake, None, i64(1), i64(4), i64(4), i64(4), i64(4),
+                        fake, sz(1 << 20), None) == 2
+    assert L.tsamd_spmm(42, 0, fake, fake, None, fake, fake, None, i64(1), i64(4), i64(4), i64(4), i64(4),
+                        fake, sz(1 << 20), None) == 2
+    assert L.tsamd_spmm(0, 0, fake, fake, None, fake, fake, None, i64(1), i64(4), i64(1 << 33), i64(4), i64(4),
+                        fake, sz(1 << 20), None) == 2
+    # null pointers; min/max without arg_out; workspace missing / too small / misaligned
+    assert L.tsamd_spmm(0, 0, None, fake, None, fake, fake, None, i64(1), i64(4), i64(4), i64(4), i64(4),
+                        fake, sz(1 << 20), None) == 1
+    assert L.tsamd_spmm(0, 3, fake, fake, None, fake, fake, None, i64(1), i64(4), i64(4), i64(4), i64(4),
+                        fake, sz(1 << 20), None) == 1
+    assert L.tsamd_spmm(0, 0, fake, fake, None, fake, fake, None, i64(1), i64(4), i64(4), i64(4), i64(4),
+                        None, sz(0), None) == 4
+    assert L.tsamd_spmm(0, 0, fake, fake, None, fake, fake, None, i64(1), i64(4), i64(4), i64(4), i64(4),
+                        fake, sz(16), None) == 4
+    assert L.tsamd_spmm(0, 0, fake, fake, None, fake, fake, None, i64(1), i64(4), i64(4), i64(4), i64(4),
+                        vp(0x1008), sz(1 << 20), None) == 4
+    # nothing to do is OK without touching anything
+    assert L.tsamd_spmm(0, 0, None, None, None, None, None, None, i64(1), i64(0), i64(4), i64(4), i64(0),
+                        None, sz(0), None) == 0
+    # backward entry points
+    assert L.tsamd_spmm_value_bw(0, 2, None, fake, fake, fake, fake, fake, i64(1), i64(4), i64(4), i64(4),
+                                 i64(4), None) == 2  # only sum / mean have a value gradient
+    assert L.tsamd_spmm_value_bw(4, 0, None, fake, fake, fake, fake, fake, i64(1), i64(4), i64(4), i64(4),
+                                 i64(4), None) == 2  # integer dtypes have no gradient
+    assert L.tsamd_spmm_minmax_bw(5, fake, None, fake, fake, fake, fake, fake, i64(1), i64(4), i64(4), i64(4),
+                                  i64(4), None, sz(0), None) == 2
+    assert L.tsamd_ind2ptr(None, i64(4), i64(3), fake, None) == 1
+    assert L.tsamd_sort_coo(fake, fake, i64(5), i64(1 << 40), i64(1 << 40), None, None, fake, fake,
+                            sz(1 << 30), None) == 2  # keys would not fit 63 bits
+    assert L.tsamd_sort_coo(fake, fake, i64(5), i64(9), i64(9), None, None, fake, None, sz(0), None) == 4
+    assert L.tsamd_segment_reduce(0, 9, fake, None, fake, i64(3), i64(1), fake, None) == 2
+    assert L.tsamd_spspmm_rows(2, fake, fake, None, fake, fake, None, i64(4), i64(4), fake, fake, i64(1), i64(0),
+                               i64(0), i64(0), fake, None, fake, None, sz(0), None) == 2  # f16: like torch.sparse.mm
+    # workspace sizes grow with the problem and include the relabel copy only when it can pay off
+    small = L.tsamd_spmm_workspace_bytes(0, 0, i64(1), i64(1000), i64(1000), i64(128), i64(5000))
+    big = L.tsamd_spmm_workspace_bytes(0, 0, i64(1), i64(1 << 21), i64(1 << 21), i64(128), i64(40 << 20))
+    halo = L.tsamd_spmm_workspace_bytes(0, 0, i64(1), i64(1 << 21), i64(1 << 24), i64(128), i64(40 << 20))
+    assert small < (1 << 22) and big > (1 << 30) and halo < (1 << 28)
