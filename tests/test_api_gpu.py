@@ -337,3 +337,39 @@ def test_spspmm_rmat_all_size_classes(ts, dev):
     assert torch.equal(torch.stack([row, col]).cpu(), Cc._indices())
     assert torch.equal(v.cpu(), Cc._values())
     assert C.is_coalesced()
+
+
+def test_fuzz_coalesce_transpose_spspmm(ts, dev):
+    """Random small COO inputs (empty, single entry, all duplicates, tall/wide) against the numpy
+    oracle: indices bit-exact, values exact (small integers)."""
+    rng = np.random.RandomState(7)
+    for case in range(120):
+        m, n = int(rng.choice([1, 2, 9, 100, 1000])), int(rng.choice([1, 3, 50, 2000]))
+        nnz = int(rng.choice([0, 1, 2, 17, 300, 3000]))
+        row = torch.from_numpy(rng.randint(0, m, size=nnz)).long()
+        col = torch.from_numpy(rng.randint(0, n, size=nnz)).long()
+        if rng.rand() < 0.2 and nnz > 0:
+            row[:] = row[0]
+            col[:] = col[0]
+        val = torch.from_numpy(rng.randint(-9, 10, size=nnz)).float()
+        op = ['add', 'mean', 'min', 'max'][rng.randint(4)]
+        if op == 'mean':
+            val = val * 0 + 2.0  # keep the mean exact
+        index = torch.stack([row, col])
+        i, v = ts.coalesce(index.to(dev), val.to(dev), m, n, op=op)
+        er, ec, ev = no.coalesce(row.numpy(), col.numpy(), val.numpy(), m, n, op)
+        assert np.array_equal(i.cpu().numpy(), np.stack([er, ec])), case
+        assert np.array_equal(v.cpu().numpy(), ev), case
+        ti, tv = ts.transpose(index.to(dev), val.to(dev), m, n)
+        tr, tc, tvv = no.transpose(row.numpy(), col.numpy(), val.numpy(), m, n)
+        assert np.array_equal(ti.cpu().numpy(), np.stack([tr, tc])) and np.array_equal(tv.cpu().numpy(), tvv), case
+        if case % 3 == 0 and er.size > 0:
+            # C = A * A^T with the coalesced pattern
+            A = ts.SparseTensor(row=i[0], col=i[1], value=v, sparse_sizes=(m, n), is_sorted=True, trust_data=True)
+            C = A @ A.t()
+            cr, cc, cv = C.coo()
+            xr, xc, xv = no.spspmm(er, ec, ev, ec[np.argsort(ec * m + er, kind='stable')],
+                                   er[np.argsort(ec * m + er, kind='stable')],
+                                   ev[np.argsort(ec * m + er, kind='stable')], m, n, m)
+            assert np.array_equal(torch.stack([cr, cc]).cpu().numpy(), np.stack([xr, xc])), case
+            assert np.array_equal(cv.cpu().numpy(), xv.astype(np.float32)), case

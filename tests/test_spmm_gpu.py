@@ -289,3 +289,39 @@ def test_relabel_path_is_bit_identical(dev, dtype, monkeypatch):
             assert torch.equal(res[('0', reduce)][1], res[('1', reduce)][1])
     check_spmm(res[('1', 'max')][0], res[('1', 'max')][1], rp, c, v, x, 'max')
     check_spmm(res[('1', 'sum')][0], None, rp, c, v, x, 'sum')
+
+
+def test_spmm_fuzz_small_shapes(dev):
+    """300 random small problems (ragged shapes, empty leading/trailing rows, rows ending exactly on
+    partition boundaries, K not a multiple of anything, batch dims) against the oracle."""
+    rng = np.random.RandomState(1234)
+    dts = [torch.float32, torch.float64, torch.bfloat16, torch.float16, torch.int32, torch.int64]
+    for case in range(300):
+        M = int(rng.choice([1, 2, 3, 7, 64, 129, 500, 1025]))
+        N = int(rng.choice([1, 2, 5, 33, 128, 1000]))
+        kind = rng.randint(4)
+        if kind == 0:      # uniform random degrees
+            deg = rng.randint(0, 6, size=M)
+        elif kind == 1:    # exactly 127/128/129 items per stretch: partition edges on row ends
+            deg = rng.choice([0, 63, 64, 65, 127, 128], size=M)
+        elif kind == 2:    # one heavy row, everything else empty
+            deg = np.zeros(M, dtype=np.int64)
+            deg[rng.randint(M)] = int(rng.choice([1, 64, 1000, 5000]))
+        else:              # heavy head, empty tail
+            deg = np.where(np.arange(M) < max(1, M // 4), rng.randint(0, 300, size=M), 0)
+        rp = torch.zeros(M + 1, dtype=torch.int64)
+        rp[1:] = torch.from_numpy(np.cumsum(deg))
+        E = int(rp[-1])
+        c = torch.from_numpy(rng.randint(0, N, size=E)).long()
+        dtype = dts[rng.randint(len(dts))]
+        K = int(rng.choice([1, 2, 3, 4, 8, 12, 16, 33, 64, 100, 130]))
+        batch = () if rng.rand() < 0.7 else (int(rng.randint(1, 4)), )
+        has_value = bool(rng.rand() < 0.6)
+        reduce = ['sum', 'mean', 'min', 'max'][rng.randint(4)]
+        v, x = make_inputs(rp, c, N, K, dtype, has_value, batch, seed=case)
+        out, arg = run_gpu(dev, rp, c, v, x, reduce)
+        try:
+            check_spmm(out, arg, rp, c, v, x, reduce)
+        except AssertionError as exc:
+            raise AssertionError('case %d: M=%d N=%d E=%d K=%d %s %s batch=%s value=%s kind=%d: %s' % (
+                case, M, N, E, K, dtype, reduce, batch, has_value, kind, exc))
