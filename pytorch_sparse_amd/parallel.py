@@ -214,6 +214,96 @@ class HaloShardedSpMM(object):
         return self.spmm_fn(self.rowptr, self.col, self.value, self.exchange(x_local), reduce)
 
 
+class PipelinedHaloSpMM(object):
+    """HaloShardedSpMM with the exchange hidden behind the compute (forward only, SUM / MEAN / MIN /
+    MAX all work because rows are never split).
+
+    The local row block is cut into `chunks` pieces of equal nnz.  Piece i needs the column set
+    S_i; what has to arrive before it can run is only D_i = S_i minus (S_0 u ... u S_{i-1}) -- hub columns are
+    fetched once, with the first piece.  A step is a software pipeline
+
+        exchange(D_0); for i: [exchange(D_{i+1}) on the RCCL stream]  ||  [SpMM(piece i)]
+
+    so only the first exchange is exposed.  Total traffic equals the one-shot halo exchange.
+    X_need is one buffer laid out [D_0 | D_1 | ...]; piece i multiplies against its prefix.
+    """
+
+    def __init__(self, rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
+                 group=None, spmm_fn: Optional[Callable] = None, chunks: int = 4):
+        self.group = group
+        self.spmm_fn = spmm_fn or _default_spmm
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert len(x_sizes) == self.world
+        self.x_sizes = list(x_sizes)
+        dev = col.device
+        M = rowptr.numel() - 1
+        self.pieces = []
+        ranges = partition_rows(rowptr, chunks, 'nnz') if self.world > 1 else [(0, M)]
+        bounds = torch.tensor([0] + list(torch.tensor(list(x_sizes)).cumsum(0).tolist()), device=dev)
+        have = torch.zeros(0, dtype=torch.int64, device=dev)  # sorted global ids already in the buffer
+        have_pos = torch.zeros(0, dtype=torch.int64, device=dev)  # their positions in the buffer
+        offset = 0
+        for (s, e) in ranges:
+            rp, c, v = narrow_rows(rowptr, col, value, s, e)
+            if self.world == 1:
+                self.pieces.append(dict(rows=(s, e), rowptr=rp, col=c, value=v, n_prefix=int(x_sizes[0])))
+                continue
+            need = torch.unique(c)
+            if have.numel() > 0:
+                idx = torch.searchsorted(have, need).clamp_(max=have.numel() - 1)
+                fresh = need[have[idx] != need]
+            else:
+                fresh = need
+            cuts = torch.searchsorted(fresh, bounds)
+            recv_counts = (cuts[1:] - cuts[:-1]).tolist()
+            want = torch.tensor(recv_counts, dtype=torch.int64, device=dev)
+            serve = torch.empty_like(want)
+            dist.all_to_all_single(serve, want, group=group)
+            send_counts = serve.tolist()
+            req_local = fresh - torch.repeat_interleave(bounds[:-1], want)
+            serve_idx = torch.empty(sum(send_counts), dtype=torch.int64, device=dev)
+            dist.all_to_all_single(serve_idx, req_local, output_split_sizes=send_counts,
+                                   input_split_sizes=recv_counts, group=group)
+            # merge the new ids into the (sorted ids -> buffer position) map
+            pos_new = offset + torch.arange(fresh.numel(), device=dev)
+            allid = torch.cat([have, fresh])
+            allpos = torch.cat([have_pos, pos_new])
+            order = torch.argsort(allid)
+            have, have_pos = allid[order], allpos[order]
+            offset += fresh.numel()
+            ccompact = have_pos[torch.searchsorted(have, c)]
+            self.pieces.append(dict(rows=(s, e), rowptr=rp, col=ccompact, value=v, serve_idx=serve_idx,
+                                    send_counts=send_counts, recv_counts=recv_counts,
+                                    seg=(offset - fresh.numel(), offset), n_prefix=offset))
+        self.n_needed = offset if self.world > 1 else int(x_sizes[0])
+        self.rows = M
+
+    def _start_exchange(self, piece, x_local: Tensor, buf: Tensor):
+        send = x_local.index_select(0, piece['serve_idx'])
+        a, b = piece['seg']
+        return dist.all_to_all_single(buf[a:b], send, output_split_sizes=piece['recv_counts'],
+                                      input_split_sizes=piece['send_counts'], group=self.group,
+                                      async_op=True), send
+
+    def __call__(self, x_local: Tensor, reduce: str = 'sum') -> Tensor:
+        if self.world == 1:
+            p = self.pieces[0]
+            return self.spmm_fn(p['rowptr'], p['col'], p['value'], x_local, reduce)
+        buf = x_local.new_empty((self.n_needed, ) + tuple(x_local.shape[1:]))
+        outs = []
+        work, keep = self._start_exchange(self.pieces[0], x_local, buf)
+        for i, p in enumerate(self.pieces):
+            nxt = None
+            if i + 1 < len(self.pieces):  # enqueue the next exchange BEFORE this piece's SpMM
+                nxt = self._start_exchange(self.pieces[i + 1], x_local, buf)
+            work.wait()  # this piece's rows have landed (the compute stream waits, the host does not)
+            outs.append(self.spmm_fn(p['rowptr'], p['col'], p['value'], buf[:p['n_prefix']], reduce))
+            if nxt is not None:
+                work, keep = nxt
+        return torch.cat(outs, dim=-2)
+
+
 def shard_matrix(rowptr: Tensor, col: Tensor, value: Optional[Tensor], n_cols: int, group=None,
                  balance: str = 'nnz', spmm_fn: Optional[Callable] = None, exchange: str = 'allgather'):
     """Convenience for a replicated global CSR: every rank cuts out its own row block.  X is
@@ -229,5 +319,5 @@ def shard_matrix(rowptr: Tensor, col: Tensor, value: Optional[Tensor], n_cols: i
         x_sizes = [(n_cols * (p + 1)) // world - (n_cols * p) // world for p in range(world)]
     s, e = ranges[rank]
     rp, c, v = narrow_rows(rowptr, col, value, s, e)
-    cls = {'allgather': RowShardedSpMM, 'halo': HaloShardedSpMM}[exchange]
+    cls = {'allgather': RowShardedSpMM, 'halo': HaloShardedSpMM, 'pipelined': PipelinedHaloSpMM}[exchange]
     return cls(rp, c, v, x_sizes, group, spmm_fn), (s, e)

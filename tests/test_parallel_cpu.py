@@ -54,6 +54,11 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
             out_local = op(x_local, reduce)
             full, _ = oc.spmm(oc.F32, reduce, rp.numpy(), c.numpy(), v.numpy(), x.numpy())
             res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]))
+        if exchange == 'pipelined':  # forward-only class
+            res['grad'] = True
+            res['range'] = (s, e)
+            q.put((rank, res))
+            return
         # backward: grad of x must be reduce-scattered to the owning rank
         opd, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=torch_spmm_sum, exchange=exchange)
         xl = x_local.clone().requires_grad_()
@@ -69,7 +74,7 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
 
 
 @pytest.mark.parametrize('balance,exchange', [('nnz', 'allgather'), ('rows', 'allgather'),
-                                              ('nnz', 'halo'), ('rows', 'halo')])
+                                              ('nnz', 'halo'), ('rows', 'halo'), ('nnz', 'pipelined')])
 def test_row_sharded_spmm_gloo_world2(balance, exchange):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -77,7 +82,7 @@ def test_row_sharded_spmm_gloo_world2(balance, exchange):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, balance, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=240) for _ in procs)
+    results = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -111,11 +116,12 @@ def test_partition_and_narrow():
     assert partition_rows(rp2, 4, 'nnz')[-1][1] == 3
 
 
-def test_halo_exchange_gloo_world4():
+@pytest.mark.parametrize('exchange', ['halo', 'pipelined'])
+def test_halo_exchange_gloo_world4(exchange):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 4, port, 'nnz', q, 'halo')) for r in range(4)]
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, 'nnz', q, exchange)) for r in range(4)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=300) for _ in procs)
@@ -128,3 +134,22 @@ def test_halo_exchange_gloo_world4():
     ends = sorted(results[r]['range'] for r in range(4))
     assert ends[0][0] == 0 and ends[-1][1] == 1 << 9
     assert all(ends[i][1] == ends[i + 1][0] for i in range(3))
+
+
+def test_bench_local_block_shapes():
+    """bench.py's per-rank workload generator (weak scaling): row block size fixed, columns span the
+    whole distributed X, owners uniform."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world in (1, 2, 4):
+        for rank in range(world):
+            rp, c, m, n = bench.local_block(10, 8, world, rank, 'cpu')
+            assert m == 1 << 10 and n == m * world and rp.numel() == m + 1 and int(rp[-1]) == c.numel()
+            assert int(c.min()) >= 0 and int(c.max()) < n
+            if world > 1:
+                share = torch.bincount(c // m, minlength=world).float() / c.numel()
+                assert (share > 0.5 / world).all()
+    assert bench.b_alg(10, 4, 8, 4, True, False) == 10 * (8 + 4 + 32) + 5 * 8 + 4 * 8 * 4
