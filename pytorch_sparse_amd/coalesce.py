@@ -1,13 +1,48 @@
-"""Functional coalesce (reference: torch_sparse/coalesce.py:5-25)."""
+"""Functional coalesce on raw COO tensors (API of torch_sparse/coalesce.py:5-25).
+
+Runs straight on the fused ops, without building a SparseStorage: one order probe, at most one
+radix sort, one head-flag/scan/compaction pass, and a segmented reduction that reads the values
+through the sort permutation (the permuted value tensor is never materialised).
+"""
+from typing import Optional, Tuple
+
 import torch
+from torch import Tensor
 
-from .storage import SparseStorage
+_OPS = ('add', 'sum', 'mean', 'min', 'max')
 
 
-def coalesce(index, value, m, n, op='add'):
-    """Sort (index, value) row-major and merge duplicate entries with `op`
-    (add | sum | mean | min | max).  Returns (index [2, nnz'], value)."""
-    storage = SparseStorage(row=index[0], col=index[1], value=value, sparse_sizes=(m, n),
-                            is_sorted=False)
-    storage = storage.coalesce(reduce=op)
-    return torch.stack([storage.row(), storage.col()], dim=0), storage.value()
+def sorted_unique(row: Tensor, col: Tensor, m: int, n: int):
+    """-> (row_u, col_u, perm or None, seg_ptr or None, nnz_u): the distinct (row, col) pairs in
+    row-major order plus what is needed to reduce the values of duplicates.  seg_ptr is None when
+    the input had no duplicates (then perm alone reorders the values)."""
+    nnz = col.numel()
+    if nnz <= 1:
+        return row, col, None, None, nnz
+    descents, dups = torch.ops.tsamd.coo_order(row, col, n).tolist()  # host sync
+    perm = None
+    if descents > 0:
+        row, col, perm = torch.ops.tsamd.sort_coo(row, col, m, n, True)
+        dups = -1  # adjacent duplicates of the unsorted order say nothing; count after the sort
+    if dups == 0:
+        return row, col, perm, None, nnz
+    row_u, col_u, seg_ptr, n_dev = torch.ops.tsamd.coalesce_index(row, col)
+    n_u = nnz - dups if dups > 0 else int(n_dev)  # second sync only on the sorted path
+    if n_u == nnz:
+        return row, col, perm, None, nnz
+    return row_u[:n_u], col_u[:n_u], perm, seg_ptr, n_u
+
+
+def coalesce(index: Tensor, value: Optional[Tensor], m: int, n: int,
+             op: str = 'add') -> Tuple[Tensor, Optional[Tensor]]:
+    """Sort `index` ([2, nnz]) row-major and merge duplicate entries, reducing their values
+    ([nnz, *], any supported dtype) with `op` in add | sum | mean | min | max."""
+    if op not in _OPS:
+        raise ValueError(op)
+    row, col, perm, seg_ptr, n_u = sorted_unique(index[0], index[1], m, n)
+    if value is not None:
+        if seg_ptr is not None:
+            value = torch.ops.tsamd.segment_reduce(value, perm, seg_ptr, n_u, op)
+        elif perm is not None:
+            value = value[perm]
+    return torch.stack([row, col], dim=0), value

@@ -1,13 +1,15 @@
-"""t() on SparseTensor and the functional transpose (reference: torch_sparse/transpose.py)."""
+"""t() on SparseTensor and the functional transpose (API of torch_sparse/transpose.py)."""
 import torch
 
+from .coalesce import coalesce
 from .storage import SparseStorage
 from .tensor import SparseTensor
 
 
 def t(src: SparseTensor) -> SparseTensor:
-    """Transpose by permuting with csr2csc (one cached radix sort) and swapping the CSR/CSC caches,
-    so ``A.t().t()`` costs nothing more (reference transpose.py:7-31)."""
+    """Transpose by permuting with csr2csc (one cached radix sort) and handing the CSC-side caches
+    over as the CSR-side caches of the result, so ``A.t().t()`` costs nothing more
+    (reference transpose.py:7-31)."""
     st = src.storage
     perm = st.csr2csc()
     row, col, value = src.coo()
@@ -23,12 +25,10 @@ SparseTensor.t = lambda self: t(self)
 
 
 def transpose(index, value, m, n, coalesced=True):
-    """Functional transpose of a COO matrix given as (index [2, nnz], value); with
-    ``coalesced=True`` the result is sorted row-major and duplicates are summed
-    (reference transpose.py:39-62)."""
-    row, col = index[1], index[0]
-    if coalesced:
-        storage = SparseStorage(row=row, col=col, value=value, sparse_sizes=(n, m), is_sorted=False)
-        storage = storage.coalesce()
-        row, col, value = storage.row(), storage.col(), storage.value()
-    return torch.stack([row, col], dim=0), value
+    """(index, value) of the n x m transpose.  With ``coalesced=True`` (default) the result is
+    sorted row-major with duplicates summed -- i.e. a coalesce of the swapped index
+    (reference transpose.py:39-62); otherwise only the two index rows are swapped."""
+    swapped = torch.stack([index[1], index[0]], dim=0)
+    if not coalesced:
+        return swapped, value
+    return coalesce(swapped, value, n, m, op='add')
