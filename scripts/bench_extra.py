@@ -111,3 +111,17 @@ if 'narrow' in which:
             print(json.dumps(dict(bench='spmm_ns_graph', dtype=str(dtype).split('.')[1], F=K, reduce=red, ms=round(t, 3), gedges=round(E / t / 1e6, 2),
                                   balg_gbs=round(balg / t / 1e6, 1), frac_hbm=round(balg / t / 1e6 / 8000, 3))), flush=True)
         del v, x
+
+if 'c1' in which:
+    # config 1: torch_sparse.spmm on 1k x 1k COO, 5k nnz (unsorted, duplicates possible), F=16 fp32
+    m = n = 1000; nnz = 5000
+    row, col = synth.uniform_edges(m, n, nnz, seed=0, device=dev)
+    index = torch.stack([row, col]); val = synth.values(nnz, device=dev); x = synth.features(n, 16, device=dev)
+    t_legacy = wall(lambda: ts.spmm(index, val, m, n, x), iters=20)
+    A = ts.SparseTensor(row=row, col=col, value=val, sparse_sizes=(m, n)); A.storage.rowptr()
+    t_mm = wall(lambda: A.matmul(x), iters=50)
+    t_k = gpu_time(lambda: A.matmul(x), iters=50)
+    out = ts.spmm(index, val, m, n, x)
+    ref = torch.zeros(m, 16, device=dev).index_add_(0, row, val[:, None] * x[col])
+    print(json.dumps(dict(bench='c1_legacy_spmm_1k', legacy_spmm_ms_wall=round(t_legacy, 4), matmul_ms_wall=round(t_mm, 4),
+                          matmul_ms_gpu=round(t_k, 4), max_abs_err=float((out - ref).abs().max()))), flush=True)
