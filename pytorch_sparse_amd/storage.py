@@ -91,7 +91,11 @@ class SparseStorage(object):
             'csc2csr': _check_index(csc2csr, 'csc2csr', col, nnz),
         }
 
-        if not is_sorted and nnz > 1:
+        # Unsorted COO handed over on the CPU: there is no CPU sort in this package, so the sort is
+        # deferred until the storage is moved to the GPU (`.cuda()` / `.to(device)`); until then every
+        # accessor refuses to hand out the (still unsorted) arrays.
+        self._pending_sort = bool(not is_sorted and nnz > 1 and not col.is_cuda)
+        if not is_sorted and nnz > 1 and col.is_cuda:
             r = self.row()
             descents = int(torch.ops.tsamd.coo_order(r, col, N)[0])  # the one host sync
             if descents > 0:
@@ -111,6 +115,7 @@ class SparseStorage(object):
 
     def _derive(self, **overrides):
         """A new storage sharing this one's tensors, with some fields replaced."""
+        self._ready()
         kw = dict(row=self._row, rowptr=self._rowptr, col=self._col, value=self._value,
                   sparse_sizes=self._sparse_sizes, is_sorted=True, trust_data=True)
         kw.update(self._cache)
@@ -118,10 +123,17 @@ class SparseStorage(object):
         return SparseStorage(**kw)
 
     # ---- COO / CSR views -------------------------------------------------------------------
+    def _ready(self):
+        if self._pending_sort:
+            raise RuntimeError('this SparseStorage was built from unsorted COO on the CPU; '
+                               'pytorch_sparse_amd has no CPU implementation -- move it to the GPU first '
+                               '(.cuda() / .to(device) sorts it there) or pass is_sorted=True')
+
     def has_row(self) -> bool:
         return self._row is not None
 
     def row(self) -> Tensor:
+        self._ready()
         if self._row is None:
             if self._rowptr is None:
                 raise ValueError
@@ -132,6 +144,7 @@ class SparseStorage(object):
         return self._rowptr is not None
 
     def rowptr(self) -> Tensor:
+        self._ready()
         if self._rowptr is None:
             if self._row is None:
                 raise ValueError
@@ -139,12 +152,14 @@ class SparseStorage(object):
         return self._rowptr
 
     def col(self) -> Tensor:
+        self._ready()
         return self._col
 
     def has_value(self) -> bool:
         return self._value is not None
 
     def value(self) -> Optional[Tensor]:
+        self._ready()
         return self._value
 
     def _layout_value(self, value: Optional[Tensor], layout: Optional[str]) -> Optional[Tensor]:
@@ -262,6 +277,7 @@ class SparseStorage(object):
 
     # ---- coalescing ------------------------------------------------------------------------
     def is_coalesced(self) -> bool:
+        self._ready()
         if self._col.numel() <= 1:
             return True
         counts = torch.ops.tsamd.coo_order(self.row(), self._col, self._sparse_sizes[1]).tolist()
@@ -269,6 +285,7 @@ class SparseStorage(object):
 
     def coalesce(self, reduce: str = 'add'):
         """Merge duplicate (row, col) entries; values of duplicates are reduced in storage order."""
+        self._ready()
         nnz = self._col.numel()
         if nnz <= 1:
             return self
@@ -307,7 +324,7 @@ class SparseStorage(object):
             return None if t is None else f(t)
         return SparseStorage(row=ap(self._row, fn), rowptr=ap(self._rowptr, fn), col=fn(self._col),
                              value=ap(self._value, value_fn or fn), sparse_sizes=self._sparse_sizes,
-                             is_sorted=True, trust_data=True,
+                             is_sorted=not self._pending_sort, trust_data=True,
                              **{k: ap(v, fn) for k, v in self._cache.items()})
 
     def copy(self):

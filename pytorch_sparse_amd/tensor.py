@@ -147,7 +147,7 @@ class SparseTensor(object):
         return len(self.sizes())
 
     def nnz(self) -> int:
-        return self.storage.col().numel()
+        return self.storage._col.numel()
 
     def numel(self) -> int:
         value = self.storage.value()
@@ -256,10 +256,10 @@ class SparseTensor(object):
         return self.storage.is_shared()
 
     def device(self):
-        return self.storage.col().device
+        return self.storage._col.device
 
     def is_cuda(self) -> bool:
-        return self.storage.col().is_cuda
+        return self.storage._col.is_cuda
 
     def dtype(self):
         value = self.storage.value()

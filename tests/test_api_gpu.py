@@ -373,3 +373,17 @@ def test_fuzz_coalesce_transpose_spspmm(ts, dev):
                                    ev[np.argsort(ec * m + er, kind='stable')], m, n, m)
             assert np.array_equal(torch.stack([cr, cc]).cpu().numpy(), np.stack([xr, xc])), case
             assert np.array_equal(cv.cpu().numpy(), xv.astype(np.float32)), case
+
+
+def test_cpu_built_tensor_is_sorted_on_the_gpu(ts, dev):
+    row = torch.tensor([2, 0, 1, 0, 2]); col = torch.tensor([1, 2, 0, 0, 0]); val = torch.tensor([1., 2, 3, 4, 5])
+    A = ts.SparseTensor(row=row, col=col, value=val, sparse_sizes=(3, 3))     # CPU, unsorted: deferred
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        A.csr()
+    G = A.to(dev)
+    r, c, v = G.coo()
+    assert r.tolist() == [0, 0, 1, 2, 2] and c.tolist() == [0, 2, 0, 0, 1] and v.tolist() == [4, 2, 3, 5, 1]
+    assert G.storage.rowptr().tolist() == [0, 2, 3, 5]
+    assert torch.equal((G @ torch.eye(3, device=dev)).cpu(), torch.tensor([[4., 0, 2], [3, 0, 0], [5, 1, 0]]))
+    back = G.cpu()                       # sorted data may live on the CPU again
+    assert back.storage.col().tolist() == [0, 2, 0, 0, 1]

@@ -30,8 +30,18 @@ def test_ops_refuse_cpu_tensors():
         torch.ops.torch_sparse.spmm_sum(None, rowptr, col, None, None, None, x)
     with pytest.raises(RuntimeError, match='no CPU implementation'):
         torch.ops.torch_sparse.ind2ptr(col, 3)
+    # unsorted COO on the CPU is accepted but stays locked until it is moved to the GPU
+    A = pytorch_sparse_amd.SparseTensor(row=torch.tensor([1, 0]), col=torch.tensor([0, 0]))
+    assert A.nnz() == 2 and A.sparse_sizes() == (2, 1)
     with pytest.raises(RuntimeError, match='no CPU implementation'):
-        pytorch_sparse_amd.SparseTensor(row=torch.tensor([1, 0]), col=torch.tensor([0, 0]))
+        A.coo()
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        A.storage.rowptr()
+    # sorted data on the CPU can be held (and inspected), it just cannot be computed on
+    B = pytorch_sparse_amd.SparseTensor(row=torch.tensor([0, 1]), col=torch.tensor([0, 0]), is_sorted=True)
+    assert B.storage.col().tolist() == [0, 0]
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        B.storage.rowptr()
 
 
 def test_api_surface():
