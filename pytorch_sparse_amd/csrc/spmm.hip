@@ -652,30 +652,45 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   return TSAMD_OK;
 }
 
+template <typename T, int VEC>
+int dispatch_reduce(int reduce, const int64_t *rowptr, const int64_t *col, const T *v, const T *x,
+                    T *o, int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
+                    Workspace ws, hipStream_t stream, hipEvent_t *ev) {
+  const bool mean = reduce == TSAMD_MEAN;
+  if (reduce == TSAMD_MIN)
+    return launch_spmm<T, VEC, RED_MIN>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev);
+  if (reduce == TSAMD_MAX)
+    return launch_spmm<T, VEC, RED_MAX>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev);
+  return launch_spmm<T, VEC, RED_ADD>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev);
+}
+
+// `vec` = elements per lane packet, chosen by the caller: the largest power of two <= kMaxVec<T>
+// that divides K and matches the pointers' alignment.
 template <typename T>
-int dispatch_spmm(int reduce, bool vec_ok, const int64_t *rowptr, const int64_t *col,
+constexpr int kMaxVec = sizeof(T) == 2 ? 4 : 16 / (int)sizeof(T);
+
+template <typename T>
+int dispatch_spmm(int reduce, int vec, const int64_t *rowptr, const int64_t *col,
                   const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
                   int64_t M, int64_t N, int64_t K, int64_t E, Workspace ws, hipStream_t stream,
                   hipEvent_t *ev) {
-  // Packet per lane: 16 bytes for 4/8-byte types; 8 bytes (4 elements) for f16/bf16 -- with 8
-  // elements per lane the per-element state (fp32 accumulator, and the arg for min/max) costs
-  // 80-84 VGPRs = 5 waves/SIMD, with 4 it is 8 waves/SIMD (measured +5...27 %).
-  constexpr int kVec = sizeof(T) == 2 ? 4 : 16 / (int)sizeof(T);
+  // Packet per lane: up to 16 bytes for 4/8-byte types; up to 8 bytes (4 elements) for f16/bf16 --
+  // with 8 narrow elements per lane the per-element state (fp32 accumulator, and the arg for
+  // min/max) costs 80-84 VGPRs = 5 waves/SIMD, with 4 it is 8 waves/SIMD (measured +5...27 %).
+  // Row pitches that are not a multiple of 16 bytes fall back to 8- or 4-byte packets
+  // (e.g. F = 602 fp32 -> 8 bytes), odd pitches to single elements.
   const T *v = reinterpret_cast<const T *>(value);
   const T *x = reinterpret_cast<const T *>(mat);
   T *o = reinterpret_cast<T *>(out);
-  const bool mean = reduce == TSAMD_MEAN;
-#define TSAMD_SPMM_GO(VEC, RED) \
-  return launch_spmm<T, VEC, RED>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev)
-  if (vec_ok) {
-    if (reduce == TSAMD_MIN) TSAMD_SPMM_GO(kVec, RED_MIN);
-    if (reduce == TSAMD_MAX) TSAMD_SPMM_GO(kVec, RED_MAX);
-    TSAMD_SPMM_GO(kVec, RED_ADD);
-  } else {
-    if (reduce == TSAMD_MIN) TSAMD_SPMM_GO(1, RED_MIN);
-    if (reduce == TSAMD_MAX) TSAMD_SPMM_GO(1, RED_MAX);
-    TSAMD_SPMM_GO(1, RED_ADD);
+#define TSAMD_SPMM_GO(VEC) \
+  return dispatch_reduce<T, VEC>(reduce, rowptr, col, v, x, o, arg_out, B, M, N, K, E, ws, stream, ev)
+  if constexpr (kMaxVec<T> >= 4) {
+    if (vec >= 4) TSAMD_SPMM_GO(4);
   }
+  if constexpr (kMaxVec<T> >= 2) {
+    if (vec >= 2) TSAMD_SPMM_GO(2);
+  }
+  TSAMD_SPMM_GO(1);
 #undef TSAMD_SPMM_GO
 }
 
@@ -709,12 +724,14 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   Workspace ws;
   carve(workspace, dtype, reduce, B, M, N, K, E, &ws);
   const size_t es = dtype_size(dtype);
-  const size_t pk = es == 2 ? 8 : 16;  // packet bytes per lane (see dispatch_spmm)
-  const bool vec_ok = (K * es) % pk == 0 && ((uintptr_t)mat % pk == 0) &&
-                      ((uintptr_t)out % pk == 0) && (!minmax || (uintptr_t)arg_out % 64 == 0);
+  int vec = es == 2 ? 4 : (int)(16 / es);  // widest packet for the type (see dispatch_spmm)
+  while (vec > 1 && !((K % vec) == 0 && ((uintptr_t)mat % (vec * es)) == 0 &&
+                      ((uintptr_t)out % (vec * es)) == 0 &&
+                      (!minmax || ((uintptr_t)arg_out % (vec * 8)) == 0)))
+    vec >>= 1;
 
   return TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
-    return dispatch_spmm<scalar_t>(reduce, vec_ok, rowptr, col, value, mat, out, arg_out, B, M, N,
+    return dispatch_spmm<scalar_t>(reduce, vec, rowptr, col, value, mat, out, arg_out, B, M, N,
                                    K, E, ws, stream, ev);
   });
 }
