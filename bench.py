@@ -145,7 +145,7 @@ def main():
     ap.add_argument('--exchange', default='pipelined', choices=['pipelined', 'halo', 'allgather'],
                     help='N > 1: all_gather of X | halo = all_to_all of the referenced rows only | '
                          'pipelined = halo exchange in row pieces, overlapped with the SpMM of the previous piece')
-    ap.add_argument('--chunks', type=int, default=4, help='row pieces of the pipelined exchange')
+    ap.add_argument('--chunks', type=int, default=8, help='row pieces of the pipelined exchange')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
