@@ -325,3 +325,38 @@ def test_spmm_fuzz_small_shapes(dev):
         except AssertionError as exc:
             raise AssertionError('case %d: M=%d N=%d E=%d K=%d %s %s batch=%s value=%s kind=%d: %s' % (
                 case, M, N, E, K, dtype, reduce, batch, has_value, kind, exc))
+
+
+def test_backward_kernels_full_size_exact(dev):
+    """BASELINE size (2^20 R-MAT, F = 64): small-integer inputs make every product and sum exact in
+    fp32, so the value gradient and the min/max backward can be compared bit-for-bit with the
+    reference's own formulas evaluated by ATen in fp64 (csrc/spmm.cpp:96-98, 204-242)."""
+    scale, K = 20, 64
+    n = 1 << scale
+    rp, c = synth.rmat_csr(scale, 20, seed=0, device=dev)
+    E = c.numel()
+    row = nat.ptr2ind(rp, E)
+    g = torch.Generator(device=dev).manual_seed(8)
+    x = torch.randint(-3, 4, (n, K), generator=g, device=dev).float()
+    go = torch.randint(-3, 4, (n, K), generator=g, device=dev).float()
+    v = torch.randint(1, 4, (E, ), generator=g, device=dev).float()
+    # value gradient: sum over k of x[col] * g[row], chunked to bound the temporary
+    gv = nat.spmm_value_bw(row, rp, c, x, go, 'sum')
+    for s in range(0, E, 1 << 22):
+        e = min(E, s + (1 << 22))
+        ref = (x[c[s:e]].double() * go[row[s:e]].double()).sum(1)
+        assert torch.equal(gv[s:e].double(), ref), s
+    deg = (rp[1:] - rp[:-1]).clamp(min=1)
+    gvm = nat.spmm_value_bw(None, rp, c, x, go, 'mean')
+    assert torch.allclose(gvm, gv / deg[row].float(), rtol=1e-6, atol=0)
+    # min/max backward against the ATen composition of the reference
+    out, arg = nat.spmm(rp, c, v, x, 'max')
+    gval, gmat = nat.spmm_minmax_bw(c, v, x, go, arg)
+    invalid = arg == E
+    a = arg.masked_fill(invalid, 0)
+    ind = c[a]
+    contrib = (x.gather(0, ind) * go).masked_fill(invalid, 0)
+    ref_gval = torch.zeros(E, dtype=torch.float64, device=dev).scatter_add_(0, a.flatten(), contrib.double().flatten())
+    ref_gmat = torch.zeros(n, K, dtype=torch.float64, device=dev).scatter_add_(0, ind, (v[a] * go).masked_fill(invalid, 0).double())
+    assert torch.equal(gval.double(), ref_gval)
+    assert torch.equal(gmat.double(), ref_gmat)
