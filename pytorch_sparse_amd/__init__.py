@@ -29,7 +29,7 @@ def load_ops():
     if not os.path.exists(_OPS) or not os.path.exists(os.path.join(_LIBDIR, 'libtsamd.so')):
         raise ImportError(
             "pytorch_sparse_amd: native libraries not found in %s. Build them with "
-            "`python -m pytorch_sparse_amd.build` (hipcc, --offload-arch=gfx950). "
+            "`python pytorch_sparse_amd/build.py` (hipcc, --offload-arch=gfx950). "
             "There is no CPU fallback." % _LIBDIR)
     torch.ops.load_library(_OPS)
     _ops_loaded = True

@@ -46,7 +46,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 'pytorch_sparse_amd: %s is missing. Build it with '
-                '`python -m pytorch_sparse_amd.build` (needs hipcc, targets gfx950). '
+                '`python pytorch_sparse_amd/build.py` (needs hipcc, targets gfx950). '
                 'There is no CPU fallback.' % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
         L.tsamd_hip_version.restype = ctypes.c_int64

@@ -5,7 +5,7 @@
   lib/_tsamd_ops.so    torch operator glue: registers torch_sparse::* ops with the
                        reference's schemas on top of libtsamd.so (g++, links torch)
 
-Run as ``python -m pytorch_sparse_amd.build`` or through ``__graft_entry__.build()``.
+Run as ``python pytorch_sparse_amd/build.py`` or through ``__graft_entry__.build()``.
 Objects are cached under ``build/`` and rebuilt when a source or header is newer.
 hipcc cross-compiles, so this works on a machine without a GPU.
 """
