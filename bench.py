@@ -255,7 +255,10 @@ def main():
                         peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=traffic, algorithmic_bytes_per_launch=balg,
                         kernel_ms=round(k_ms, 4), partition_ms=round(prof[0], 4), fixup_ms=round(prof[2], 4),
-                        whole_op_frac=round(balg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None)
+                        whole_op_frac=round(balg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
+                        note='achieved = algorithmic (no-reuse) bytes / kernel time; it can exceed the HBM peak because '
+                             'part of the gathered rows is served by L2 (compare traffic); whole_op_frac also counts '
+                             'the relabel copy, partition and fix-up kernels of the same tsamd_spmm call')
         line = dict(metric='SpMM GEdges/s', value=round(gedges, 3), unit='GEdges/s', n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
