@@ -224,6 +224,82 @@ int tsamd_spspmm_compact(int dtype, const int64_t *rowC, const int64_t *rowptrC,
                          const int64_t *prodptr, const int64_t *colT, const void *valT,
                          int64_t nnz, int64_t *colC, void *valC, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Sub-matrix extraction (the callers either side of the sharded
+ * SpMM path).  Pure index work on a sorted pattern; order preserving.
+ *
+ * select -- pick K segments (rows of a CSR, or columns of a CSC) by id, duplicates and
+ * negative (wrapping) ids allowed.  Replaces torch_sparse/index_select.py:13-68 (rowcount[idx],
+ * cumsum, repeat_interleave, torch_scatter.gather_csr, fancy-index gathers).
+ *   1. tsamd_select_plan: out_ptr[K+1] = exclusive scan of the picked segment lengths;
+ *        info[0] = total entries, info[1] = number of ids outside [-S, S)  (device, 2 int64).
+ *   2. host reads info (the one sync: the output size is data dependent), allocates.
+ *   3. tsamd_select_fill: for output entry e of output segment i:
+ *        seg_out[e] = i, ind_out[e] = ind[src], pos_out[e] = src  with
+ *        src = ptr[idx[i]] + (e - out_ptr[i]).  Any of the three outputs may be NULL.
+ *
+ * filter -- keep the entries of a COO list that satisfy a predicate.  Replaces the
+ * boolean-mask compositions of torch_sparse/narrow.py:44-50, masked_select.py:15-90 and
+ * diag.py:10-17 (compare -> nonzero -> gathers).
+ *   1. tsamd_filter_plan: pos[n+1] = exclusive scan of the keep flags, *count = kept entries.
+ *        pred TSAMD_KEEP_COL_RANGE: a <= col < a + b      TSAMD_KEEP_OFF_DIAG: row != col - a
+ *        TSAMD_KEEP_MASK: mask[i]   TSAMD_KEEP_MASK_ROW: mask[row[i]]   TSAMD_KEEP_MASK_COL:
+ *        mask[col[i]]   (mask = one byte per element, non-zero keeps).  With TSAMD_KEEP_MASK and
+ *        row = col = NULL, pos is the rank of every set mask byte (new id of a kept row/column).
+ *   2. host reads *count, allocates.
+ *   3. tsamd_filter_apply: kept entry i goes to slot pos[i]:
+ *        row_out = (row_map ? row_map[row] : row) - row_shift, same for col, src_out = i.
+ * ------------------------------------------------------------------------ */
+enum {
+  TSAMD_KEEP_COL_RANGE = 0,
+  TSAMD_KEEP_OFF_DIAG = 1,
+  TSAMD_KEEP_MASK = 2,
+  TSAMD_KEEP_MASK_ROW = 3,
+  TSAMD_KEEP_MASK_COL = 4
+};
+size_t tsamd_select_workspace_bytes(int64_t K);
+int tsamd_select_plan(const int64_t *ptr, int64_t S, const int64_t *idx, int64_t K,
+                      int64_t *out_ptr, int64_t *info, void *workspace, size_t workspace_bytes,
+                      void *stream);
+int tsamd_select_fill(const int64_t *ptr, int64_t S, const int64_t *ind, const int64_t *idx,
+                      int64_t K, const int64_t *out_ptr, int64_t total, int64_t *seg_out,
+                      int64_t *ind_out, int64_t *pos_out, void *stream);
+size_t tsamd_filter_workspace_bytes(int64_t n);
+int tsamd_filter_plan(int pred, const int64_t *row, const int64_t *col, const uint8_t *mask,
+                      int64_t n, int64_t a, int64_t b, int64_t *pos, int64_t *count,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int tsamd_filter_apply(const int64_t *pos, const int64_t *row, const int64_t *col, int64_t n,
+                       const int64_t *row_map, const int64_t *col_map, int64_t row_shift,
+                       int64_t col_shift, int64_t *row_out, int64_t *col_out, int64_t *src_out,
+                       void *stream);
+
+/* Column-wise concatenation without a sort (replaces the cat + re-sort of
+ * torch_sparse/cat.py:117-165): entry i of one operand goes to slot i + delta[row[i]] of the
+ * row-interleaved output, with  delta[r] = out_rowptr[r] + (entries of earlier operands in
+ * row r) - rowptr[r];  row_out = row, col_out = col + col_shift, src_out = src_offset + i.
+ * Called once per operand on the same output arrays. */
+int tsamd_scatter_rows(const int64_t *row, const int64_t *col, int64_t n, const int64_t *delta,
+                       int64_t col_shift, int64_t src_offset, int64_t *row_out, int64_t *col_out,
+                       int64_t *src_out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Diagonal insertion into a sorted pattern WITHOUT entries on the k-th diagonal.
+ * tsamd_num_diag        = length of the k-th diagonal of an M x N matrix.
+ * tsamd_non_diag_mask   replaces non_diag_mask_cpu / non_diag_mask_cuda
+ *                       (csrc/cpu/diag_cpu.cpp:5-47, csrc/cuda/diag_cuda.cu:9-62):
+ *                       mask[E + num_diag] (bytes) is 1 at the slots the existing entries keep
+ *                       once the full diagonal is merged in, 0 at the diagonal's slots.
+ * tsamd_insert_diag     does the merge itself (replaces the mask + four boolean-mask scatters of
+ *                       torch_sparse/diag.py:37-79): row_out/col_out[E + num_diag] is the merged
+ *                       sorted pattern, src_out[p] = old position of an existing entry, or
+ *                       E + j for the j-th diagonal entry (one gather assembles the values).
+ * ------------------------------------------------------------------------ */
+int64_t tsamd_num_diag(int64_t M, int64_t N, int64_t k);
+int tsamd_non_diag_mask(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                        int64_t k, uint8_t *mask, void *stream);
+int tsamd_insert_diag(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                      int64_t k, int64_t *row_out, int64_t *col_out, int64_t *src_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

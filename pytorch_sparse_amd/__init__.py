@@ -46,10 +46,18 @@ from .coalesce import coalesce  # noqa: E402
 from .spmm import spmm  # noqa: E402
 from .spspmm import spspmm  # noqa: E402
 from .reduce import sum, mean, min, max  # noqa: E402,A004
-from .mul import mul, mul_nnz, add  # noqa: E402
+from .mul import mul, mul_, mul_nnz, mul_nnz_, add, add_, add_nnz, add_nnz_  # noqa: E402
+from .select import (narrow, __narrow_diag__, select, index_select, index_select_nnz,  # noqa: E402
+                     masked_select, masked_select_nnz, permute)
+from .cat import cat  # noqa: E402
+from .diag import remove_diag, set_diag, fill_diag, get_diag  # noqa: E402
+from .convert import to_torch_sparse, from_torch_sparse, to_scipy, from_scipy, eye, spadd  # noqa: E402
 
 __all__ = [
     'SparseStorage', 'SparseTensor', 't', 'transpose', 'matmul', 'coalesce', 'spmm', 'spspmm',
-    'sum', 'mean', 'min', 'max', 'mul', 'mul_nnz', 'add',
+    'sum', 'mean', 'min', 'max', 'mul', 'mul_', 'mul_nnz', 'mul_nnz_', 'add', 'add_', 'add_nnz',
+    'add_nnz_', 'narrow', '__narrow_diag__', 'select', 'index_select', 'index_select_nnz',
+    'masked_select', 'masked_select_nnz', 'permute', 'cat', 'remove_diag', 'set_diag', 'fill_diag',
+    'get_diag', 'to_torch_sparse', 'from_torch_sparse', 'to_scipy', 'from_scipy', 'eye', 'spadd',
     '__version__',
 ]

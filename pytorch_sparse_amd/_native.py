@@ -24,6 +24,10 @@ SYMBOLS = [
     'tsamd_exclusive_scan_workspace_bytes', 'tsamd_exclusive_scan_i64',
     'tsamd_spspmm_plan_workspace_bytes', 'tsamd_spspmm_plan', 'tsamd_spspmm_rows_workspace_bytes',
     'tsamd_spspmm_rows', 'tsamd_spspmm_compact',
+    'tsamd_select_workspace_bytes', 'tsamd_select_plan', 'tsamd_select_fill',
+    'tsamd_filter_workspace_bytes', 'tsamd_filter_plan', 'tsamd_filter_apply',
+    'tsamd_scatter_rows',
+    'tsamd_num_diag', 'tsamd_non_diag_mask', 'tsamd_insert_diag',
 ]
 
 DTYPES = {

@@ -1,0 +1,334 @@
+// Sub-matrix extraction on gfx950: segment (row / column) selection and predicate filtering of
+// a sorted COO/CSR pattern.  SURVEY.md section 8f rank 3 -- the callers either side of the
+// sharded SpMM path.  Replaces the ATen/torch_scatter compositions of the reference:
+//   * index_select(dim 0/1)    torch_sparse/index_select.py:13-68   (rowcount[idx], cumsum,
+//                              repeat_interleave, gather_csr, three fancy-index gathers)
+//   * masked_select(dim 0/1)   torch_sparse/masked_select.py:15-63  (mask[row], boolean-index
+//                              compaction = nonzero + gathers, repeat_interleave)
+//   * narrow(dim 1)            torch_sparse/narrow.py:44-50         (two compares, boolean index)
+//   * remove_diag              torch_sparse/diag.py:10-17
+//   * masked_select_nnz        torch_sparse/masked_select.py:76-90
+// with two fused primitives, each a fixed three-launch sequence and one data-dependent size:
+//   select  : counts of the picked segments -> device scan -> one streaming fill that writes
+//             the new segment ids, the gathered indices and the source positions (for values)
+//   filter  : predicate flags -> device scan -> one compaction that writes shifted / remapped
+//             (row, col) and the source positions
+// Pure index work, HBM-bound; order preserving, so sorted input gives sorted output.
+#include "common.h"
+#include "scan.h"
+
+namespace tsamd {
+namespace {
+
+// cnt[i] = length of segment idx[i] (negative ids wrap like torch indexing); ids outside
+// [-S, S) are counted in *err and contribute an empty segment.
+__global__ void select_count_kernel(const int64_t *__restrict__ ptr, int64_t S,
+                                    const int64_t *__restrict__ idx, int64_t K,
+                                    int64_t *__restrict__ cnt, unsigned long long *err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  int64_t j = idx[i];
+  if (j < 0) j += S;
+  if (j < 0 || j >= S) {
+    atomicAdd(err, 1ull);
+    cnt[i] = 0;
+    return;
+  }
+  cnt[i] = ptr[j + 1] - ptr[j];
+}
+
+constexpr int kSegPerBlock = 256;
+
+// A workgroup owns 256 consecutive OUTPUT segments: their output offsets and source starts go
+// to LDS, then the block streams over its output range with coalesced stores; each thread
+// finds its segment by a binary search in LDS (8 steps), so hub segments cost nothing extra.
+__global__ __launch_bounds__(256) void select_fill_kernel(
+    const int64_t *__restrict__ ptr, int64_t S, const int64_t *__restrict__ ind,
+    const int64_t *__restrict__ idx, int64_t K, const int64_t *__restrict__ out_ptr,
+    int64_t *__restrict__ seg_out, int64_t *__restrict__ ind_out, int64_t *__restrict__ pos_out) {
+  __shared__ int64_t so[kSegPerBlock + 1];
+  __shared__ int64_t ss[kSegPerBlock];
+  const int64_t s0 = (int64_t)blockIdx.x * kSegPerBlock;
+  const int nseg = (int)((K - s0) < kSegPerBlock ? (K - s0) : kSegPerBlock);
+  for (int i = threadIdx.x; i <= nseg; i += blockDim.x) so[i] = out_ptr[s0 + i];
+  for (int i = threadIdx.x; i < nseg; i += blockDim.x) {
+    int64_t j = idx[s0 + i];
+    if (j < 0) j += S;
+    ss[i] = (j >= 0 && j < S) ? ptr[j] : 0;
+  }
+  __syncthreads();
+  const int64_t e0 = so[0], e1 = so[nseg];
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    int lo = 0, hi = nseg;  // last i with so[i] <= e
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (so[mid] <= e) lo = mid; else hi = mid;
+    }
+    const int64_t src = ss[lo] + (e - so[lo]);
+    if (seg_out) seg_out[e] = s0 + lo;
+    if (ind_out) ind_out[e] = ind[src];
+    if (pos_out) pos_out[e] = src;
+  }
+}
+
+__device__ inline bool keep_entry(int pred, const int64_t *row, const int64_t *col,
+                                  const uint8_t *mask, int64_t i, int64_t a, int64_t b) {
+  switch (pred) {
+    case TSAMD_KEEP_COL_RANGE: {
+      const int64_t c = col[i];
+      return c >= a && c < a + b;
+    }
+    case TSAMD_KEEP_OFF_DIAG: return row[i] != col[i] - a;
+    case TSAMD_KEEP_MASK: return mask[i] != 0;
+    case TSAMD_KEEP_MASK_ROW: return mask[row[i]] != 0;
+    case TSAMD_KEEP_MASK_COL: return mask[col[i]] != 0;
+    default: return false;
+  }
+}
+
+__global__ void filter_flags_kernel(int pred, const int64_t *__restrict__ row,
+                                    const int64_t *__restrict__ col,
+                                    const uint8_t *__restrict__ mask, int64_t n, int64_t a,
+                                    int64_t b, int64_t *__restrict__ pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[i] = keep_entry(pred, row, col, mask, i, a, b) ? 1 : 0;
+}
+
+// pos = exclusive scan of the keep flags with pos[n] = count; entry i is kept iff pos[i+1] > pos[i]
+__global__ void filter_apply_kernel(const int64_t *__restrict__ pos, const int64_t *__restrict__ row,
+                                    const int64_t *__restrict__ col, int64_t n,
+                                    const int64_t *__restrict__ row_map,
+                                    const int64_t *__restrict__ col_map, int64_t row_shift,
+                                    int64_t col_shift, int64_t *__restrict__ row_out,
+                                    int64_t *__restrict__ col_out, int64_t *__restrict__ src_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = pos[i];
+  if (pos[i + 1] == p) return;
+  if (row_out) {
+    const int64_t r = row[i];
+    row_out[p] = (row_map ? row_map[r] : r) - row_shift;
+  }
+  if (col_out) {
+    const int64_t c = col[i];
+    col_out[p] = (col_map ? col_map[c] : c) - col_shift;
+  }
+  if (src_out) src_out[p] = i;
+}
+
+// Column-wise concatenation (cat_second): entry e of one operand lands at e + delta[row[e]] of the
+// row-interleaved output, delta[r] = out_rowptr[r] + (entries of earlier operands in row r) - rowptr[r].
+__global__ void scatter_rows_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+                                    int64_t n, const int64_t *__restrict__ delta, int64_t col_shift,
+                                    int64_t src_offset, int64_t *__restrict__ row_out,
+                                    int64_t *__restrict__ col_out, int64_t *__restrict__ src_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t r = row[i];
+  const int64_t p = i + delta[r];
+  if (row_out) row_out[p] = r;
+  if (col_out) col_out[p] = col[i] + col_shift;
+  if (src_out) src_out[p] = src_offset + i;
+}
+
+// ---- diagonal insertion (reference: csrc/cpu/diag_cpu.cpp:5-47, torch_sparse/diag.py:37-79) ----
+// Number of entries of the k-th diagonal {(d, d + k) : start <= d < start + num_diag} that precede
+// the off-diagonal entry (r, c) in row-major order.
+__device__ inline int64_t diag_before(int64_t r, int64_t c, int64_t k, int64_t start,
+                                      int64_t num_diag) {
+  int64_t below = r - start;
+  below = below < 0 ? 0 : (below > num_diag ? num_diag : below);
+  const bool own = r >= start && r < start + num_diag && r + k < c;
+  return below + (own ? 1 : 0);
+}
+
+// mask[E + num_diag]: true at the slots the existing (off-diagonal, sorted) entries move to
+__global__ void non_diag_mask_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+                                     int64_t E, int64_t k, int64_t start, int64_t num_diag,
+                                     uint8_t *__restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  const int64_t r = row[i], c = col[i];
+  // an entry ON the diagonal keeps no slot (the reference leaves its mask byte unset as well)
+  if (r >= start && r < start + num_diag && r + k == c) return;
+  mask[i + diag_before(r, c, k, start, num_diag)] = 1;
+}
+
+// fused set_diag: existing entries move to their slots, src = their old position ...
+__global__ void insert_diag_move_kernel(const int64_t *__restrict__ row,
+                                        const int64_t *__restrict__ col, int64_t E, int64_t k,
+                                        int64_t start, int64_t num_diag, int64_t *__restrict__ row_out,
+                                        int64_t *__restrict__ col_out, int64_t *__restrict__ src_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  const int64_t r = row[i], c = col[i];
+  const int64_t p = i + diag_before(r, c, k, start, num_diag);
+  row_out[p] = r;
+  col_out[p] = c;
+  src_out[p] = i;
+}
+
+// ... and diagonal entry j lands after the `lower_bound` of (d, d + k) among the existing
+// entries plus the j diagonal entries before it; src = E + j.
+__global__ void insert_diag_fill_kernel(const int64_t *__restrict__ row,
+                                        const int64_t *__restrict__ col, int64_t E, int64_t k,
+                                        int64_t start, int64_t num_diag, int64_t *__restrict__ row_out,
+                                        int64_t *__restrict__ col_out, int64_t *__restrict__ src_out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= num_diag) return;
+  const int64_t d = start + j, c = d + k;
+  int64_t lo = 0, hi = E;  // first i with (row[i], col[i]) >= (d, c)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    const int64_t r = row[mid];
+    if (r < d || (r == d && col[mid] < c)) lo = mid + 1; else hi = mid;
+  }
+  const int64_t p = lo + j;
+  row_out[p] = d;
+  col_out[p] = c;
+  src_out[p] = E + j;
+}
+
+}  // namespace
+}  // namespace tsamd
+
+using namespace tsamd;
+
+extern "C" size_t tsamd_select_workspace_bytes(int64_t K) { return scan_workspace_bytes(K + 1); }
+
+extern "C" int tsamd_select_plan(const int64_t *ptr, int64_t S, const int64_t *idx, int64_t K,
+                                 int64_t *out_ptr, int64_t *info, void *workspace,
+                                 size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (S < 0 || K < 0 || !out_ptr || !info || !ptr) return TSAMD_ERR_INVALID;
+  if (K > 0 && !idx) return TSAMD_ERR_INVALID;
+  if (!workspace || workspace_bytes < tsamd_select_workspace_bytes(K)) return TSAMD_ERR_WORKSPACE;
+  TSAMD_HIP_TRY(hipMemsetAsync(info, 0, 2 * sizeof(int64_t), stream));
+  // out_ptr[K] = 0 so that the scan over K+1 counts leaves the total in out_ptr[K]
+  TSAMD_HIP_TRY(hipMemsetAsync(out_ptr + K, 0, sizeof(int64_t), stream));
+  if (K > 0) {
+    hipLaunchKernelGGL(select_count_kernel, dim3((unsigned int)ceil_div(K, 256)), dim3(256), 0,
+                       stream, ptr, S, idx, K, out_ptr,
+                       reinterpret_cast<unsigned long long *>(info + 1));
+    TSAMD_LAUNCH_CHECK();
+  }
+  return exclusive_scan_i64(out_ptr, out_ptr, K + 1, info, workspace, stream);
+}
+
+extern "C" int tsamd_select_fill(const int64_t *ptr, int64_t S, const int64_t *ind,
+                                 const int64_t *idx, int64_t K, const int64_t *out_ptr,
+                                 int64_t total, int64_t *seg_out, int64_t *ind_out,
+                                 int64_t *pos_out, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (S < 0 || K < 0 || total < 0) return TSAMD_ERR_INVALID;
+  if (K == 0 || total == 0) return TSAMD_OK;
+  if (!ptr || !idx || !out_ptr || (ind_out && !ind)) return TSAMD_ERR_INVALID;
+  hipLaunchKernelGGL(select_fill_kernel, dim3((unsigned int)ceil_div(K, kSegPerBlock)), dim3(256), 0,
+                     stream, ptr, S, ind, idx, K, out_ptr, seg_out, ind_out, pos_out);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+extern "C" size_t tsamd_filter_workspace_bytes(int64_t n) { return scan_workspace_bytes(n + 1); }
+
+extern "C" int tsamd_filter_plan(int pred, const int64_t *row, const int64_t *col,
+                                 const uint8_t *mask, int64_t n, int64_t a, int64_t b, int64_t *pos,
+                                 int64_t *count, void *workspace, size_t workspace_bytes,
+                                 void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || !pos || !count) return TSAMD_ERR_INVALID;
+  if (pred < TSAMD_KEEP_COL_RANGE || pred > TSAMD_KEEP_MASK_COL) return TSAMD_ERR_UNSUPPORTED;
+  const bool need_row = pred == TSAMD_KEEP_OFF_DIAG || pred == TSAMD_KEEP_MASK_ROW;
+  const bool need_col =
+      pred == TSAMD_KEEP_COL_RANGE || pred == TSAMD_KEEP_OFF_DIAG || pred == TSAMD_KEEP_MASK_COL;
+  const bool need_mask = pred >= TSAMD_KEEP_MASK;
+  if (n > 0 && ((need_row && !row) || (need_col && !col) || (need_mask && !mask)))
+    return TSAMD_ERR_INVALID;
+  if (!workspace || workspace_bytes < tsamd_filter_workspace_bytes(n)) return TSAMD_ERR_WORKSPACE;
+  TSAMD_HIP_TRY(hipMemsetAsync(pos + n, 0, sizeof(int64_t), stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(filter_flags_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0,
+                       stream, pred, row, col, mask, n, a, b, pos);
+    TSAMD_LAUNCH_CHECK();
+  }
+  return exclusive_scan_i64(pos, pos, n + 1, count, workspace, stream);
+}
+
+extern "C" int tsamd_filter_apply(const int64_t *pos, const int64_t *row, const int64_t *col,
+                                  int64_t n, const int64_t *row_map, const int64_t *col_map,
+                                  int64_t row_shift, int64_t col_shift, int64_t *row_out,
+                                  int64_t *col_out, int64_t *src_out, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0) return TSAMD_ERR_INVALID;
+  if (n == 0) return TSAMD_OK;
+  if (!pos || (row_out && !row) || (col_out && !col)) return TSAMD_ERR_INVALID;
+  hipLaunchKernelGGL(filter_apply_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
+                     pos, row, col, n, row_map, col_map, row_shift, col_shift, row_out, col_out,
+                     src_out);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+extern "C" int tsamd_scatter_rows(const int64_t *row, const int64_t *col, int64_t n,
+                                  const int64_t *delta, int64_t col_shift, int64_t src_offset,
+                                  int64_t *row_out, int64_t *col_out, int64_t *src_out,
+                                  void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0) return TSAMD_ERR_INVALID;
+  if (n == 0) return TSAMD_OK;
+  if (!row || !delta || (col_out && !col)) return TSAMD_ERR_INVALID;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
+                     row, col, n, delta, col_shift, src_offset, row_out, col_out, src_out);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+static inline void diag_extent(int64_t M, int64_t N, int64_t k, int64_t *start, int64_t *num_diag) {
+  int64_t n = k < 0 ? (M + k < N ? M + k : N) : (M < N - k ? M : N - k);
+  *num_diag = n < 0 ? 0 : n;
+  *start = k < 0 ? -k : 0;
+}
+
+extern "C" int64_t tsamd_num_diag(int64_t M, int64_t N, int64_t k) {
+  int64_t start, n;
+  diag_extent(M, N, k, &start, &n);
+  return n;
+}
+
+extern "C" int tsamd_non_diag_mask(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
+                                   int64_t N, int64_t k, uint8_t *mask, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (E < 0 || M < 0 || N < 0) return TSAMD_ERR_INVALID;
+  int64_t start, num_diag;
+  diag_extent(M, N, k, &start, &num_diag);
+  if (E + num_diag == 0) return TSAMD_OK;
+  if (!mask || (E > 0 && (!row || !col))) return TSAMD_ERR_INVALID;
+  TSAMD_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)(E + num_diag), stream));
+  if (E == 0) return TSAMD_OK;
+  hipLaunchKernelGGL(non_diag_mask_kernel, dim3((unsigned int)ceil_div(E, 256)), dim3(256), 0, stream,
+                     row, col, E, k, start, num_diag, mask);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+extern "C" int tsamd_insert_diag(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
+                                 int64_t N, int64_t k, int64_t *row_out, int64_t *col_out,
+                                 int64_t *src_out, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (E < 0 || M < 0 || N < 0) return TSAMD_ERR_INVALID;
+  int64_t start, num_diag;
+  diag_extent(M, N, k, &start, &num_diag);
+  if (E + num_diag == 0) return TSAMD_OK;
+  if (!row_out || !col_out || !src_out || (E > 0 && (!row || !col))) return TSAMD_ERR_INVALID;
+  if (E > 0) {
+    hipLaunchKernelGGL(insert_diag_move_kernel, dim3((unsigned int)ceil_div(E, 256)), dim3(256), 0,
+                       stream, row, col, E, k, start, num_diag, row_out, col_out, src_out);
+    TSAMD_LAUNCH_CHECK();
+  }
+  if (num_diag > 0) {
+    hipLaunchKernelGGL(insert_diag_fill_kernel, dim3((unsigned int)ceil_div(num_diag, 256)), dim3(256),
+                       0, stream, row, col, E, k, start, num_diag, row_out, col_out, src_out);
+    TSAMD_LAUNCH_CHECK();
+  }
+  return TSAMD_OK;
+}

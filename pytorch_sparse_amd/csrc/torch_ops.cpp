@@ -465,6 +465,200 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   return std::make_tuple(rowptrC, colC, valC);
 }
 
+// ---- sub-matrix extraction (include/tsamd.h "select" / "filter") ---------
+// Pick K segments of a (ptr, ind) pattern: -> (out_ptr[K+1], seg[T], ind_out[T], pos[T]) where
+// seg/ind_out are empty unless asked for.  One host sync (T is data dependent); ids outside
+// [-S, S) raise IndexError like torch indexing does.
+std::tuple<Tensor, Tensor, Tensor, Tensor> select_segments(Tensor ptr, Tensor ind, Tensor idx,
+                                                           bool want_seg, bool want_ind) {
+  check_index(ptr, "ptr");
+  check_index(ind, "ind");
+  check_index(idx, "idx");
+  TORCH_CHECK(ptr.numel() >= 1, "select_segments: empty ptr");
+  c10::hip::HIPGuard guard(ptr.get_device());
+  ptr = ptr.contiguous();
+  ind = ind.contiguous();
+  idx = idx.contiguous();
+  const int64_t S = ptr.numel() - 1, K = idx.numel();
+  auto iopt = ptr.options().requires_grad(false);
+  void *stream = current_stream(ptr);
+  Tensor out_ptr = torch::empty({K + 1}, iopt), info = torch::empty({2}, iopt);
+  Tensor ws = workspace(tsamd_select_workspace_bytes(K), ptr);
+  check_status(tsamd_select_plan(ptr.data_ptr<int64_t>(), S, idx.data_ptr<int64_t>(), K,
+                                 out_ptr.data_ptr<int64_t>(), info.data_ptr<int64_t>(),
+                                 ws.data_ptr(), (size_t)ws.numel(), stream),
+               "tsamd_select_plan");
+  Tensor h = info.cpu();  // the one sync
+  const int64_t total = h.data_ptr<int64_t>()[0], bad = h.data_ptr<int64_t>()[1];
+  TORCH_CHECK_INDEX(bad == 0, "index out of range: ", bad, " of ", K,
+                    " selected ids are outside [-", S, ", ", S, ")");
+  TORCH_CHECK(total <= ind.numel() * (K > 0 ? K : 1), "select_segments: inconsistent ptr");
+  Tensor seg = torch::empty({want_seg ? total : 0}, iopt);
+  Tensor ind_out = torch::empty({want_ind ? total : 0}, iopt);
+  Tensor pos = torch::empty({total}, iopt);
+  check_status(tsamd_select_fill(ptr.data_ptr<int64_t>(), S, ind.data_ptr<int64_t>(),
+                                 idx.data_ptr<int64_t>(), K, out_ptr.data_ptr<int64_t>(), total,
+                                 want_seg ? seg.data_ptr<int64_t>() : nullptr,
+                                 want_ind ? ind_out.data_ptr<int64_t>() : nullptr,
+                                 pos.data_ptr<int64_t>(), stream),
+               "tsamd_select_fill");
+  return std::make_tuple(out_ptr, seg, ind_out, pos);
+}
+
+int keep_code(const std::string &p) {
+  if (p == "col_range") return TSAMD_KEEP_COL_RANGE;
+  if (p == "off_diag") return TSAMD_KEEP_OFF_DIAG;
+  if (p == "mask") return TSAMD_KEEP_MASK;
+  if (p == "mask_row") return TSAMD_KEEP_MASK_ROW;
+  if (p == "mask_col") return TSAMD_KEEP_MASK_COL;
+  TORCH_CHECK(false, "unknown predicate '", p, "'");
+}
+
+// Keep the entries of (row, col) that satisfy `pred` -> (row_out, col_out, src, n_mask).
+// remap (mask_row / mask_col only): kept rows / columns are renumbered by their rank among the set
+// mask bytes and n_mask is the number of set bytes (the new sparse size); otherwise n_mask = -1.
+// One host sync.  The caller guarantees len(mask) covers every row / col id it is indexed with.
+std::tuple<Tensor, Tensor, Tensor, int64_t> filter_coo(std::string pred, OptTensor row_,
+                                                       OptTensor col_, OptTensor mask_, int64_t a,
+                                                       int64_t b, bool remap, int64_t row_shift,
+                                                       int64_t col_shift, bool want_row,
+                                                       bool want_col) {
+  const int code = keep_code(pred);
+  TORCH_CHECK(row_.has_value() || col_.has_value() || mask_.has_value(), "filter_coo: no input");
+  const Tensor &like = row_.has_value() ? row_.value() : (col_.has_value() ? col_.value() : mask_.value());
+  c10::hip::HIPGuard guard(like.get_device());
+  Tensor row, col, mask;
+  int64_t n = -1;
+  if (row_.has_value()) {
+    check_index(row_.value(), "row");
+    row = row_.value().contiguous();
+    n = row.numel();
+  }
+  if (col_.has_value()) {
+    check_index(col_.value(), "col");
+    col = col_.value().contiguous();
+    TORCH_CHECK(n < 0 || n == col.numel(), "row and col differ in length");
+    n = col.numel();
+  }
+  if (mask_.has_value()) {
+    check_gpu(mask_.value(), "mask");
+    TORCH_CHECK(mask_.value().dim() == 1 && (mask_.value().scalar_type() == at::kBool ||
+                                             mask_.value().scalar_type() == at::kByte),
+                "mask must be a 1-D bool / uint8 tensor");
+    mask = mask_.value().contiguous();
+    if (code == TSAMD_KEEP_MASK) {
+      TORCH_CHECK(n < 0 || n == mask.numel(), "mask and index differ in length");
+      n = mask.numel();
+    }
+  }
+  TORCH_CHECK(n >= 0, "filter_coo: nothing to filter");
+  TORCH_CHECK(code < TSAMD_KEEP_MASK || mask.defined(), "predicate '", pred, "' needs a mask");
+  TORCH_CHECK(!remap || code == TSAMD_KEEP_MASK_ROW || code == TSAMD_KEEP_MASK_COL,
+              "remap needs a mask_row / mask_col predicate");
+  TORCH_CHECK(!want_row || row.defined(), "want_row without row");
+  TORCH_CHECK(!want_col || col.defined(), "want_col without col");
+  auto iopt = like.options().dtype(torch::kLong).requires_grad(false);
+  void *stream = current_stream(like);
+  const uint8_t *mp = mask.defined() ? reinterpret_cast<const uint8_t *>(mask.data_ptr()) : nullptr;
+  const int64_t *rp = row.defined() ? row.data_ptr<int64_t>() : nullptr;
+  const int64_t *cp = col.defined() ? col.data_ptr<int64_t>() : nullptr;
+
+  Tensor cnt = torch::zeros({2}, iopt), rank;
+  if (remap) {
+    const int64_t L = mask.numel();
+    rank = torch::empty({L + 1}, iopt);
+    Tensor ws0 = workspace(tsamd_filter_workspace_bytes(L), like);
+    check_status(tsamd_filter_plan(TSAMD_KEEP_MASK, nullptr, nullptr, mp, L, 0, 0,
+                                   rank.data_ptr<int64_t>(), cnt.data_ptr<int64_t>() + 1,
+                                   ws0.data_ptr(), (size_t)ws0.numel(), stream),
+                 "tsamd_filter_plan");
+  }
+  Tensor pos = torch::empty({n + 1}, iopt);
+  Tensor ws = workspace(tsamd_filter_workspace_bytes(n), like);
+  check_status(tsamd_filter_plan(code, rp, cp, mp, n, a, b, pos.data_ptr<int64_t>(),
+                                 cnt.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
+               "tsamd_filter_plan");
+  Tensor h = cnt.cpu();  // the one sync
+  const int64_t kept = h.data_ptr<int64_t>()[0];
+  const int64_t n_mask = remap ? h.data_ptr<int64_t>()[1] : -1;
+  Tensor row_out = torch::empty({want_row ? kept : 0}, iopt);
+  Tensor col_out = torch::empty({want_col ? kept : 0}, iopt);
+  Tensor src = torch::empty({kept}, iopt);
+  const int64_t *map = remap ? rank.data_ptr<int64_t>() : nullptr;
+  check_status(
+      tsamd_filter_apply(pos.data_ptr<int64_t>(), rp, cp, n,
+                         code == TSAMD_KEEP_MASK_ROW ? map : nullptr,
+                         code == TSAMD_KEEP_MASK_COL ? map : nullptr, row_shift, col_shift,
+                         want_row ? row_out.data_ptr<int64_t>() : nullptr,
+                         want_col ? col_out.data_ptr<int64_t>() : nullptr, src.data_ptr<int64_t>(),
+                         stream),
+      "tsamd_filter_apply");
+  return std::make_tuple(row_out, col_out, src, n_mask);
+}
+
+// One operand of a column-wise concatenation: writes its entries into the preallocated,
+// row-interleaved (row_out, col_out, src_out); see tsamd_scatter_rows.  No sync.
+void scatter_rows(Tensor row, Tensor col, Tensor delta, int64_t col_shift, int64_t src_offset,
+                  Tensor row_out, Tensor col_out, Tensor src_out) {
+  check_index(row, "row");
+  check_index(col, "col");
+  check_index(delta, "delta");
+  check_index(row_out, "row_out");
+  check_index(col_out, "col_out");
+  check_index(src_out, "src_out");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  TORCH_CHECK(row_out.is_contiguous() && col_out.is_contiguous() && src_out.is_contiguous(),
+              "outputs must be contiguous");
+  TORCH_CHECK(row_out.numel() == col_out.numel() && row_out.numel() == src_out.numel() &&
+                  row_out.numel() >= row.numel(),
+              "outputs too small");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  delta = delta.contiguous();
+  check_status(tsamd_scatter_rows(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), row.numel(),
+                                  delta.data_ptr<int64_t>(), col_shift, src_offset,
+                                  row_out.data_ptr<int64_t>(), col_out.data_ptr<int64_t>(),
+                                  src_out.data_ptr<int64_t>(), current_stream(row)),
+               "tsamd_scatter_rows");
+}
+
+// torch_sparse::non_diag_mask(Tensor row, Tensor col, int M, int N, int k) -> Tensor  (reference
+// schema, csrc/diag.cpp:22-36)
+Tensor non_diag_mask(Tensor row, Tensor col, int64_t M, int64_t N, int64_t k) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  Tensor mask = torch::empty({E + tsamd_num_diag(M, N, k)}, row.options().dtype(torch::kBool));
+  check_status(tsamd_non_diag_mask(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N, k,
+                                   reinterpret_cast<uint8_t *>(mask.data_ptr()), current_stream(row)),
+               "tsamd_non_diag_mask");
+  return mask;
+}
+
+// merged (row, col, src) of a sorted off-diagonal pattern and the full k-th diagonal; no sync
+std::tuple<Tensor, Tensor, Tensor> insert_diag(Tensor row, Tensor col, int64_t M, int64_t N,
+                                               int64_t k) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel(), T = E + tsamd_num_diag(M, N, k);
+  Tensor row_out = torch::empty({T}, row.options()), col_out = torch::empty({T}, row.options());
+  Tensor src = torch::empty({T}, row.options());
+  check_status(tsamd_insert_diag(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N, k,
+                                 row_out.data_ptr<int64_t>(), col_out.data_ptr<int64_t>(),
+                                 src.data_ptr<int64_t>(), current_stream(row)),
+               "tsamd_insert_diag");
+  return std::make_tuple(row_out, col_out, src);
+}
+
 }  // namespace
 
 static auto registry = torch::RegisterOperators()
@@ -479,4 +673,9 @@ static auto registry = torch::RegisterOperators()
                            .op("tsamd::sort_coo", &sort_coo)
                            .op("tsamd::coalesce_index", &coalesce_index)
                            .op("tsamd::segment_reduce", &segment_reduce)
-                           .op("tsamd::spspmm", &spspmm);
+                           .op("tsamd::spspmm", &spspmm)
+                           .op("tsamd::select_segments", &select_segments)
+                           .op("tsamd::filter_coo", &filter_coo)
+                           .op("tsamd::scatter_rows", &scatter_rows)
+                           .op("torch_sparse::non_diag_mask", &non_diag_mask)
+                           .op("tsamd::insert_diag", &insert_diag);

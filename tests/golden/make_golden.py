@@ -12,7 +12,12 @@ container (it cannot travel to the GPU box; the fixtures can).
                                   in for the pip dependency.  Runs in a subprocess so the
                                   `torch_sparse::` names never meet the product's.
 
-Usage:  python tests/golden/make_golden.py          (needs /root/reference)
+  part 3  py3_*.npz             : the reference Python package again, on the shared case list of
+                                  tests/golden/cases3.py (narrow / select / index_select /
+                                  masked_select / permute / cat / diag / add / mul), with the
+                                  reference's csrc/cpu/diag_cpu.cpp added to the op library.
+
+Usage:  python tests/golden/make_golden.py [part1] [part2] [part3]     (needs /root/reference)
 """
 import os
 import subprocess
@@ -162,28 +167,66 @@ print('part 2: reference python fixtures written')
 '''
 
 
-def part2():
-    """Import the reference Python from a scratch dir (symlinks + a loader __init__)."""
+PART3 = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ['TS_SCRATCH'])
+sys.path.insert(0, os.environ['TS_GOLDEN'])
+import torch_sparse
+import cases3
+out_dir = os.environ['TS_OUT']
+raw = cases3.make_inputs()
+np.savez_compressed(os.path.join(out_dir, 'py3_inputs.npz'), **{k: v.numpy() for k, v in raw.items()})
+I = cases3.tensors(torch_sparse, cases3.load_inputs(os.path.join(out_dir, 'py3_inputs.npz')), 'cpu')
+n_ok, raised = 0, []
+for name, fn in cases3.all_cases():
+    try:
+        out = fn(torch_sparse, I)
+    except Exception as e:  # the reference itself rejects this call: no fixture
+        raised.append('%s (%s)' % (name, type(e).__name__))
+        continue
+    d = {}
+    if isinstance(out, torch.Tensor):
+        d['dense'] = out.numpy()
+    else:
+        row, col, value = out.coo()
+        d.update(row=row.numpy(), col=col.numpy(), sizes=np.array(out.sparse_sizes()),
+                 rowptr=out.storage.rowptr().numpy())
+        if value is not None:
+            d['value'] = value.numpy()
+    np.savez_compressed(os.path.join(out_dir, 'py3_%s.npz' % name), **d)
+    n_ok += 1
+print('part 3: %d fixtures; the reference raises for: %s' % (n_ok, ', '.join(raised) or '-'))
+"""
+
+
+def make_scratch(modules, op_sources):
+    """A scratch copy of the reference Python package (symlinks + a loader __init__) next to an op
+    library with the reference's own registration names, built straight from its sources."""
     from torch.utils import cpp_extension as ce
     scratch = tempfile.mkdtemp(prefix='ts_ref_py_')
     pkg = os.path.join(scratch, 'torch_sparse')
     os.makedirs(pkg)
     refpkg = os.path.join(REF, 'torch_sparse')
-    keep = ['storage', 'tensor', 'utils', 'typing', 'matmul', 'coalesce', 'transpose', 'spmm', 'spspmm',
-            'testing']
-    for f in keep:
+    for f in ['storage', 'tensor', 'utils', 'typing', 'testing'] + modules:
         os.symlink(os.path.join(refpkg, f + '.py'), os.path.join(pkg, f + '.py'))
     os.symlink(os.path.join(HERE, 'shims', 'torch_scatter'), os.path.join(scratch, 'torch_scatter'))
-    # the op library with the reference's own names, built straight from its sources
     csrc = os.path.join(REF, 'csrc')
     lib = os.path.join(pkg, '_ops_cpu.so')
     tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
     inc = [csrc, os.path.join(ROOT, 'oracle', 'shim')] + ce.include_paths()
-    srcs = [os.path.join(csrc, s) for s in ('spmm.cpp', 'cpu/spmm_cpu.cpp', 'convert.cpp', 'cpu/convert_cpu.cpp')]
+    srcs = [os.path.join(csrc, s) for s in op_sources]
     subprocess.check_call(['g++', '-O2', '-fopenmp', '-DAT_PARALLEL_OPENMP', '-Wno-sign-compare', '-std=c++17',
                            '-fPIC', '-shared', '-D_GLIBCXX_USE_CXX11_ABI=%d' % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
                           + ['-I' + i for i in inc] + srcs +
                           ['-o', lib, '-L' + tlib, '-ltorch', '-ltorch_cpu', '-lc10', '-Wl,-rpath,' + tlib])
+    return scratch, pkg
+
+
+SPMM_SRCS = ('spmm.cpp', 'cpu/spmm_cpu.cpp', 'convert.cpp', 'cpu/convert_cpu.cpp')
+
+
+def part2():
+    scratch, pkg = make_scratch(['matmul', 'coalesce', 'transpose', 'spmm', 'spspmm'], SPMM_SRCS)
     with open(os.path.join(pkg, '__init__.py'), 'w') as f:
         f.write("import os, torch\n"
                 "torch.ops.load_library(os.path.join(os.path.dirname(__file__), '_ops_cpu.so'))\n"
@@ -194,8 +237,30 @@ def part2():
     subprocess.check_call([sys.executable, '-c', PART2], env=env)
 
 
+def part3():
+    """py3_*.npz: narrow / select / index_select / masked_select / permute / cat / diag / add / mul of
+    the reference Python package on the inputs and cases of tests/golden/cases3.py."""
+    mods = ['transpose', 'coalesce', 'narrow', 'select', 'index_select', 'masked_select', 'permute', 'cat',
+            'diag', 'add', 'mul', 'reduce']
+    scratch, pkg = make_scratch(mods, SPMM_SRCS + ('diag.cpp', 'cpu/diag_cpu.cpp'))
+    with open(os.path.join(pkg, '__init__.py'), 'w') as f:
+        f.write("import os, torch\n"
+                "torch.ops.load_library(os.path.join(os.path.dirname(__file__), '_ops_cpu.so'))\n"
+                "from .storage import SparseStorage\nfrom .tensor import SparseTensor\n"
+                "from .transpose import t\nfrom .narrow import narrow, __narrow_diag__\n"
+                "from .select import select\nfrom .index_select import index_select, index_select_nnz\n"
+                "from .masked_select import masked_select, masked_select_nnz\nfrom .permute import permute\n"
+                "from .diag import remove_diag, set_diag, fill_diag, get_diag\n"
+                "from .add import add, add_, add_nnz, add_nnz_\nfrom .mul import mul, mul_, mul_nnz, mul_nnz_\n"
+                "from .reduce import sum, mean, min, max\nfrom .cat import cat\n"
+                "from .coalesce import coalesce\nfrom .transpose import transpose\n")
+    env = dict(os.environ, TS_SCRATCH=scratch, TS_OUT=HERE, TS_GOLDEN=HERE, OMP_NUM_THREADS='1')
+    subprocess.check_call([sys.executable, '-c', PART3], env=env)
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree %s not present' % REF)
-    part1()
-    part2()
+    todo = sys.argv[1:] or ['part1', 'part2', 'part3']
+    for name in todo:  # e.g. `make_golden.py part3` regenerates only the py3_* fixtures
+        {'part1': part1, 'part2': part2, 'part3': part3}[name]()

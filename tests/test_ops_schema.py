@@ -13,6 +13,8 @@ EXPECTED = {
     'ind2ptr': 'torch_sparse::ind2ptr(Tensor _0, int _1) -> Tensor _0',
     'ptr2ind': 'torch_sparse::ptr2ind(Tensor _0, int _1) -> Tensor _0',
     'cuda_version': 'torch_sparse::cuda_version() -> int _0',
+    # csrc/diag.cpp:22-36 (widening)
+    'non_diag_mask': 'torch_sparse::non_diag_mask(Tensor _0, Tensor _1, int _2, int _3, int _4) -> Tensor _0',
 }
 
 
@@ -49,3 +51,32 @@ def test_api_surface():
         assert hasattr(pytorch_sparse_amd, name)
     for m in ('matmul', 'spmm', 'spspmm', 't', 'coalesce', 'csr', 'coo', 'csc', 'to_dense'):
         assert hasattr(pytorch_sparse_amd.SparseTensor, m)
+    # the widened surface: every name the reference package exports for it
+    for name in ('narrow', '__narrow_diag__', 'select', 'index_select', 'index_select_nnz', 'masked_select',
+                 'masked_select_nnz', 'permute', 'remove_diag', 'set_diag', 'fill_diag', 'get_diag', 'add',
+                 'add_', 'add_nnz', 'add_nnz_', 'mul', 'mul_', 'mul_nnz', 'mul_nnz_', 'sum', 'mean', 'min',
+                 'max', 'cat', 'to_torch_sparse', 'from_torch_sparse', 'to_scipy', 'from_scipy', 'eye', 'spadd'):
+        assert hasattr(pytorch_sparse_amd, name), name
+    for m in ('narrow', 'select', 'index_select', 'index_select_nnz', 'masked_select', 'masked_select_nnz',
+              'permute', 'remove_diag', 'set_diag', 'fill_diag', 'get_diag', 'add', 'add_', 'mul', 'mul_',
+              '__getitem__', '__add__', '__mul__', 'sum', 'mean', 'min', 'max'):
+        assert hasattr(pytorch_sparse_amd.SparseTensor, m), m
+
+
+def test_view_ops_need_no_kernel():
+    """narrow(0) / cat(0) / cat((0,1)) on a CSR-holding tensor are views and memcpys: they work on host
+    tensors too (that is how a loader process cuts the row shards before the upload)."""
+    ts = pytorch_sparse_amd
+    a = ts.SparseTensor(rowptr=torch.tensor([0, 2, 3, 5]), col=torch.tensor([0, 2, 1, 0, 2]),
+                        value=torch.arange(5.), sparse_sizes=(3, 3), is_sorted=True)
+    b = a.narrow(0, 1, 2)
+    assert b.sparse_sizes() == (2, 3) and b.storage.rowptr().tolist() == [0, 1, 3]
+    assert b.storage.col().tolist() == [1, 0, 2] and b.storage.value().tolist() == [2., 3., 4.]
+    c = ts.cat([a.narrow(0, 0, 1), b], 0)
+    assert c.storage.rowptr().tolist() == [0, 2, 3, 5] and c.storage.col().tolist() == [0, 2, 1, 0, 2]
+    d = ts.cat([a, b], (0, 1))
+    assert d.sparse_sizes() == (5, 6) and d.storage.col().tolist() == [0, 2, 1, 0, 2, 4, 3, 5]
+    assert a[1:].storage.col().tolist() == [1, 0, 2] and a[-1].storage.value().tolist() == [3., 4.]
+    import pytest
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        a.narrow(1, 0, 2)
