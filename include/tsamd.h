@@ -244,7 +244,8 @@ int tsamd_spspmm_compact(int dtype, const int64_t *rowC, const int64_t *rowptrC,
  *   1. tsamd_filter_plan: pos[n+1] = exclusive scan of the keep flags, *count = kept entries.
  *        pred TSAMD_KEEP_COL_RANGE: a <= col < a + b      TSAMD_KEEP_OFF_DIAG: row != col - a
  *        TSAMD_KEEP_MASK: mask[i]   TSAMD_KEEP_MASK_ROW: mask[row[i]]   TSAMD_KEEP_MASK_COL:
- *        mask[col[i]]   (mask = one byte per element, non-zero keeps).  With TSAMD_KEEP_MASK and
+ *        mask[col[i]]   (mask = one byte per element, non-zero keeps)   TSAMD_KEEP_COL_MAPPED:
+ *        map[col[i]] >= 0  (map = int64 per column id).  With TSAMD_KEEP_MASK and
  *        row = col = NULL, pos is the rank of every set mask byte (new id of a kept row/column).
  *   2. host reads *count, allocates.
  *   3. tsamd_filter_apply: kept entry i goes to slot pos[i]:
@@ -255,7 +256,8 @@ enum {
   TSAMD_KEEP_OFF_DIAG = 1,
   TSAMD_KEEP_MASK = 2,
   TSAMD_KEEP_MASK_ROW = 3,
-  TSAMD_KEEP_MASK_COL = 4
+  TSAMD_KEEP_MASK_COL = 4,
+  TSAMD_KEEP_COL_MAPPED = 5
 };
 size_t tsamd_select_workspace_bytes(int64_t K);
 int tsamd_select_plan(const int64_t *ptr, int64_t S, const int64_t *idx, int64_t K,
@@ -266,8 +268,8 @@ int tsamd_select_fill(const int64_t *ptr, int64_t S, const int64_t *ind, const i
                       int64_t *ind_out, int64_t *pos_out, void *stream);
 size_t tsamd_filter_workspace_bytes(int64_t n);
 int tsamd_filter_plan(int pred, const int64_t *row, const int64_t *col, const uint8_t *mask,
-                      int64_t n, int64_t a, int64_t b, int64_t *pos, int64_t *count,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      const int64_t *map, int64_t n, int64_t a, int64_t b, int64_t *pos,
+                      int64_t *count, void *workspace, size_t workspace_bytes, void *stream);
 int tsamd_filter_apply(const int64_t *pos, const int64_t *row, const int64_t *col, int64_t n,
                        const int64_t *row_map, const int64_t *col_map, int64_t row_shift,
                        int64_t col_shift, int64_t *row_out, int64_t *col_out, int64_t *src_out,
@@ -299,6 +301,54 @@ int tsamd_non_diag_mask(const int64_t *row, const int64_t *col, int64_t E, int64
                         int64_t k, uint8_t *mask, void *stream);
 int tsamd_insert_diag(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
                       int64_t k, int64_t *row_out, int64_t *col_out, int64_t *src_out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Mini-batch producers.  CPU-only in the reference except the walk.
+ *
+ * tsamd_random_walk   replaces random_walk_cpu / random_walk_cuda (csrc/cpu/rw_cpu.cpp:5-45,
+ *                     csrc/cuda/rw_cuda.cu:10-53).  rand[n, L] are the uniform floats in [0, 1)
+ *                     the reference draws with torch::rand; out[n, L + 1], out[w, 0] = start[w],
+ *                     out[w, l + 1] = col[rowptr[cur] + int64(rand[w, l] * deg(cur))].
+ *                     A node without neighbours keeps the walk where it is.
+ *
+ * sample_adj (csrc/cpu/sample_cpu.cpp:10-140) = plan + draw + relabel + a per-row sort:
+ *   tsamd_sample_plan   out_ptr[n + 1] = exclusive scan of the per-row sample counts
+ *                       (num_neighbors < 0: all; with replacement: num_neighbors if deg > 0;
+ *                       else min(deg, num_neighbors)); info[0] = total, info[1] = #bad ids.
+ *   tsamd_sample_draw   num_neighbors >= 0: e_id[t] = position of the drawn entry, nbr[t] = its
+ *                       column.  Without replacement the draws of a row are distinct (keyed
+ *                       bijection of [0, deg) evaluated at 0..k-1, see csrc/sample.hip).
+ *                       (num_neighbors < 0 is tsamd_select_fill with ind_out = nbr, pos_out = e_id.)
+ *   tsamd_relabel_plan / _apply   replaces the std::unordered_map walk of relabel_cpu /
+ *                       relabel_one_hop_cpu / sample_adj_cpu (csrc/cpu/relabel_cpu.cpp:5-155):
+ *                       ids in idx[n] keep local id = their position, every other id in nbr[T]
+ *                       gets n + (rank of its first occurrence in nbr order).  slot[M] (M = number
+ *                       of node ids) and rank[T + 1] are scratch the caller provides; info[0] =
+ *                       number of new nodes, info[1] = #ids outside [0, M).  _apply writes
+ *                       local[T] and n_id[n + info[0]] (either may be NULL).
+ * tsamd_subset_assoc  assoc[M] = position of every node in idx, -1 elsewhere (the association
+ *                     array of subgraph_cpu, csrc/cpu/saint_cpu.cpp:17-18); *err = #bad ids.
+ *                     SAINT sub-graphs are then select + filter(TSAMD_KEEP_COL_MAPPED).
+ * ------------------------------------------------------------------------ */
+int tsamd_random_walk(const int64_t *rowptr, const int64_t *col, const int64_t *start,
+                      const float *rand, int64_t n, int64_t walk_length, int64_t *out,
+                      void *stream);
+size_t tsamd_sample_workspace_bytes(int64_t n);
+int tsamd_sample_plan(const int64_t *rowptr, int64_t M, const int64_t *idx, int64_t n,
+                      int64_t num_neighbors, int replace, int64_t *out_ptr, int64_t *info,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int tsamd_sample_draw(const int64_t *rowptr, const int64_t *col, const int64_t *idx, int64_t n,
+                      int64_t num_neighbors, int replace, uint64_t seed, const int64_t *out_ptr,
+                      int64_t *e_id, int64_t *nbr, void *stream);
+size_t tsamd_relabel_workspace_bytes(int64_t T);
+int tsamd_relabel_plan(const int64_t *idx, int64_t n, const int64_t *nbr, int64_t T, int64_t M,
+                       int64_t *slot, int64_t *rank, int64_t *info, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int tsamd_relabel_apply(const int64_t *idx, int64_t n, const int64_t *nbr, int64_t T, int64_t M,
+                        const int64_t *slot, const int64_t *rank, int64_t *local, int64_t *n_id,
+                        void *stream);
+int tsamd_subset_assoc(const int64_t *idx, int64_t n, int64_t M, int64_t *assoc, int64_t *err,
+                       void *stream);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 
 Compiles, unmodified and where they lie under /root/reference:
     csrc/spmm.cpp  csrc/cpu/spmm_cpu.cpp  csrc/convert.cpp  csrc/cpu/convert_cpu.cpp
+    csrc/{sample,rw,saint,relabel,diag}.cpp + their csrc/cpu/*_cpu.cpp   (SURVEY 8f widening)
 with g++ (mirrors setup.py:67-81 of the reference: -O3 -fopenmp -DAT_PARALLEL_OPENMP,
 no WITH_CUDA => CPU only) into ``oracle/_ref/libts_ref.so``.  The two op files are
 included through ``ref_wrap_*.cpp`` so their registrations land in ``ts_ref::`` instead
@@ -31,10 +32,13 @@ def build(verbose=True):
     import torch
     from torch.utils import cpp_extension as ce
     os.makedirs(OUT, exist_ok=True)
-    srcs = [os.path.join(HERE, 'ref_wrap_spmm.cpp'), os.path.join(csrc, 'cpu', 'spmm_cpu.cpp'),
-            os.path.join(HERE, 'ref_wrap_convert.cpp'), os.path.join(csrc, 'cpu', 'convert_cpu.cpp')]
-    deps = srcs + [os.path.join(HERE, 'ref_wrap.h'), os.path.join(csrc, 'spmm.cpp'),
-                   os.path.join(csrc, 'convert.cpp'), os.path.join(csrc, 'cpu', 'reducer.h')]
+    families = ['spmm', 'convert', 'sample', 'rw', 'saint', 'relabel', 'diag']
+    srcs, deps = [], [os.path.join(HERE, 'ref_wrap.h'), os.path.join(csrc, 'cpu', 'reducer.h'),
+                      os.path.abspath(__file__)]
+    for fam in families:
+        srcs += [os.path.join(HERE, 'ref_wrap_%s.cpp' % fam), os.path.join(csrc, 'cpu', fam + '_cpu.cpp')]
+        deps.append(os.path.join(csrc, fam + '.cpp'))
+    deps += srcs
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
@@ -48,7 +52,7 @@ def build(verbose=True):
         subprocess.check_call(['g++'] + flags + ['-I' + i for i in inc] + ['-c', s, '-o', o])
     if verbose:
         print('[oracle/_ref] compiling the reference CPU path from', csrc, flush=True)
-    with cf.ThreadPoolExecutor(4) as ex:
+    with cf.ThreadPoolExecutor(8) as ex:
         list(ex.map(cc, zip(srcs, objs)))
     subprocess.check_call(['g++', '-shared', '-fopenmp', '-o', LIB] + objs +
                           ['-L' + tlib, '-ltorch', '-ltorch_cpu', '-lc10', '-Wl,-rpath,' + tlib])

@@ -74,3 +74,81 @@ def spspmm(rowA, colA, valA, rowB, colB, valB, m, k, n):
     prow, pcol = rowA[ea], colB[eb]
     pval = (valA[ea] * valB[eb]).astype(np.result_type(valA.dtype, valB.dtype))
     return coalesce(prow, pcol, pval, m, n, 'add')
+
+
+# ---------------------------------------------------------------------------------------------
+# mini-batch producers -- pinned by tests/golden/py4_*.npz, the outputs of
+# the reference's csrc/cpu/{rw,sample,saint,relabel}_cpu.cpp compiled unmodified
+# ---------------------------------------------------------------------------------------------
+def random_walk(rowptr, col, start, rand):
+    """csrc/cpu/rw_cpu.cpp:29-42: cur = col[row_start + int64(rand * deg)] with a float32 product.
+    (Nodes without neighbours keep the walk in place; the reference reads out of the row there.)"""
+    rowptr, col = np.asarray(rowptr, np.int64), np.asarray(col, np.int64)
+    rand = np.asarray(rand, np.float32)
+    n, L = rand.shape
+    out = np.empty((n, L + 1), np.int64)
+    cur = np.asarray(start, np.int64).copy()
+    out[:, 0] = cur
+    for l in range(L):
+        s = rowptr[cur]
+        deg = rowptr[cur + 1] - s
+        p = (rand[:, l] * deg.astype(np.float32)).astype(np.int64)
+        p = np.minimum(p, np.maximum(deg - 1, 0))
+        has = deg > 0
+        cur = np.where(has, col[np.where(has, s + p, 0)] if col.size else cur, cur)
+        out[:, l + 1] = cur
+    return out
+
+
+def relabel(col, idx):
+    """csrc/cpu/relabel_cpu.cpp:5-46: ids in idx keep their position, every other id gets
+    len(idx) + rank of its first occurrence in col."""
+    col, idx = np.asarray(col, np.int64), np.asarray(idx, np.int64)
+    M = int(max(col.max(initial=-1), idx.max(initial=-1))) + 1
+    local = np.full(M, -1, np.int64)
+    local[idx] = np.arange(idx.size)
+    is_new = local[col] < 0 if col.size else np.zeros(0, bool)
+    uniq, first = np.unique(col[is_new], return_index=True)
+    order = np.argsort(first, kind='stable')
+    new_nodes = uniq[order]
+    local[new_nodes] = idx.size + np.arange(new_nodes.size)
+    return (local[col] if col.size else col), np.concatenate([idx, new_nodes])
+
+
+def _gather_rows(rowptr, idx):
+    rowptr, idx = np.asarray(rowptr, np.int64), np.asarray(idx, np.int64)
+    cnt = rowptr[idx + 1] - rowptr[idx] if idx.size else np.zeros(0, np.int64)
+    out_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    seg = np.repeat(np.arange(idx.size), cnt)
+    pos = np.arange(out_ptr[-1]) - out_ptr[seg] + rowptr[idx][seg] if idx.size else np.zeros(0, np.int64)
+    return out_ptr, seg, pos.astype(np.int64)
+
+
+def relabel_one_hop(rowptr, col, idx, bipartite):
+    """csrc/cpu/relabel_cpu.cpp:48-155 -> (out_rowptr, out_col, positions of the kept entries, out_idx)"""
+    out_ptr, _, pos = _gather_rows(rowptr, idx)
+    out_col, out_idx = relabel(np.asarray(col, np.int64)[pos], idx)
+    if not bipartite:
+        extra = out_idx.size - np.asarray(idx).size
+        out_ptr = np.concatenate([out_ptr, np.full(extra, pos.size, np.int64)])
+    return out_ptr, out_col, pos, out_idx
+
+
+def sample_adj_all(rowptr, col, idx):
+    """csrc/cpu/sample_cpu.cpp:40-58,116-137 with num_neighbors < 0: every neighbour, relabelled in
+    first-occurrence order, rows sorted by the new column id -> (rowptr, col, n_id, e_id)."""
+    out_ptr, seg, pos = _gather_rows(rowptr, idx)
+    local, n_id = relabel(np.asarray(col, np.int64)[pos], idx)
+    order = np.lexsort((local, seg))
+    return out_ptr, local[order], n_id, pos[order]
+
+
+def saint_subgraph(idx, rowptr, col):
+    """csrc/cpu/saint_cpu.cpp:5-52 -> (row, col, edge_index)"""
+    idx = np.asarray(idx, np.int64)
+    assoc = np.full(np.asarray(rowptr).size - 1, -1, np.int64)
+    assoc[idx] = np.arange(idx.size)
+    _, seg, pos = _gather_rows(rowptr, idx)
+    w = assoc[np.asarray(col, np.int64)[pos]] if pos.size else np.zeros(0, np.int64)
+    keep = w >= 0
+    return seg[keep], w[keep], pos[keep]

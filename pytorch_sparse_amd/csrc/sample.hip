@@ -1,0 +1,304 @@
+// Mini-batch producers on gfx950: uniform random walks, one-hop neighbour sampling and the
+// first-occurrence relabelling every sampler of the reference ends with.
+// The reference has these on the CPU only (a CUDA kernel exists just for the random walk):
+//   * random_walk        csrc/cpu/rw_cpu.cpp:5-45, csrc/cuda/rw_cuda.cu:10-53
+//   * sample_adj         csrc/cpu/sample_cpu.cpp:10-140  (std::unordered_map relabel, Floyd sampling,
+//                        one torch::randint call per draw)
+//   * relabel(_one_hop)  csrc/cpu/relabel_cpu.cpp:5-155
+// Here:
+//   * walks: one lane per walk, `rand` handed in (so the result is a pure function of its inputs);
+//   * draws: one lane per (row, j).  Without replacement the j-th draw of a row is pi_row(j) for a
+//     keyed pseudo-random BIJECTION pi_row of [0, deg) (add / odd-multiply / xor-shift rounds on
+//     ceil(log2 deg) bits + cycle walking, keys from Philox4x32-10 of (seed, row)): distinct by
+//     construction, O(1) state, no per-row set, hubs and leaves cost the same.  With replacement a
+//     Philox draw per (row, j);
+//   * relabel: a dense slot[] array over the node ids (8 B per node of the graph): seeds hold
+//     -(i+1), every other drawn node the minimum draw position (atomicMin) = its FIRST OCCURRENCE in
+//     row-major order; flags + device scan rank the first occurrences -> new ids n, n+1, ... in the
+//     order the reference's sequential std::unordered_map walk assigns them.
+#include "common.h"
+#include "scan.h"
+
+namespace tsamd {
+namespace {
+
+// ---- random walk ------------------------------------------------------------------------------
+__global__ void random_walk_kernel(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
+                                   const int64_t *__restrict__ start, const float *__restrict__ rand,
+                                   int64_t n, int64_t L, int64_t *__restrict__ out) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  int64_t cur = start[w];
+  out[w * (L + 1)] = cur;
+  for (int64_t l = 0; l < L; ++l) {
+    const int64_t s = rowptr[cur], e = rowptr[cur + 1];
+    // reference: col[s + int64(rand * deg)]; a node without neighbours keeps the walk in place
+    // (the reference reads the next row's first entry there)
+    if (e > s) {
+      int64_t p = (int64_t)(rand[w * L + l] * (float)(e - s));
+      if (p >= e - s) p = e - s - 1;  // float rounding of a rand just below 1 on a huge row
+      cur = col[s + p];
+    }
+    out[w * (L + 1) + l + 1] = cur;
+  }
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) --------------------------------------------------------
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ inline U4 philox(uint64_t seed, uint64_t c_lo, uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  U4 c = {(uint32_t)c_lo, (uint32_t)(c_lo >> 32), c2, c3};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = {hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__device__ inline uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+
+// j -> pi(j): keyed bijection of [0, deg), deg >= 2, j < deg
+__device__ inline uint64_t permute_index(uint64_t j, uint64_t deg, uint64_t seed, uint64_t row) {
+  const int b = 64 - __clzll((long long)(deg - 1));  // 2^(b-1) < deg <= 2^b
+  const uint64_t mask = b >= 64 ? ~0ull : ((1ull << b) - 1);
+  const int s = b > 1 ? b / 2 : 1;
+  const U4 a = philox(seed, row, 0u, 0x5A17u), c = philox(seed, row, 1u, 0x5A17u);
+  const uint64_t k0 = u64(a.x, a.y), k1 = u64(a.z, a.w) | 1ull;
+  const uint64_t k2 = u64(c.x, c.y), k3 = u64(c.z, c.w) | 1ull;
+  uint64_t x = j;
+  do {  // cycle walking: < 2 rounds expected, the domain is less than twice deg
+    x = (x + k0) & mask;
+    x = (x * k1) & mask;
+    x ^= x >> s;
+    x = (x + k2) & mask;
+    x = (x * k3) & mask;
+    x ^= x >> s;
+    x = (x * 0x9E3779B97F4A7C15ull) & mask;
+    x ^= x >> s;
+    x = (x + (k0 >> 7)) & mask;
+  } while (x >= deg);
+  return x;
+}
+
+__device__ inline int64_t wrap_id(int64_t j, int64_t S) { return j < 0 ? j + S : j; }
+
+// cnt[i] = number of neighbours row idx[i] contributes
+__global__ void sample_count_kernel(const int64_t *__restrict__ rowptr, int64_t M,
+                                    const int64_t *__restrict__ idx, int64_t n, int64_t k,
+                                    int replace, int64_t *__restrict__ cnt,
+                                    unsigned long long *err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = idx[i];
+  if (v < 0 || v >= M) {
+    atomicAdd(err, 1ull);
+    cnt[i] = 0;
+    return;
+  }
+  const int64_t deg = rowptr[v + 1] - rowptr[v];
+  cnt[i] = k < 0 ? deg : (replace ? (deg > 0 ? k : 0) : (deg < k ? deg : k));
+}
+
+// one lane per (row i, draw j), j < k
+__global__ void sample_draw_kernel(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
+                                   const int64_t *__restrict__ idx, int64_t n, int64_t k, int replace,
+                                   uint64_t seed, const int64_t *__restrict__ out_ptr,
+                                   int64_t *__restrict__ e_id, int64_t *__restrict__ nbr) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * k) return;
+  const int64_t i = t / k, j = t - i * k;
+  const int64_t o = out_ptr[i];
+  if (j >= out_ptr[i + 1] - o) return;
+  const int64_t v = idx[i];
+  const int64_t s = rowptr[v], deg = rowptr[v + 1] - s;
+  int64_t p;
+  if (replace) {
+    const U4 r = philox(seed, (uint64_t)i, (uint32_t)j, 0xD4A3u ^ (uint32_t)((uint64_t)j >> 32));
+    p = (int64_t)__umul64hi(u64(r.x, r.y), (uint64_t)deg);
+  } else {
+    p = deg <= k ? j : (int64_t)permute_index((uint64_t)j, (uint64_t)deg, seed, (uint64_t)i);
+  }
+  e_id[o + j] = s + p;
+  nbr[o + j] = col[s + p];
+}
+
+// ---- first-occurrence relabel -------------------------------------------------------------------
+__global__ void relabel_seed_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t M,
+                                    int64_t *__restrict__ slot, unsigned long long *err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = idx[i];
+  if (v < 0 || v >= M) {
+    atomicAdd(err, 1ull);
+    return;
+  }
+  slot[v] = -(i + 1);
+}
+
+__global__ void relabel_first_kernel(const int64_t *__restrict__ nbr, int64_t T, int64_t M,
+                                     int64_t *__restrict__ slot, unsigned long long *err) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int64_t c = nbr[t];
+  if (c < 0 || c >= M) {
+    atomicAdd(err, 1ull);
+    return;
+  }
+  if (slot[c] >= 0) atomicMin(reinterpret_cast<long long *>(&slot[c]), (long long)t);
+}
+
+__global__ void relabel_flag_kernel(const int64_t *__restrict__ nbr, int64_t T, int64_t M,
+                                    const int64_t *__restrict__ slot, int64_t *__restrict__ rank) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int64_t c = nbr[t];
+  rank[t] = (c >= 0 && c < M && slot[c] == t) ? 1 : 0;
+}
+
+__global__ void relabel_apply_kernel(const int64_t *__restrict__ idx, int64_t n,
+                                     const int64_t *__restrict__ nbr, int64_t T, int64_t M,
+                                     const int64_t *__restrict__ slot, const int64_t *__restrict__ rank,
+                                     int64_t *__restrict__ local, int64_t *__restrict__ n_id) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n && n_id) n_id[t] = idx[t];
+  if (t >= T) return;
+  const int64_t c = nbr[t];
+  if (c < 0 || c >= M) return;
+  const int64_t s = slot[c];
+  if (s < 0) {
+    if (local) local[t] = -(s + 1);
+  } else {
+    const int64_t id = n + rank[s];
+    if (local) local[t] = id;
+    if (s == t && n_id) n_id[id] = c;
+  }
+}
+
+// assoc[idx[i]] = i  (node -> position in the subset, -1 elsewhere; SAINT sub-graphs)
+__global__ void assoc_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t M,
+                             int64_t *__restrict__ assoc, unsigned long long *err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = idx[i];
+  if (v < 0 || v >= M) {
+    atomicAdd(err, 1ull);
+    return;
+  }
+  assoc[v] = i;
+}
+
+}  // namespace
+}  // namespace tsamd
+
+using namespace tsamd;
+
+extern "C" int tsamd_random_walk(const int64_t *rowptr, const int64_t *col, const int64_t *start,
+                                 const float *rand, int64_t n, int64_t walk_length, int64_t *out,
+                                 void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || walk_length < 0) return TSAMD_ERR_INVALID;
+  if (n == 0) return TSAMD_OK;
+  if (!rowptr || !start || !out || (walk_length > 0 && (!rand || !col))) return TSAMD_ERR_INVALID;
+  hipLaunchKernelGGL(random_walk_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
+                     rowptr, col, start, rand, n, walk_length, out);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+extern "C" size_t tsamd_sample_workspace_bytes(int64_t n) { return scan_workspace_bytes(n + 1); }
+
+extern "C" int tsamd_sample_plan(const int64_t *rowptr, int64_t M, const int64_t *idx, int64_t n,
+                                 int64_t num_neighbors, int replace, int64_t *out_ptr, int64_t *info,
+                                 void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || n < 0 || !rowptr || !out_ptr || !info || (n > 0 && !idx)) return TSAMD_ERR_INVALID;
+  if (!workspace || workspace_bytes < tsamd_sample_workspace_bytes(n)) return TSAMD_ERR_WORKSPACE;
+  TSAMD_HIP_TRY(hipMemsetAsync(info, 0, 2 * sizeof(int64_t), stream));
+  TSAMD_HIP_TRY(hipMemsetAsync(out_ptr + n, 0, sizeof(int64_t), stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(sample_count_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
+                       rowptr, M, idx, n, num_neighbors, replace, out_ptr,
+                       reinterpret_cast<unsigned long long *>(info + 1));
+    TSAMD_LAUNCH_CHECK();
+  }
+  return exclusive_scan_i64(out_ptr, out_ptr, n + 1, info, workspace, stream);
+}
+
+extern "C" int tsamd_sample_draw(const int64_t *rowptr, const int64_t *col, const int64_t *idx,
+                                 int64_t n, int64_t num_neighbors, int replace, uint64_t seed,
+                                 const int64_t *out_ptr, int64_t *e_id, int64_t *nbr, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || num_neighbors < 0) return TSAMD_ERR_INVALID;  // "all neighbours" is tsamd_select_fill
+  const int64_t total = n * num_neighbors;
+  if (total == 0) return TSAMD_OK;
+  if (!rowptr || !col || !idx || !out_ptr || !e_id || !nbr) return TSAMD_ERR_INVALID;
+  hipLaunchKernelGGL(sample_draw_kernel, dim3((unsigned int)ceil_div(total, 256)), dim3(256), 0, stream,
+                     rowptr, col, idx, n, num_neighbors, replace, seed, out_ptr, e_id, nbr);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+extern "C" size_t tsamd_relabel_workspace_bytes(int64_t T) { return scan_workspace_bytes(T + 1); }
+
+extern "C" int tsamd_relabel_plan(const int64_t *idx, int64_t n, const int64_t *nbr, int64_t T,
+                                  int64_t M, int64_t *slot, int64_t *rank, int64_t *info,
+                                  void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || T < 0 || M < 0 || !rank || !info) return TSAMD_ERR_INVALID;
+  if ((M > 0 && !slot) || (n > 0 && !idx) || (T > 0 && !nbr)) return TSAMD_ERR_INVALID;
+  if (!workspace || workspace_bytes < tsamd_relabel_workspace_bytes(T)) return TSAMD_ERR_WORKSPACE;
+  TSAMD_HIP_TRY(hipMemsetAsync(info, 0, 2 * sizeof(int64_t), stream));
+  // every slot = 0x7f7f... : "not seen", larger than any draw position
+  if (M > 0) TSAMD_HIP_TRY(hipMemsetAsync(slot, 0x7f, sizeof(int64_t) * (size_t)M, stream));
+  TSAMD_HIP_TRY(hipMemsetAsync(rank + T, 0, sizeof(int64_t), stream));
+  unsigned long long *err = reinterpret_cast<unsigned long long *>(info + 1);
+  if (n > 0) {
+    hipLaunchKernelGGL(relabel_seed_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
+                       idx, n, M, slot, err);
+    TSAMD_LAUNCH_CHECK();
+  }
+  if (T > 0) {
+    const unsigned int blocks = (unsigned int)ceil_div(T, 256);
+    hipLaunchKernelGGL(relabel_first_kernel, dim3(blocks), dim3(256), 0, stream, nbr, T, M, slot, err);
+    TSAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(relabel_flag_kernel, dim3(blocks), dim3(256), 0, stream, nbr, T, M,
+                       (const int64_t *)slot, rank);
+    TSAMD_LAUNCH_CHECK();
+  }
+  return exclusive_scan_i64(rank, rank, T + 1, info, workspace, stream);
+}
+
+extern "C" int tsamd_relabel_apply(const int64_t *idx, int64_t n, const int64_t *nbr, int64_t T,
+                                   int64_t M, const int64_t *slot, const int64_t *rank,
+                                   int64_t *local, int64_t *n_id, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || T < 0 || M < 0) return TSAMD_ERR_INVALID;
+  const int64_t work = n > T ? n : T;
+  if (work == 0) return TSAMD_OK;
+  if ((T > 0 && (!nbr || !slot || !rank)) || (n > 0 && n_id && !idx)) return TSAMD_ERR_INVALID;
+  hipLaunchKernelGGL(relabel_apply_kernel, dim3((unsigned int)ceil_div(work, 256)), dim3(256), 0, stream,
+                     idx, n, nbr, T, M, slot, rank, local, n_id);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+extern "C" int tsamd_subset_assoc(const int64_t *idx, int64_t n, int64_t M, int64_t *assoc,
+                                  int64_t *err, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || M < 0 || !err || (M > 0 && !assoc) || (n > 0 && !idx)) return TSAMD_ERR_INVALID;
+  TSAMD_HIP_TRY(hipMemsetAsync(err, 0, sizeof(int64_t), stream));
+  if (M > 0) TSAMD_HIP_TRY(hipMemsetAsync(assoc, 0xff, sizeof(int64_t) * (size_t)M, stream));  // -1
+  if (n > 0) {
+    hipLaunchKernelGGL(assoc_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream, idx, n,
+                       M, assoc, reinterpret_cast<unsigned long long *>(err));
+    TSAMD_LAUNCH_CHECK();
+  }
+  return TSAMD_OK;
+}

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void select_fill_kernel(
 }
 
 __device__ inline bool keep_entry(int pred, const int64_t *row, const int64_t *col,
-                                  const uint8_t *mask, int64_t i, int64_t a, int64_t b) {
+                                  const uint8_t *mask, const int64_t *map, int64_t i, int64_t a,
+                                  int64_t b) {
   switch (pred) {
     case TSAMD_KEEP_COL_RANGE: {
       const int64_t c = col[i];
@@ -82,16 +83,18 @@ __device__ inline bool keep_entry(int pred, const int64_t *row, const int64_t *c
     case TSAMD_KEEP_MASK: return mask[i] != 0;
     case TSAMD_KEEP_MASK_ROW: return mask[row[i]] != 0;
     case TSAMD_KEEP_MASK_COL: return mask[col[i]] != 0;
+    case TSAMD_KEEP_COL_MAPPED: return map[col[i]] >= 0;
     default: return false;
   }
 }
 
 __global__ void filter_flags_kernel(int pred, const int64_t *__restrict__ row,
                                     const int64_t *__restrict__ col,
-                                    const uint8_t *__restrict__ mask, int64_t n, int64_t a,
+                                    const uint8_t *__restrict__ mask,
+                                    const int64_t *__restrict__ map, int64_t n, int64_t a,
                                     int64_t b, int64_t *__restrict__ pos) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) pos[i] = keep_entry(pred, row, col, mask, i, a, b) ? 1 : 0;
+  if (i < n) pos[i] = keep_entry(pred, row, col, mask, map, i, a, b) ? 1 : 0;
 }
 
 // pos = exclusive scan of the keep flags with pos[n] = count; entry i is kept iff pos[i+1] > pos[i]
@@ -232,23 +235,24 @@ extern "C" int tsamd_select_fill(const int64_t *ptr, int64_t S, const int64_t *i
 extern "C" size_t tsamd_filter_workspace_bytes(int64_t n) { return scan_workspace_bytes(n + 1); }
 
 extern "C" int tsamd_filter_plan(int pred, const int64_t *row, const int64_t *col,
-                                 const uint8_t *mask, int64_t n, int64_t a, int64_t b, int64_t *pos,
-                                 int64_t *count, void *workspace, size_t workspace_bytes,
-                                 void *stream_) {
+                                 const uint8_t *mask, const int64_t *map, int64_t n, int64_t a,
+                                 int64_t b, int64_t *pos, int64_t *count, void *workspace,
+                                 size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (n < 0 || !pos || !count) return TSAMD_ERR_INVALID;
-  if (pred < TSAMD_KEEP_COL_RANGE || pred > TSAMD_KEEP_MASK_COL) return TSAMD_ERR_UNSUPPORTED;
+  if (pred < TSAMD_KEEP_COL_RANGE || pred > TSAMD_KEEP_COL_MAPPED) return TSAMD_ERR_UNSUPPORTED;
   const bool need_row = pred == TSAMD_KEEP_OFF_DIAG || pred == TSAMD_KEEP_MASK_ROW;
-  const bool need_col =
-      pred == TSAMD_KEEP_COL_RANGE || pred == TSAMD_KEEP_OFF_DIAG || pred == TSAMD_KEEP_MASK_COL;
-  const bool need_mask = pred >= TSAMD_KEEP_MASK;
-  if (n > 0 && ((need_row && !row) || (need_col && !col) || (need_mask && !mask)))
+  const bool need_col = pred == TSAMD_KEEP_COL_RANGE || pred == TSAMD_KEEP_OFF_DIAG ||
+                        pred == TSAMD_KEEP_MASK_COL || pred == TSAMD_KEEP_COL_MAPPED;
+  const bool need_mask = pred >= TSAMD_KEEP_MASK && pred <= TSAMD_KEEP_MASK_COL;
+  const bool need_map = pred == TSAMD_KEEP_COL_MAPPED;
+  if (n > 0 && ((need_row && !row) || (need_col && !col) || (need_mask && !mask) || (need_map && !map)))
     return TSAMD_ERR_INVALID;
   if (!workspace || workspace_bytes < tsamd_filter_workspace_bytes(n)) return TSAMD_ERR_WORKSPACE;
   TSAMD_HIP_TRY(hipMemsetAsync(pos + n, 0, sizeof(int64_t), stream));
   if (n > 0) {
     hipLaunchKernelGGL(filter_flags_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0,
-                       stream, pred, row, col, mask, n, a, b, pos);
+                       stream, pred, row, col, mask, map, n, a, b, pos);
     TSAMD_LAUNCH_CHECK();
   }
   return exclusive_scan_i64(pos, pos, n + 1, count, workspace, stream);

@@ -1,0 +1,65 @@
+"""Mini-batch producer timings on one MI355X: neighbour sampling, random walks,
+SAINT sub-graphs on the config-2 graph (R-MAT scale 20, edge factor 20).  GPU wall time of the public
+API call including its host syncs.  The reference runs these on the CPU only; its timings on the same
+box come from tests/report_sampler_baseline.py (the oracle may only be touched from tests/).
+Prints one JSON object per line."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import pytorch_sparse_amd as ts  # noqa: E402
+from pytorch_sparse_amd import synth  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def wall(fn, iters=7, warm=2):
+    for _ in range(warm):
+        fn()
+    t = []
+    for _ in range(iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        t.append(time.perf_counter() - t0)
+    t.sort()
+    return t[len(t) // 2] * 1e3
+
+
+scale = int(os.environ.get('SCALE', 20))
+rp, c = synth.rmat_csr(scale, 20, seed=0, device=dev)
+n = 1 << scale
+E = c.numel()
+A = ts.SparseTensor(rowptr=rp, col=c, value=synth.values(E, device=dev), sparse_sizes=(n, n), is_sorted=True,
+                    trust_data=True)
+A.storage.row()
+g = torch.Generator().manual_seed(0)
+perm = torch.randperm(n, generator=g).to(dev)
+
+for seeds in (1_000, 100_000, n):
+    idx = perm[:seeds]
+    for k, replace in ((10, False), (25, False), (10, True), (-1, False)):
+        if k < 0 and seeds > 100_000:
+            continue
+        ms = wall(lambda: A.sample_adj(idx, k, replace=replace))
+        adj, n_id = A.sample_adj(idx, k, replace=replace)
+        print(json.dumps(dict(bench='sample_adj', seeds=seeds, k=k, replace=replace, ms=round(ms, 3),
+                              sampled=adj.nnz(), n_id=n_id.numel(),
+                              mdraws_per_s=round(adj.nnz() / ms / 1e3, 1))), flush=True)
+
+for walks, L in ((100_000, 20), (n, 20), (n, 80)):
+    start = perm[:walks]
+    ms = wall(lambda: A.random_walk(start, L))
+    print(json.dumps(dict(bench='random_walk', walks=walks, length=L, ms=round(ms, 3),
+                          msteps_per_s=round(walks * L / ms / 1e3, 1))), flush=True)
+
+for frac in (0.01, 0.25):
+    idx = perm[:int(n * frac)]
+    ms = wall(lambda: A.saint_subgraph(idx))
+    sub, _ = A.saint_subgraph(idx)
+    print(json.dumps(dict(bench='saint_subgraph', nodes=idx.numel(), ms=round(ms, 3), edges=sub.nnz())), flush=True)

@@ -17,7 +17,11 @@ container (it cannot travel to the GPU box; the fixtures can).
                                   masked_select / permute / cat / diag / add / mul), with the
                                   reference's csrc/cpu/diag_cpu.cpp added to the op library.
 
-Usage:  python tests/golden/make_golden.py [part1] [part2] [part3]     (needs /root/reference)
+  part 4  py4_*.npz             : the reference's CPU samplers compiled unmodified (rw, sample,
+                                  saint, relabel): random walks together with the floats they
+                                  drew, and the deterministic cases of the others.
+
+Usage:  python tests/golden/make_golden.py [part1] [part2] [part3] [part4]   (needs /root/reference)
 """
 import os
 import subprocess
@@ -258,9 +262,79 @@ def part3():
     subprocess.check_call([sys.executable, '-c', PART3], env=env)
 
 
+PART4 = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ['TS_SCRATCH'])
+import torch_sparse
+from torch_sparse import SparseTensor
+out_dir = os.environ['TS_OUT']
+def save(name, **kw):
+    np.savez_compressed(os.path.join(out_dir, name), **{k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+
+g = torch.Generator().manual_seed(77)
+n, nnz = 200, 1500
+key = torch.cat([torch.randperm(n * n, generator=g)[:nnz], torch.arange(n) * n + (torch.arange(n) + 1) % n]).unique()
+row, col = key // n, key % n                       # every node has at least one out-edge
+value = torch.randint(-8, 9, (key.numel(),), generator=g).float() / 4
+A = SparseTensor(row=row, col=col, value=value, sparse_sizes=(n, n))
+rowptr = A.storage.rowptr()
+save('py4_graph.npz', rowptr=rowptr, row=row, col=col, value=value, n=n)
+
+# random walks: the op draws torch.rand((N, L)) from the global CPU generator -> re-draw it with the same seed
+for seed, (N, L) in enumerate([(64, 10), (200, 3), (5, 0), (1, 40)]):
+    start = torch.randint(0, n, (N,), generator=g)
+    torch.manual_seed(100 + seed)
+    out = torch.ops.torch_sparse.random_walk(rowptr, col, start, L)
+    torch.manual_seed(100 + seed)
+    rand = torch.rand((N, L))
+    save('py4_rw_%d.npz' % seed, start=start, rand=rand, out=out)
+
+# take-all neighbour "sampling" (num_neighbors = -1) is deterministic
+for seed, m in enumerate([30, 1, 200, 0]):
+    idx = torch.randperm(n, generator=g)[:m]
+    r, c, n_id, e_id = torch.ops.torch_sparse.sample_adj(rowptr, col, idx, -1, False)
+    adj, n_id2 = A.sample_adj(idx, -1)
+    assert torch.equal(n_id, n_id2)
+    save('py4_sample_all_%d.npz' % seed, idx=idx, rowptr=r, col=c, n_id=n_id, e_id=e_id, value=adj.storage.value())
+    # oversized k without replacement also takes everything (perm = all positions), but the reference
+    # walks a std::unordered_set there, so only the take-all case above has a defined n_id order
+
+# SAINT sub-graphs and relabel
+for seed, m in enumerate([50, 200, 1, 0]):
+    idx = torch.randperm(n, generator=g)[:m]
+    r, c, e = torch.ops.torch_sparse.saint_subgraph(idx, rowptr, row, col)
+    sub, e2 = A.saint_subgraph(idx)
+    assert torch.equal(e, e2)
+    save('py4_saint_%d.npz' % seed, idx=idx, row=r, col=c, edge_index=e, value=sub.storage.value())
+    sel = torch.randint(0, key.numel(), (3 * m,), generator=g)
+    oc, oi = torch.ops.torch_sparse.relabel(col[sel], idx)
+    save('py4_relabel_%d.npz' % seed, idx=idx, col=col[sel], out_col=oc, out_idx=oi)
+    for bip in (False, True):
+        orp, oc, ov, oi = torch.ops.torch_sparse.relabel_one_hop(rowptr, col, value, idx, bip)
+        save('py4_relabel_one_hop_%d_%d.npz' % (seed, int(bip)), idx=idx, rowptr=orp, col=oc, value=ov, out_idx=oi)
+print('part 4: sampler / walk / saint / relabel fixtures written')
+"""
+
+
+def part4():
+    """py4_*.npz: random_walk (with the floats it drew), take-all sample_adj, saint_subgraph, relabel,
+    relabel_one_hop of the reference's CPU kernels."""
+    srcs = SPMM_SRCS + ('rw.cpp', 'cpu/rw_cpu.cpp', 'sample.cpp', 'cpu/sample_cpu.cpp', 'saint.cpp',
+                        'cpu/saint_cpu.cpp', 'relabel.cpp', 'cpu/relabel_cpu.cpp')
+    scratch, pkg = make_scratch(['transpose', 'coalesce', 'sample', 'saint', 'rw'], srcs)
+    with open(os.path.join(pkg, '__init__.py'), 'w') as f:
+        f.write("import os, torch\n"
+                "torch.ops.load_library(os.path.join(os.path.dirname(__file__), '_ops_cpu.so'))\n"
+                "from .storage import SparseStorage\nfrom .tensor import SparseTensor\n"
+                "from .sample import sample, sample_adj\nfrom .saint import saint_subgraph\n"
+                "from .rw import random_walk\n")
+    env = dict(os.environ, TS_SCRATCH=scratch, TS_OUT=HERE, OMP_NUM_THREADS='1')
+    subprocess.check_call([sys.executable, '-c', PART4], env=env)
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree %s not present' % REF)
-    todo = sys.argv[1:] or ['part1', 'part2', 'part3']
+    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4']
     for name in todo:  # e.g. `make_golden.py part3` regenerates only the py3_* fixtures
-        {'part1': part1, 'part2': part2, 'part3': part3}[name]()
+        {'part1': part1, 'part2': part2, 'part3': part3, 'part4': part4}[name]()

@@ -15,6 +15,12 @@ EXPECTED = {
     'cuda_version': 'torch_sparse::cuda_version() -> int _0',
     # csrc/diag.cpp:22-36 (widening)
     'non_diag_mask': 'torch_sparse::non_diag_mask(Tensor _0, Tensor _1, int _2, int _3, int _4) -> Tensor _0',
+    # csrc/rw.cpp, sample.cpp, relabel.cpp, saint.cpp (widening)
+    'random_walk': 'torch_sparse::random_walk(Tensor _0, Tensor _1, Tensor _2, int _3) -> Tensor _0',
+    'sample_adj': 'torch_sparse::sample_adj(Tensor _0, Tensor _1, Tensor _2, int _3, bool _4) -> (Tensor _0, Tensor _1, Tensor _2, Tensor _3)',
+    'relabel': 'torch_sparse::relabel(Tensor _0, Tensor _1) -> (Tensor _0, Tensor _1)',
+    'relabel_one_hop': 'torch_sparse::relabel_one_hop(Tensor _0, Tensor _1, Tensor? _2, Tensor _3, bool _4) -> (Tensor _0, Tensor _1, Tensor? _2, Tensor _3)',
+    'saint_subgraph': 'torch_sparse::saint_subgraph(Tensor _0, Tensor _1, Tensor _2, Tensor _3) -> (Tensor _0, Tensor _1, Tensor _2)',
 }
 
 
@@ -23,6 +29,21 @@ def test_reference_op_schemas():
         op = getattr(torch.ops.torch_sparse, name)
         assert str(op.default._schema) == schema, (name, str(op.default._schema))
     assert torch.ops.torch_sparse.cuda_version() >= 60000000
+
+
+def test_schemas_equal_the_compiled_reference():
+    """Every op registered here under torch_sparse:: has exactly the schema the reference's own op
+    file registers (its csrc/*.cpp compiled unmodified into oracle/_ref under the ts_ref:: namespace)."""
+    import pytest
+    from oracle import ref
+    if not ref.available():
+        pytest.skip('oracle/_ref not built')
+    ref.ops()
+    for name in EXPECTED:
+        if name == 'cuda_version':  # csrc/version.cpp is not part of oracle/_ref
+            continue
+        want = str(getattr(torch.ops.ts_ref, name).default._schema).replace('ts_ref::', 'torch_sparse::')
+        assert str(getattr(torch.ops.torch_sparse, name).default._schema) == want, name
 
 
 def test_ops_refuse_cpu_tensors():
@@ -53,13 +74,14 @@ def test_api_surface():
         assert hasattr(pytorch_sparse_amd.SparseTensor, m)
     # the widened surface: every name the reference package exports for it
     for name in ('narrow', '__narrow_diag__', 'select', 'index_select', 'index_select_nnz', 'masked_select',
-                 'masked_select_nnz', 'permute', 'remove_diag', 'set_diag', 'fill_diag', 'get_diag', 'add',
+                 'masked_select_nnz', 'permute', 'remove_diag', 'set_diag', 'fill_diag', 'get_diag', 'sample', 'sample_adj', 'random_walk', 'saint_subgraph', 'add',
                  'add_', 'add_nnz', 'add_nnz_', 'mul', 'mul_', 'mul_nnz', 'mul_nnz_', 'sum', 'mean', 'min',
                  'max', 'cat', 'to_torch_sparse', 'from_torch_sparse', 'to_scipy', 'from_scipy', 'eye', 'spadd'):
         assert hasattr(pytorch_sparse_amd, name), name
     for m in ('narrow', 'select', 'index_select', 'index_select_nnz', 'masked_select', 'masked_select_nnz',
               'permute', 'remove_diag', 'set_diag', 'fill_diag', 'get_diag', 'add', 'add_', 'mul', 'mul_',
-              '__getitem__', '__add__', '__mul__', 'sum', 'mean', 'min', 'max'):
+              '__getitem__', '__add__', '__mul__', 'sum', 'mean', 'min', 'max', 'sample', 'sample_adj', 'random_walk',
+              'saint_subgraph'):
         assert hasattr(pytorch_sparse_amd.SparseTensor, m), m
 
 

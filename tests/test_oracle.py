@@ -186,3 +186,82 @@ def test_np_oracle_matches_reference_python_fixtures():
             assert np.allclose(v, z['vC'], rtol=1e-6, atol=1e-6), f
         n_checked += 1
     assert n_checked > 20
+
+
+def test_np_oracle_matches_reference_sampler_fixtures():
+    """random_walk / relabel / relabel_one_hop / take-all sample_adj / saint_subgraph restatements
+    against the outputs of the reference's CPU kernels compiled unmodified (make_golden.py part 4)."""
+    import glob
+    from oracle import np_oracle as npo
+    G = np.load(os.path.join(GOLDEN, 'py4_graph.npz'))
+    rowptr, col = G['rowptr'], G['col']
+    n_checked = 0
+    for path in sorted(glob.glob(os.path.join(GOLDEN, 'py4_*.npz'))):
+        name = os.path.basename(path)
+        z = np.load(path)
+        if name.startswith('py4_rw_'):
+            np.testing.assert_array_equal(npo.random_walk(rowptr, col, z['start'], z['rand']), z['out'])
+        elif name.startswith('py4_sample_all_'):
+            rp, c, n_id, e_id = npo.sample_adj_all(rowptr, col, z['idx'])
+            for got, key in ((rp, 'rowptr'), (c, 'col'), (n_id, 'n_id'), (e_id, 'e_id')):
+                np.testing.assert_array_equal(got, z[key], err_msg=name + ':' + key)
+        elif name.startswith('py4_saint_'):
+            r, c, e = npo.saint_subgraph(z['idx'], rowptr, col)
+            for got, key in ((r, 'row'), (c, 'col'), (e, 'edge_index')):
+                np.testing.assert_array_equal(got, z[key], err_msg=name + ':' + key)
+        elif name.startswith('py4_relabel_one_hop_'):
+            bip = name.endswith('_1.npz')
+            rp, c, pos, oi = npo.relabel_one_hop(rowptr, col, z['idx'], bip)
+            np.testing.assert_array_equal(rp, z['rowptr'])
+            np.testing.assert_array_equal(c, z['col'])
+            np.testing.assert_array_equal(oi, z['out_idx'])
+            np.testing.assert_array_equal(G['value'][pos], z['value'])
+        elif name.startswith('py4_relabel_'):
+            oc, oi = npo.relabel(z['col'], z['idx'])
+            np.testing.assert_array_equal(oc, z['out_col'])
+            np.testing.assert_array_equal(oi, z['out_idx'])
+        else:
+            continue
+        n_checked += 1
+    assert n_checked == 24
+
+
+@pytest.mark.skipif(not ref.available(), reason='oracle/_ref not built')
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_np_oracle_matches_compiled_reference_samplers(seed):
+    """The same restatements against the reference's CPU kernels run live (oracle/_ref), on random
+    graphs with isolated nodes excluded from walks (the reference reads out of the row there)."""
+    from oracle import np_oracle as npo
+    r = ref.ops()
+    rng = np.random.default_rng(seed)
+    n = 300 + 50 * seed
+    key = np.unique(np.concatenate([rng.integers(0, n * n, 4000), np.arange(n) * n + (np.arange(n) + 1) % n]))
+    row, col = key // n, key % n
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(row, minlength=n), out=rowptr[1:])
+    t = torch.from_numpy
+    idx = rng.permutation(n)[:rng.integers(1, n)]
+
+    torch.manual_seed(seed)
+    start = rng.integers(0, n, 77)
+    out = r.random_walk(t(rowptr), t(col), t(start), 12)
+    torch.manual_seed(seed)
+    rand = torch.rand((77, 12)).numpy()
+    np.testing.assert_array_equal(npo.random_walk(rowptr, col, start, rand), out.numpy())
+
+    want = r.sample_adj(t(rowptr), t(col), t(idx), -1, False)
+    for g, w in zip(npo.sample_adj_all(rowptr, col, idx), want):
+        np.testing.assert_array_equal(g, w.numpy())
+    want = r.saint_subgraph(t(idx), t(rowptr), t(row), t(col))
+    for g, w in zip(npo.saint_subgraph(idx, rowptr, col), want):
+        np.testing.assert_array_equal(g, w.numpy())
+    cols = col[rng.integers(0, col.size, 500)]
+    want = r.relabel(t(cols), t(idx))
+    for g, w in zip(npo.relabel(cols, idx), want):
+        np.testing.assert_array_equal(g, w.numpy())
+    for bip in (False, True):
+        w_rp, w_c, _, w_idx = r.relabel_one_hop(t(rowptr), t(col), None, t(idx), bip)
+        g_rp, g_c, _, g_idx = npo.relabel_one_hop(rowptr, col, idx, bip)
+        np.testing.assert_array_equal(g_rp, w_rp.numpy())
+        np.testing.assert_array_equal(g_c, w_c.numpy())
+        np.testing.assert_array_equal(g_idx, w_idx.numpy())

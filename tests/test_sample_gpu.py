@@ -1,0 +1,270 @@
+"""Mini-batch producers on the GPU: random_walk, sample_adj, saint_subgraph,
+relabel, relabel_one_hop.
+
+  * bit-exact against tests/golden/py4_*.npz -- outputs of the reference's CPU kernels compiled
+    unmodified (make_golden.py part 4): walks with the floats the reference drew, and every
+    deterministic case of the others;
+  * bit-exact against the numpy restatement (oracle/np_oracle.py, itself pinned by those fixtures)
+    on graphs the fixtures cannot carry;
+  * for the random draws: the properties the reference guarantees (counts, distinctness, membership,
+    relabelling, row order), reproducibility under torch.manual_seed, and chi-square uniformity.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as npo
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DEV = 'cuda'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.fixture(scope='module')
+def ts():
+    import pytorch_sparse_amd
+    return pytorch_sparse_amd
+
+
+@pytest.fixture(scope='module')
+def graph(ts):
+    G = np.load(os.path.join(GOLDEN, 'py4_graph.npz'))
+    A = ts.SparseTensor(row=dev(G['row']), col=dev(G['col']), value=dev(G['value']),
+                        sparse_sizes=(int(G['n']), int(G['n'])), is_sorted=True)
+    return G, A
+
+
+def _fixtures(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN, prefix + '*.npz')))
+
+
+@pytest.mark.parametrize('path', _fixtures('py4_rw_'), ids=os.path.basename)
+def test_golden_random_walk(graph, path):
+    G, A = graph
+    z = np.load(path)
+    out = torch.ops.tsamd.random_walk_with_rand(dev(G['rowptr']), dev(G['col']), dev(z['start']), dev(z['rand']))
+    np.testing.assert_array_equal(host(out), z['out'])
+
+
+@pytest.mark.parametrize('path', _fixtures('py4_sample_all_'), ids=os.path.basename)
+def test_golden_sample_adj_take_all(ts, graph, path):
+    G, A = graph
+    z = np.load(path)
+    rp, c, n_id, e_id = torch.ops.torch_sparse.sample_adj(dev(G['rowptr']), dev(G['col']), dev(z['idx']), -1, False)
+    for got, key in ((rp, 'rowptr'), (c, 'col'), (n_id, 'n_id'), (e_id, 'e_id')):
+        np.testing.assert_array_equal(host(got), z[key], err_msg=key)
+    adj, n_id2 = A.sample_adj(dev(z['idx']), -1)
+    assert torch.equal(n_id2, n_id)
+    assert adj.sparse_sizes() == (z['idx'].size, z['n_id'].size)
+    np.testing.assert_array_equal(host(adj.storage.value()), z['value'])
+
+
+@pytest.mark.parametrize('path', _fixtures('py4_saint_'), ids=os.path.basename)
+def test_golden_saint_subgraph(ts, graph, path):
+    G, A = graph
+    z = np.load(path)
+    r, c, e = torch.ops.torch_sparse.saint_subgraph(dev(z['idx']), dev(G['rowptr']), dev(G['row']), dev(G['col']))
+    for got, key in ((r, 'row'), (c, 'col'), (e, 'edge_index')):
+        np.testing.assert_array_equal(host(got), z[key], err_msg=key)
+    sub, e2 = ts.saint_subgraph(A, dev(z['idx']))
+    assert torch.equal(e2, e) and sub.sparse_sizes() == (z['idx'].size, z['idx'].size)
+    np.testing.assert_array_equal(host(sub.storage.value()), z['value'])
+
+
+@pytest.mark.parametrize('path', _fixtures('py4_relabel_'), ids=os.path.basename)
+def test_golden_relabel(graph, path):
+    G, A = graph
+    z = np.load(path)
+    if 'one_hop' in path:
+        bip = path.endswith('_1.npz')
+        rp, c, v, oi = torch.ops.torch_sparse.relabel_one_hop(dev(G['rowptr']), dev(G['col']), dev(G['value']),
+                                                              dev(z['idx']), bip)
+        np.testing.assert_array_equal(host(rp), z['rowptr'])
+        np.testing.assert_array_equal(host(c), z['col'])
+        np.testing.assert_array_equal(host(v), z['value'])
+        np.testing.assert_array_equal(host(oi), z['out_idx'])
+        rp2, c2, v2, _ = torch.ops.torch_sparse.relabel_one_hop(dev(G['rowptr']), dev(G['col']), None,
+                                                                dev(z['idx']), bip)
+        assert v2 is None and torch.equal(c2, c) and torch.equal(rp2, rp)
+    else:
+        oc, oi = torch.ops.torch_sparse.relabel(dev(z['col']), dev(z['idx']))
+        np.testing.assert_array_equal(host(oc), z['out_col'])
+        np.testing.assert_array_equal(host(oi), z['out_idx'])
+
+
+# ---------------------------------------------------------------------------------------------
+# larger graphs against the numpy restatement
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def big():
+    from pytorch_sparse_amd import synth
+    rowptr, col = synth.rmat_csr(17, 16, seed=5)
+    return rowptr.numpy(), col.numpy()
+
+
+def test_large_deterministic_ops_match_oracle(big):
+    rowptr, col = big
+    n = rowptr.size - 1
+    rng = np.random.default_rng(0)
+    rp, c = dev(rowptr), dev(col)
+    row = torch.ops.torch_sparse.ptr2ind(rp, col.size)
+
+    idx = rng.permutation(n)[:20_000]
+    got = torch.ops.torch_sparse.sample_adj(rp, c, dev(idx), -1, False)
+    want = npo.sample_adj_all(rowptr, col, idx)
+    # R-MAT has duplicate edges: equal new column ids inside a row may swap their e_id (the
+    # reference's std::sort is not stable either) -> compare e_id through the column it points to
+    for g, w, key in zip(got[:3], want[:3], ('rowptr', 'col', 'n_id')):
+        np.testing.assert_array_equal(host(g), w, err_msg=key)
+    np.testing.assert_array_equal(col[host(got[3])], col[want[3]])
+    np.testing.assert_array_equal(np.sort(host(got[3])), np.sort(want[3]))
+
+    sub = rng.permutation(n)[:40_000]
+    got = torch.ops.torch_sparse.saint_subgraph(dev(sub), rp, row, c)
+    for g, w, key in zip(got, npo.saint_subgraph(sub, rowptr, col), ('row', 'col', 'edge_index')):
+        np.testing.assert_array_equal(host(g), w, err_msg=key)
+
+    cols = col[rng.integers(0, col.size, 300_000)]
+    got = torch.ops.torch_sparse.relabel(dev(cols), dev(idx))
+    for g, w in zip(got, npo.relabel(cols, idx)):
+        np.testing.assert_array_equal(host(g), w)
+
+    for bip in (False, True):
+        g_rp, g_c, _, g_idx = torch.ops.torch_sparse.relabel_one_hop(rp, c, None, dev(idx), bip)
+        w_rp, w_c, _, w_idx = npo.relabel_one_hop(rowptr, col, idx, bip)
+        np.testing.assert_array_equal(host(g_rp), w_rp)
+        np.testing.assert_array_equal(host(g_c), w_c)
+        np.testing.assert_array_equal(host(g_idx), w_idx)
+
+    start = rng.integers(0, n, 100_000)
+    rand = rng.random((100_000, 20), dtype=np.float32)
+    out = torch.ops.tsamd.random_walk_with_rand(rp, c, dev(start), dev(rand))
+    np.testing.assert_array_equal(host(out), npo.random_walk(rowptr, col, start, rand))
+
+
+def test_random_walk_follows_edges(ts, big):
+    rowptr, col = big
+    n = rowptr.size - 1
+    A = ts.SparseTensor(rowptr=dev(rowptr), col=dev(col), sparse_sizes=(n, n), is_sorted=True)
+    start = torch.randint(0, n, (50_000, ), device=DEV)
+    torch.manual_seed(3)
+    walk = A.random_walk(start, 8)
+    assert walk.shape == (50_000, 9) and torch.equal(walk[:, 0], start)
+    torch.manual_seed(3)
+    assert torch.equal(ts.random_walk(A, start, 8), walk)  # reproducible under the device generator
+    w = host(walk)
+    deg = rowptr[1:] - rowptr[:-1]
+    keys = set((np.repeat(np.arange(n), deg) * n + col).tolist())
+    src, dst = w[:, :-1].ravel(), w[:, 1:].ravel()
+    stay = deg[src] == 0
+    assert np.array_equal(dst[stay], src[stay])  # isolated nodes keep the walk in place
+    assert all(k in keys for k in (src[~stay] * n + dst[~stay]).tolist())
+    assert len(np.unique(w[:, 1])) > 1000  # not degenerate
+
+
+@pytest.mark.parametrize('replace', [False, True])
+@pytest.mark.parametrize('k', [1, 5, 25])
+def test_sample_adj_properties(ts, big, k, replace):
+    rowptr, col = big
+    n = rowptr.size - 1
+    rng = np.random.default_rng(k)
+    idx = rng.permutation(n)[:30_000]
+    A = ts.SparseTensor(rowptr=dev(rowptr), col=dev(col), value=torch.arange(col.size, device=DEV).float(),
+                        sparse_sizes=(n, n), is_sorted=True)
+    torch.manual_seed(11)
+    adj, n_id = A.sample_adj(dev(idx), k, replace=replace)
+    rp, c, v = (host(t) for t in adj.csr())
+    n_id = host(n_id)
+    e_id = v.astype(np.int64)  # value = position in the source, so it doubles as e_id
+    deg = rowptr[idx + 1] - rowptr[idx]
+    cnt = np.where(deg > 0, k, 0) if replace else np.minimum(deg, k)
+    np.testing.assert_array_equal(rp[1:] - rp[:-1], cnt)
+    assert adj.sparse_sizes() == (idx.size, n_id.size)
+    # relabelling: seeds first, every id once, columns point back at the sampled source entry
+    np.testing.assert_array_equal(n_id[:idx.size], idx)
+    assert np.unique(n_id).size == n_id.size
+    np.testing.assert_array_equal(n_id[c], col[e_id])
+    # every sampled entry belongs to the row of its seed
+    seg = np.repeat(np.arange(idx.size), cnt)
+    assert np.all((e_id >= rowptr[idx][seg]) & (e_id < rowptr[idx + 1][seg]))
+    if not replace:
+        assert np.unique(e_id).size == e_id.size  # distinct draws
+    # rows sorted by the new column id
+    same_row = seg[1:] == seg[:-1]
+    assert np.all(c[1:][same_row] >= c[:-1][same_row])
+    # new nodes are numbered in first-occurrence order of the (row-major) draws: the first time an id
+    # >= n_seeds appears when rows are scanned in order, it must be the next unused id
+    # (checked on the unsorted draw order through the op's e_id is not possible; check monotone cover)
+    new = c[c >= idx.size]
+    assert new.size == 0 or (np.unique(new).size == n_id.size - idx.size)
+    # reproducible
+    torch.manual_seed(11)
+    adj2, n_id2 = A.sample_adj(dev(idx), k, replace=replace)
+    assert torch.equal(adj2.storage.col(), adj.storage.col()) and np.array_equal(host(n_id2), n_id)
+    torch.manual_seed(12)
+    adj3, _ = A.sample_adj(dev(idx), k, replace=replace)
+    if (deg > k).sum() > 100:
+        assert not torch.equal(adj3.storage.value(), adj.storage.value())
+
+
+@pytest.mark.parametrize('replace', [False, True])
+def test_sample_adj_uniform(ts, replace):
+    """2000 rows share the same 1000 neighbours; every neighbour must be drawn equally often."""
+    R, D, k = 2000, 1000, 100
+    rowptr = np.concatenate([np.arange(R + 1) * D, np.full(D, R * D)]).astype(np.int64)
+    col = np.tile(np.arange(R, R + D), R).astype(np.int64)
+    torch.manual_seed(2024)
+    rp, c, n_id, e_id = torch.ops.torch_sparse.sample_adj(dev(rowptr), dev(col), torch.arange(R, device=DEV), k, replace)
+    picked = col[host(e_id)] - R
+    counts = np.bincount(picked, minlength=D).astype(np.float64)
+    expect = R * k / D
+    chi2 = ((counts - expect) ** 2 / expect).sum()
+    # with replacement chi2 ~ chi-square(999): 999 +- 45; without, the draws of a row are negatively
+    # correlated and the statistic shrinks by (1 - k/D)
+    lo, hi = (820, 1180) if replace else (720, 1080)
+    assert lo < chi2 < hi, chi2
+    # different rows must draw independently: two rows share k*k/D = 10 neighbours on average
+    B = np.zeros((R, D), bool)
+    B[np.repeat(np.arange(R), k), picked] = True
+    overlap = (B[:-1] & B[1:]).sum(1).mean()
+    want = k * k / D if not replace else D * (1 - (1 - 1 / D) ** k) ** 2
+    assert abs(overlap - want) < 0.5, overlap
+
+
+def test_sample_with_replacement_api(ts, big):
+    rowptr, col = big
+    n = rowptr.size - 1
+    A = ts.SparseTensor(rowptr=dev(rowptr), col=dev(col), sparse_sizes=(n, n), is_sorted=True)
+    subset = torch.randint(0, n, (10_000, ), device=DEV)
+    out = host(A.sample(7, subset))
+    assert out.shape == (10_000, 7)
+    s = host(subset)
+    deg = rowptr[s + 1] - rowptr[s]
+    assert np.all(out[deg == 0] == -1)
+    for i in np.nonzero(deg > 0)[0][:500]:
+        assert set(out[i]) <= set(col[rowptr[s[i]]:rowptr[s[i] + 1]])
+    assert ts.sample(A, 3).shape == (n, 3)
+
+
+def test_bad_ids_raise(ts, graph):
+    G, A = graph
+    n = int(G['n'])
+    bad = torch.tensor([0, n], device=DEV)
+    with pytest.raises(IndexError):
+        A.sample_adj(bad, 3)
+    with pytest.raises(IndexError):
+        A.saint_subgraph(bad)
+    with pytest.raises(IndexError):
+        torch.ops.torch_sparse.relabel_one_hop(dev(G['rowptr']), dev(G['col']), None, bad, False)
