@@ -2,7 +2,7 @@
 
 Compiles, unmodified and where they lie under /root/reference:
     csrc/spmm.cpp  csrc/cpu/spmm_cpu.cpp  csrc/convert.cpp  csrc/cpu/convert_cpu.cpp
-    csrc/{sample,rw,saint,relabel,diag}.cpp + their csrc/cpu/*_cpu.cpp   (SURVEY 8f widening)
+    csrc/{sample,rw,saint,relabel,diag,neighbor_sample}.cpp + their csrc/cpu/*_cpu.cpp   (SURVEY 8f widening)
 with g++ (mirrors setup.py:67-81 of the reference: -O3 -fopenmp -DAT_PARALLEL_OPENMP,
 no WITH_CUDA => CPU only) into ``oracle/_ref/libts_ref.so``.  The two op files are
 included through ``ref_wrap_*.cpp`` so their registrations land in ``ts_ref::`` instead
@@ -32,7 +32,7 @@ def build(verbose=True):
     import torch
     from torch.utils import cpp_extension as ce
     os.makedirs(OUT, exist_ok=True)
-    families = ['spmm', 'convert', 'sample', 'rw', 'saint', 'relabel', 'diag']
+    families = ['spmm', 'convert', 'sample', 'rw', 'saint', 'relabel', 'diag', 'neighbor_sample']
     srcs, deps = [], [os.path.join(HERE, 'ref_wrap.h'), os.path.join(csrc, 'cpu', 'reducer.h'),
                       os.path.abspath(__file__)]
     for fam in families:

@@ -152,3 +152,24 @@ def saint_subgraph(idx, rowptr, col):
     w = assoc[np.asarray(col, np.int64)[pos]] if pos.size else np.zeros(0, np.int64)
     keep = w >= 0
     return seg[keep], w[keep], pos[keep]
+
+
+def neighbor_sample_all(colptr, row, input_node, num_hops, directed):
+    """csrc/cpu/neighbor_sample_cpu.cpp:15-124 with num_neighbors = [-1] * num_hops (every in-neighbour):
+    -> (node, row, col, edge).  Hop l expands the nodes found in hop l-1; new nodes are appended in
+    first-occurrence order; directed=False returns every stored edge between the sampled nodes."""
+    colptr, row = np.asarray(colptr, np.int64), np.asarray(row, np.int64)
+    samples = np.asarray(input_node, np.int64)
+    begin, end = 0, samples.size
+    rows, cols, edges = [], [], []
+    for _ in range(num_hops):
+        frontier = samples[begin:end]
+        _, seg, pos = _gather_rows(colptr, frontier)
+        local, samples = relabel(row[pos], samples)
+        rows.append(local), cols.append(seg + begin), edges.append(pos)
+        begin, end = end, samples.size
+    if not directed:
+        i, v, pos = saint_subgraph(samples, colptr, row)
+        return samples, v, i, pos
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)  # noqa: E731
+    return samples, cat(rows), cat(cols), cat(edges)

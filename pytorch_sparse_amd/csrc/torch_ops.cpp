@@ -819,42 +819,123 @@ std::tuple<Tensor, Tensor, OptTensor, Tensor> relabel_one_hop(Tensor rowptr, Ten
   return std::make_tuple(out_ptr, r.local, out_value, r.n_id);
 }
 
+// Entries of the segments idx of (ptr, ind) whose index is itself in idx:
+// -> (position of the segment in idx, position of the index in idx, position of the entry), in
+// idx order and stored order inside a segment.  Two host syncs.
+std::tuple<Tensor, Tensor, Tensor> induced_entries(Tensor idx, Tensor ptr, Tensor ind) {
+  idx = idx.contiguous();
+  const int64_t M = ptr.numel() - 1, n = idx.numel();
+  auto iopt = ptr.options().requires_grad(false);
+  void *stream = current_stream(ptr);
+  Tensor assoc = torch::empty({M}, iopt), err = torch::empty({1}, iopt);
+  check_status(tsamd_subset_assoc(idx.data_ptr<int64_t>(), n, M, assoc.data_ptr<int64_t>(),
+                                  err.data_ptr<int64_t>(), stream),
+               "tsamd_subset_assoc");
+  auto sel = select_segments(ptr, ind, idx, true, true);  // sync 1 (raises on bad ids)
+  Tensor seg = std::get<1>(sel), nbr = std::get<2>(sel), pos = std::get<3>(sel);
+  const int64_t T = nbr.numel();
+  Tensor keep = torch::empty({T + 1}, iopt), cnt = torch::empty({1}, iopt);
+  Tensor ws = workspace(tsamd_filter_workspace_bytes(T), ptr);
+  check_status(tsamd_filter_plan(TSAMD_KEEP_COL_MAPPED, nullptr, nbr.data_ptr<int64_t>(), nullptr,
+                                 assoc.data_ptr<int64_t>(), T, 0, 0, keep.data_ptr<int64_t>(),
+                                 cnt.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
+               "tsamd_filter_plan");
+  const int64_t kept = cnt.item<int64_t>();  // sync 2
+  Tensor seg_out = torch::empty({kept}, iopt), map_out = torch::empty({kept}, iopt);
+  Tensor src = torch::empty({kept}, iopt);
+  check_status(tsamd_filter_apply(keep.data_ptr<int64_t>(), seg.data_ptr<int64_t>(),
+                                  nbr.data_ptr<int64_t>(), T, nullptr, assoc.data_ptr<int64_t>(), 0, 0,
+                                  seg_out.data_ptr<int64_t>(), map_out.data_ptr<int64_t>(),
+                                  src.data_ptr<int64_t>(), stream),
+               "tsamd_filter_apply");
+  return std::make_tuple(seg_out, map_out, pos.index_select(0, src));
+}
+
 // torch_sparse::saint_subgraph(Tensor idx, Tensor rowptr, Tensor row, Tensor col)
 //   -> (Tensor row, Tensor col, Tensor edge_index)                       (csrc/saint.cpp:20-33)
 // Sub-graph induced by the node subset idx, nodes renumbered by their position in idx; rows in
-// idx order, every row keeps its stored column order (as subgraph_cpu does).  Two host syncs.
+// idx order, every row keeps its stored column order (as subgraph_cpu does).
 std::tuple<Tensor, Tensor, Tensor> saint_subgraph(Tensor idx, Tensor rowptr, Tensor row, Tensor col) {
   check_index(idx, "idx");
   check_index(rowptr, "rowptr");
   check_index(col, "col");
   TORCH_CHECK(rowptr.numel() >= 1, "saint_subgraph: empty rowptr");
   c10::hip::HIPGuard guard(rowptr.get_device());
-  idx = idx.contiguous();
-  const int64_t M = rowptr.numel() - 1, n = idx.numel();
-  auto iopt = rowptr.options().requires_grad(false);
-  void *stream = current_stream(rowptr);
-  Tensor assoc = torch::empty({M}, iopt), err = torch::empty({1}, iopt);
-  check_status(tsamd_subset_assoc(idx.data_ptr<int64_t>(), n, M, assoc.data_ptr<int64_t>(),
-                                  err.data_ptr<int64_t>(), stream),
-               "tsamd_subset_assoc");
-  auto sel = select_segments(rowptr, col, idx, true, true);  // sync 1 (raises on bad ids)
-  Tensor seg = std::get<1>(sel), nbr = std::get<2>(sel), pos = std::get<3>(sel);
-  const int64_t T = nbr.numel();
-  Tensor keep = torch::empty({T + 1}, iopt), cnt = torch::empty({1}, iopt);
-  Tensor ws = workspace(tsamd_filter_workspace_bytes(T), rowptr);
-  check_status(tsamd_filter_plan(TSAMD_KEEP_COL_MAPPED, nullptr, nbr.data_ptr<int64_t>(), nullptr,
-                                 assoc.data_ptr<int64_t>(), T, 0, 0, keep.data_ptr<int64_t>(),
-                                 cnt.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
-               "tsamd_filter_plan");
-  const int64_t kept = cnt.item<int64_t>();  // sync 2
-  Tensor row_out = torch::empty({kept}, iopt), col_out = torch::empty({kept}, iopt);
-  Tensor src = torch::empty({kept}, iopt);
-  check_status(tsamd_filter_apply(keep.data_ptr<int64_t>(), seg.data_ptr<int64_t>(),
-                                  nbr.data_ptr<int64_t>(), T, nullptr, assoc.data_ptr<int64_t>(), 0, 0,
-                                  row_out.data_ptr<int64_t>(), col_out.data_ptr<int64_t>(),
-                                  src.data_ptr<int64_t>(), stream),
-               "tsamd_filter_apply");
-  return std::make_tuple(row_out, col_out, pos.index_select(0, src));
+  return induced_entries(idx, rowptr, col);
+}
+
+// torch_sparse::neighbor_sample(Tensor colptr, Tensor row, Tensor input_node, int[] num_neighbors,
+//                               bool replace, bool directed) -> (Tensor node, Tensor row, Tensor col, Tensor edge)
+// (reference schema, csrc/neighbor_sample.cpp:18-27; CPU-only there).  Multi-hop sampling on the
+// CSC view: hop l draws num_neighbors[l] in-neighbours of every node discovered in hop l-1; nodes
+// are numbered in first-occurrence order across hops; an edge is (local id of the drawn source,
+// local id of the frontier node, position in `row`).  directed=false returns instead every stored
+// edge between the sampled nodes.  Two host syncs per hop.
+std::tuple<Tensor, Tensor, Tensor, Tensor> neighbor_sample(const Tensor &colptr_, const Tensor &row_,
+                                                           const Tensor &input_node,
+                                                           std::vector<int64_t> num_neighbors,
+                                                           bool replace, bool directed) {
+  check_index(colptr_, "colptr");
+  check_index(row_, "row");
+  check_index(input_node, "input_node");
+  TORCH_CHECK(colptr_.numel() >= 1, "neighbor_sample: empty colptr");
+  c10::hip::HIPGuard guard(colptr_.get_device());
+  Tensor colptr = colptr_.contiguous(), row = row_.contiguous();
+  const int64_t M = colptr.numel() - 1;
+  auto iopt = colptr.options().requires_grad(false);
+  void *stream = current_stream(colptr);
+  Tensor samples = input_node.contiguous();
+  int64_t begin = 0, end = samples.numel();
+  std::vector<Tensor> rows, cols, edges;
+  const uint64_t seed0 = (uint64_t)torch::randint(0, std::numeric_limits<int64_t>::max(), {1},
+                                                  torch::TensorOptions().dtype(torch::kLong))
+                             .item<int64_t>();
+  for (size_t ell = 0; ell < num_neighbors.size(); ++ell) {
+    const int64_t k = num_neighbors[ell], F = end - begin;
+    Tensor frontier = samples.narrow(0, begin, F);
+    Tensor out_ptr = torch::empty({F + 1}, iopt), info = torch::empty({2}, iopt);
+    Tensor ws = workspace(tsamd_sample_workspace_bytes(F), colptr);
+    check_status(tsamd_sample_plan(colptr.data_ptr<int64_t>(), M, frontier.data_ptr<int64_t>(), F, k,
+                                   replace ? 1 : 0, out_ptr.data_ptr<int64_t>(),
+                                   info.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
+                 "tsamd_sample_plan");
+    Tensor h = info.cpu();  // sync 1
+    const int64_t T = h.data_ptr<int64_t>()[0], bad = h.data_ptr<int64_t>()[1];
+    TORCH_CHECK_INDEX(bad == 0, "index out of range: ", bad, " node ids are outside [0, ", M, ")");
+    Tensor e = torch::empty({T}, iopt), nbr = torch::empty({T}, iopt);
+    if (k < 0) {
+      check_status(tsamd_select_fill(colptr.data_ptr<int64_t>(), M, row.data_ptr<int64_t>(),
+                                     frontier.data_ptr<int64_t>(), F, out_ptr.data_ptr<int64_t>(), T,
+                                     nullptr, nbr.data_ptr<int64_t>(), e.data_ptr<int64_t>(), stream),
+                   "tsamd_select_fill");
+    } else {
+      check_status(tsamd_sample_draw(colptr.data_ptr<int64_t>(), row.data_ptr<int64_t>(),
+                                     frontier.data_ptr<int64_t>(), F, k, replace ? 1 : 0,
+                                     seed0 + 0x9E3779B97F4A7C15ull * (uint64_t)(ell + 1),
+                                     out_ptr.data_ptr<int64_t>(), e.data_ptr<int64_t>(),
+                                     nbr.data_ptr<int64_t>(), stream),
+                   "tsamd_sample_draw");
+    }
+    Relabelled r = relabel_impl(samples, nbr, M, directed);  // sync 2
+    if (directed) {
+      Tensor seg = torch::empty({T}, iopt);
+      check_status(tsamd_ptr2ind(out_ptr.data_ptr<int64_t>(), F, T, seg.data_ptr<int64_t>(), stream),
+                   "tsamd_ptr2ind");
+      rows.push_back(r.local);
+      cols.push_back(begin > 0 ? seg + begin : seg);
+      edges.push_back(e);
+    }
+    samples = r.n_id;
+    begin = end;
+    end = samples.numel();
+  }
+  if (!directed) {
+    auto sub = induced_entries(samples, colptr, row);
+    return std::make_tuple(samples, std::get<1>(sub), std::get<0>(sub), std::get<2>(sub));
+  }
+  Tensor none = torch::empty({0}, iopt);
+  return std::make_tuple(samples, rows.empty() ? none : torch::cat(rows), cols.empty() ? none : torch::cat(cols),
+                         edges.empty() ? none : torch::cat(edges));
 }
 
 }  // namespace
@@ -882,4 +963,5 @@ static auto registry = torch::RegisterOperators()
                            .op("torch_sparse::sample_adj", &sample_adj)
                            .op("torch_sparse::relabel", &relabel)
                            .op("torch_sparse::relabel_one_hop", &relabel_one_hop)
-                           .op("torch_sparse::saint_subgraph", &saint_subgraph);
+                           .op("torch_sparse::saint_subgraph", &saint_subgraph)
+                           .op("torch_sparse::neighbor_sample", &neighbor_sample);

@@ -63,3 +63,12 @@ for frac in (0.01, 0.25):
     ms = wall(lambda: A.saint_subgraph(idx))
     sub, _ = A.saint_subgraph(idx)
     print(json.dumps(dict(bench='saint_subgraph', nodes=idx.numel(), ms=round(ms, 3), edges=sub.nnz())), flush=True)
+
+# multi-hop neighbor_sample (the CSR arrays serve as the CSC view of the transposed graph)
+for seeds, fan in ((1024, [25, 10]), (1024, [15, 10, 5]), (100_000, [10, 10])):
+    inp = perm[:seeds]
+    fn = lambda: torch.ops.torch_sparse.neighbor_sample(rp, c, inp, fan, False, True)  # noqa: E731
+    ms = wall(fn)
+    node, r_, c_, e_ = fn()
+    print(json.dumps(dict(bench='neighbor_sample', seeds=seeds, fanout=fan, ms=round(ms, 3), nodes=node.numel(),
+                          edges=e_.numel(), medges_per_s=round(e_.numel() / ms / 1e3, 1))), flush=True)

@@ -21,7 +21,10 @@ container (it cannot travel to the GPU box; the fixtures can).
                                   saint, relabel): random walks together with the floats they
                                   drew, and the deterministic cases of the others.
 
-Usage:  python tests/golden/make_golden.py [part1] [part2] [part3] [part4]   (needs /root/reference)
+  part 5  py5_*.npz             : multi-hop neighbor_sample (csrc/cpu/neighbor_sample_cpu.cpp), the
+                                  take-all cases, on the CSC view of the part-4 graph.
+
+Usage:  python tests/golden/make_golden.py [part1] ... [part5]   (needs /root/reference)
 """
 import os
 import subprocess
@@ -332,9 +335,46 @@ def part4():
     subprocess.check_call([sys.executable, '-c', PART4], env=env)
 
 
+PART5 = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ['TS_SCRATCH'])
+import torch_sparse
+out_dir = os.environ['TS_OUT']
+G = np.load(os.path.join(out_dir, 'py4_graph.npz'))
+n = int(G['n'])
+# CSC view of the py4 graph: colptr over the columns, `row` holds the sources
+order = np.lexsort((G['row'], G['col']))
+row_csc, col_csc = G['row'][order], G['col'][order]
+colptr = np.zeros(n + 1, np.int64); np.cumsum(np.bincount(col_csc, minlength=n), out=colptr[1:])
+g = torch.Generator().manual_seed(5)
+k = 0
+for m in (1, 8, 40):
+    inp = torch.randperm(n, generator=g)[:m]
+    for fan in ([-1], [-1, -1], [-1, -1, -1], [1000, 1000]):
+        for directed in (True, False):
+            node, r, c, e = torch.ops.torch_sparse.neighbor_sample(torch.from_numpy(colptr), torch.from_numpy(row_csc), inp, fan, False, directed)
+            np.savez_compressed(os.path.join(out_dir, 'py5_neighbor_sample_%02d.npz' % k), colptr=colptr, row=row_csc,
+                                input_node=inp.numpy(), num_neighbors=np.array(fan), directed=directed,
+                                node=node.numpy(), out_row=r.numpy(), out_col=c.numpy(), out_edge=e.numpy())
+            k += 1
+print('part 5: %d neighbor_sample fixtures written' % k)
+"""
+
+
+def part5():
+    """py5_*.npz: the deterministic (take-all) cases of the reference's multi-hop neighbor_sample."""
+    srcs = SPMM_SRCS + ('neighbor_sample.cpp', 'cpu/neighbor_sample_cpu.cpp')
+    scratch, pkg = make_scratch([], srcs)
+    with open(os.path.join(pkg, '__init__.py'), 'w') as f:
+        f.write("import os, torch\n"
+                "torch.ops.load_library(os.path.join(os.path.dirname(__file__), '_ops_cpu.so'))\n")
+    env = dict(os.environ, TS_SCRATCH=scratch, TS_OUT=HERE, OMP_NUM_THREADS='1')
+    subprocess.check_call([sys.executable, '-c', PART5], env=env)
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree %s not present' % REF)
-    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4']
+    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4', 'part5']
     for name in todo:  # e.g. `make_golden.py part3` regenerates only the py3_* fixtures
-        {'part1': part1, 'part2': part2, 'part3': part3, 'part4': part4}[name]()
+        {'part1': part1, 'part2': part2, 'part3': part3, 'part4': part4, 'part5': part5}[name]()

@@ -42,3 +42,8 @@ for frac in (0.01, 0.25):
     ms, out = wall(lambda: r.saint_subgraph(idx, rp, row, c))
     print(json.dumps(dict(bench='saint_subgraph_cpu_reference', nodes=idx.numel(), ms=round(ms, 1),
                           edges=out[0].numel())), flush=True)
+for seeds, fan in ((1024, [25, 10]), (1024, [15, 10, 5]), (20_000, [10, 10])):
+    ms, out = wall(lambda: r.neighbor_sample(rp, c, perm[:seeds], fan, False, True))
+    print(json.dumps(dict(bench='neighbor_sample_cpu_reference', seeds=seeds, fanout=fan, ms=round(ms, 1),
+                          nodes=out[0].numel(), edges=out[3].numel(),
+                          medges_per_s=round(out[3].numel() / ms / 1e3, 3))), flush=True)

@@ -21,6 +21,7 @@ EXPECTED = {
     'relabel': 'torch_sparse::relabel(Tensor _0, Tensor _1) -> (Tensor _0, Tensor _1)',
     'relabel_one_hop': 'torch_sparse::relabel_one_hop(Tensor _0, Tensor _1, Tensor? _2, Tensor _3, bool _4) -> (Tensor _0, Tensor _1, Tensor? _2, Tensor _3)',
     'saint_subgraph': 'torch_sparse::saint_subgraph(Tensor _0, Tensor _1, Tensor _2, Tensor _3) -> (Tensor _0, Tensor _1, Tensor _2)',
+    'neighbor_sample': 'torch_sparse::neighbor_sample(Tensor _0, Tensor _1, Tensor _2, int[] _3, bool _4, bool _5) -> (Tensor _0, Tensor _1, Tensor _2, Tensor _3)',
 }
 
 

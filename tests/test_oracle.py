@@ -265,3 +265,36 @@ def test_np_oracle_matches_compiled_reference_samplers(seed):
         np.testing.assert_array_equal(g_rp, w_rp.numpy())
         np.testing.assert_array_equal(g_c, w_c.numpy())
         np.testing.assert_array_equal(g_idx, w_idx.numpy())
+
+
+def test_np_neighbor_sample_matches_fixtures_and_compiled_reference():
+    """Multi-hop take-all neighbour sampling: numpy restatement vs make_golden.py part 5 fixtures, and
+    vs the live compiled reference on random graphs."""
+    import glob
+    from oracle import np_oracle as npo
+    paths = sorted(glob.glob(os.path.join(GOLDEN, 'py5_neighbor_sample_*.npz')))
+    assert len(paths) == 24
+    for path in paths:
+        z = np.load(path)
+        got = npo.neighbor_sample_all(z['colptr'], z['row'], z['input_node'], len(z['num_neighbors']),
+                                      bool(z['directed']))
+        for g, key in zip(got, ('node', 'out_row', 'out_col', 'out_edge')):
+            np.testing.assert_array_equal(g, z[key], err_msg=os.path.basename(path) + ':' + key)
+    if not ref.available():
+        return
+    r = ref.ops()
+    rng = np.random.default_rng(3)
+    for trial in range(4):
+        n = 500
+        key = np.unique(rng.integers(0, n * n, 4000))
+        order = np.lexsort((key // n, key % n))
+        row, col = (key // n)[order], (key % n)[order]
+        colptr = np.zeros(n + 1, np.int64)
+        np.cumsum(np.bincount(col, minlength=n), out=colptr[1:])
+        inp = rng.permutation(n)[:rng.integers(1, 50)]
+        for hops in (1, 3):
+            for directed in (True, False):
+                want = r.neighbor_sample(torch.from_numpy(colptr), torch.from_numpy(row), torch.from_numpy(inp),
+                                         [-1] * hops, False, directed)
+                for g, w in zip(npo.neighbor_sample_all(colptr, row, inp, hops, directed), want):
+                    np.testing.assert_array_equal(g, w.numpy())

@@ -268,3 +268,73 @@ def test_bad_ids_raise(ts, graph):
         A.saint_subgraph(bad)
     with pytest.raises(IndexError):
         torch.ops.torch_sparse.relabel_one_hop(dev(G['rowptr']), dev(G['col']), None, bad, False)
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-hop neighbor_sample (PyG's NeighborLoader entry point)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('path', _fixtures('py5_neighbor_sample_'), ids=os.path.basename)
+def test_golden_neighbor_sample(path):
+    z = np.load(path)
+    got = torch.ops.torch_sparse.neighbor_sample(dev(z['colptr']), dev(z['row']), dev(z['input_node']),
+                                                 z['num_neighbors'].tolist(), False, bool(z['directed']))
+    for g, key in zip(got, ('node', 'out_row', 'out_col', 'out_edge')):
+        np.testing.assert_array_equal(host(g), z[key], err_msg=key)
+
+
+def _csc(big):
+    rowptr, col = big  # use the CSR arrays of the R-MAT graph as a CSC (colptr, row): same structure
+    return rowptr, col
+
+
+@pytest.mark.parametrize('directed', [True, False])
+def test_large_neighbor_sample_take_all_matches_oracle(big, directed):
+    colptr, row = _csc(big)
+    n = colptr.size - 1
+    inp = np.random.default_rng(1).permutation(n)[:200]
+    got = torch.ops.torch_sparse.neighbor_sample(dev(colptr), dev(row), dev(inp), [-1, -1], False, directed)
+    want = npo.neighbor_sample_all(colptr, row, inp, 2, directed)
+    for g, w, key in zip(got, want, ('node', 'row', 'col', 'edge')):
+        np.testing.assert_array_equal(host(g), w, err_msg=key)
+
+
+@pytest.mark.parametrize('replace', [False, True])
+def test_neighbor_sample_properties(big, replace):
+    colptr, row = _csc(big)
+    n = colptr.size - 1
+    inp = np.random.default_rng(2).permutation(n)[:1024]
+    fan = [10, 5, 3]
+    torch.manual_seed(7)
+    node, r, c, e = (host(t) for t in torch.ops.torch_sparse.neighbor_sample(dev(colptr), dev(row), dev(inp), fan,
+                                                                             replace, True))
+    # seeds first, every node once, edges consistent with the source arrays
+    np.testing.assert_array_equal(node[:inp.size], inp)
+    assert np.unique(node).size == node.size
+    np.testing.assert_array_equal(node[r], row[e])                       # source of the sampled entry
+    assert np.all((e >= colptr[node[c]]) & (e < colptr[node[c] + 1]))      # entry lies in the target's column
+    assert r.max() < node.size and c.max() < node.size
+    # hop structure: targets of hop l are exactly the nodes discovered in hop l-1, in order
+    deg = colptr[1:] - colptr[:-1]
+    begin, end, off = 0, inp.size, 0
+    for k in fan:
+        d = deg[node[begin:end]]
+        cnt = np.where(d > 0, k, 0) if replace else np.minimum(d, k)
+        T = int(cnt.sum())
+        np.testing.assert_array_equal(c[off:off + T], np.repeat(np.arange(begin, end), cnt))
+        if not replace:
+            assert np.unique(e[off:off + T]).size == T
+        new_end = int(max(r[off:off + T].max(initial=end - 1) + 1, end))
+        # first-occurrence numbering: ids >= end appear in increasing order of first appearance
+        fresh = r[off:off + T][r[off:off + T] >= end]
+        first = fresh[np.sort(np.unique(fresh, return_index=True)[1])]
+        np.testing.assert_array_equal(first, np.arange(end, new_end))
+        begin, end, off = end, new_end, off + T
+    assert off == e.size and end == node.size
+    # reproducible, and undirected mode returns the induced sub-graph of the same node set
+    torch.manual_seed(7)
+    node2, r2, c2, e2 = torch.ops.torch_sparse.neighbor_sample(dev(colptr), dev(row), dev(inp), fan, replace, False)
+    np.testing.assert_array_equal(host(node2), node)
+    i, v, pos = npo.saint_subgraph(node, colptr, row)
+    np.testing.assert_array_equal(host(r2), v)
+    np.testing.assert_array_equal(host(c2), i)
+    np.testing.assert_array_equal(host(e2), pos)
