@@ -9,6 +9,8 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
+from .segment import segment_reduce
+
 _OPS = ('add', 'sum', 'mean', 'min', 'max')
 
 
@@ -42,7 +44,7 @@ def coalesce(index: Tensor, value: Optional[Tensor], m: int, n: int,
     row, col, perm, seg_ptr, n_u = sorted_unique(index[0], index[1], m, n)
     if value is not None:
         if seg_ptr is not None:
-            value = torch.ops.tsamd.segment_reduce(value, perm, seg_ptr, n_u, op)
+            value = segment_reduce(value, perm, seg_ptr, n_u, op)  # differentiable, like segment_csr
         elif perm is not None:
             value = value[perm]
     return torch.stack([row, col], dim=0), value

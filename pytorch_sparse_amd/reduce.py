@@ -4,12 +4,13 @@ SURVEY.md section 8f, rank 2: the step either side of SpMM in GCN-style normalis
 (``deg = adj.sum(dim=1)``).  Row reductions are a segmented reduction over ``rowptr``; column
 reductions read the values through ``csr2csc`` and segment over ``colptr`` -- both through
 ``tsamd::segment_reduce`` (the reference uses torch_scatter's segment_csr / scatter).  Empty rows /
-columns give 0.  Results are not differentiable w.r.t. the sparse values.
+columns give 0.  Differentiable w.r.t. the sparse values like the reference (segment.py).
 """
 from typing import Optional
 
 import torch
 
+from .segment import segment_reduce
 from .tensor import SparseTensor
 
 
@@ -42,10 +43,9 @@ def reduction(src: SparseTensor, dim: Optional[int] = None, reduce: str = 'sum')
         if reduce in ('sum', 'add'):
             return (st.rowcount() if dim == 1 else st.colcount()).to(src.dtype())
         return torch.ones(src.size(dim == 0), dtype=src.dtype(), device=src.device())
-    value = value.detach()
     if dim == 1:
-        return torch.ops.tsamd.segment_reduce(value, None, st.rowptr(), src.size(0), reduce)
-    return torch.ops.tsamd.segment_reduce(value, st.csr2csc(), st.colptr(), src.size(1), reduce)
+        return segment_reduce(value, None, st.rowptr(), src.size(0), reduce)
+    return segment_reduce(value, st.csr2csc(), st.colptr(), src.size(1), reduce)
 
 
 def sum(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:

@@ -297,7 +297,8 @@ class SparseStorage(object):
         n = nnz - dup
         value = self._value
         if value is not None:
-            value = torch.ops.tsamd.segment_reduce(value, None, seg_ptr, n, reduce)
+            from .segment import segment_reduce
+            value = segment_reduce(value, None, seg_ptr, n, reduce)
         return SparseStorage(row=row_u[:n].clone(), col=col_u[:n].clone(), value=value,
                              sparse_sizes=self._sparse_sizes, is_sorted=True, trust_data=True)
 

@@ -387,3 +387,63 @@ def test_cpu_built_tensor_is_sorted_on_the_gpu(ts, dev):
     assert torch.equal((G @ torch.eye(3, device=dev)).cpu(), torch.tensor([[4., 0, 2], [3, 0, 0], [5, 1, 0]]))
     back = G.cpu()                       # sorted data may live on the CPU again
     assert back.storage.col().tolist() == [0, 2, 0, 0, 1]
+
+
+# ---------------------------------------------------------------------------------------------
+# reductions and coalesce are differentiable w.r.t. the sparse values (torch_scatter's segment_csr
+# is, in the reference): compare with torch's own scatter autograd
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'min', 'max'])
+@pytest.mark.parametrize('dim', [0, 1])
+def test_reduction_gradients(reduce, dim):
+    import pytorch_sparse_amd as ts
+    g = torch.Generator().manual_seed(3)
+    m, n, nnz = 300, 200, 4000
+    key = torch.randperm(m * n, generator=g)[:nnz].sort().values
+    row, col = (key // n).cuda(), (key % n).cuda()
+    for shape in ((nnz, ), (nnz, 3)):
+        v0 = torch.randn(shape, generator=g, dtype=torch.float64).cuda()  # no ties
+        value = v0.clone().requires_grad_()
+        A = ts.SparseTensor(row=row, col=col, value=value, sparse_sizes=(m, n), is_sorted=True)
+        out = getattr(A, reduce)(dim=dim)
+        gout = torch.randn(out.shape, generator=g, dtype=torch.float64).cuda()
+        out.backward(gout)
+        # reference: torch.scatter_reduce along the kept index
+        ref_v = v0.clone().requires_grad_()
+        index = row if dim == 1 else col
+        size = m if dim == 1 else n
+        idx = index.view((-1, ) + (1, ) * (ref_v.dim() - 1)).expand_as(ref_v)
+        red = {'sum': 'sum', 'mean': 'mean', 'min': 'amin', 'max': 'amax'}[reduce]
+        want = torch.zeros((size, ) + tuple(shape[1:]), dtype=torch.float64, device='cuda').scatter_reduce(
+            0, idx, ref_v, red, include_self=False)
+        want.backward(gout)
+        torch.testing.assert_close(out.detach(), want.detach(), rtol=1e-12, atol=1e-12)
+        torch.testing.assert_close(value.grad, ref_v.grad, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('op', ['add', 'mean', 'min', 'max'])
+def test_coalesce_gradients(op):
+    import pytorch_sparse_amd as ts
+    g = torch.Generator().manual_seed(4)
+    m, n, nnz = 40, 30, 3000  # many duplicates
+    index = torch.stack([torch.randint(0, m, (nnz, ), generator=g), torch.randint(0, n, (nnz, ), generator=g)]).cuda()
+    v0 = torch.randn(nnz, 2, generator=g, dtype=torch.float64).cuda()
+    value = v0.clone().requires_grad_()
+    oi, ov = ts.coalesce(index, value, m, n, op=op)
+    gout = torch.randn(ov.shape, generator=g, dtype=torch.float64).cuda()
+    ov.backward(gout)
+    ref_v = v0.clone().requires_grad_()
+    key = index[0] * n + index[1]
+    uniq, inv = key.unique(return_inverse=True)
+    red = {'add': 'sum', 'mean': 'mean', 'min': 'amin', 'max': 'amax'}[op]
+    want = torch.zeros((uniq.numel(), 2), dtype=torch.float64, device='cuda').scatter_reduce(
+        0, inv.view(-1, 1).expand(-1, 2), ref_v, red, include_self=False)
+    want.backward(gout)
+    assert torch.equal(oi[0] * n + oi[1], uniq)
+    torch.testing.assert_close(ov.detach(), want.detach(), rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(value.grad, ref_v.grad, rtol=1e-12, atol=1e-12)
+    # SparseTensor.coalesce and sparse + sparse carry the gradient too
+    A = ts.SparseTensor(row=index[0], col=index[1], value=value, sparse_sizes=(m, n))
+    value.grad = None
+    A.coalesce(reduce=op if op != 'add' else 'sum').storage.value().sum().backward()
+    assert value.grad is not None and float(value.grad.abs().sum()) > 0

@@ -279,7 +279,7 @@ def test_values_stay_differentiable(ts):
     idx = torch.randint(0, 500, (300, ), device=DEV)
     outs = [A.index_select(0, idx), A.index_select(1, idx[idx < 400]), A.narrow(1, 10, 200),
             A.masked_select(0, torch.rand(500, device=DEV) < 0.5), ts.cat([A, A], 1), A.fill_diag(2.0),
-            ts.mul(A, A)]  # (sparse + sparse goes through coalesce, whose reduction is not differentiable)
+            ts.mul(A, A), ts.add(A, A)]
     total = sum(o.storage.value().sum() for o in outs)
     total.backward()
     assert value.grad is not None and bool(torch.isfinite(value.grad).all())
