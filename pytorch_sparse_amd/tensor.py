@@ -166,6 +166,18 @@ class SparseTensor(object):
     def avg_col_length(self) -> float:
         return self.nnz() / self.sparse_size(1)
 
+    def bandwidth(self) -> int:
+        row, col, _ = self.coo()
+        return int((row - col).abs_().max())
+
+    def avg_bandwidth(self) -> float:
+        row, col, _ = self.coo()
+        return float((row - col).abs_().to(torch.float).mean())
+
+    def bandwidth_proportion(self, bandwidth: int) -> float:
+        row, col, _ = self.coo()
+        return int(((row - col).abs_() <= bandwidth).sum()) / self.nnz()
+
     def is_quadratic(self) -> bool:
         return self.sparse_size(0) == self.sparse_size(1)
 
@@ -393,10 +405,8 @@ class SparseTensor(object):
         value = ones() if value is None else value.detach().cpu()
         return scipy.sparse.csc_matrix((value, row.cpu(), colptr.cpu()), self.sizes())
 
-    # ---- out of scope --------------------------------------------------------------------------
-    def __getitem__(self, index: Any):
-        raise NotImplementedError('SparseTensor indexing/slicing is outside the accelerated hot path '
-                                  '(SURVEY.md section 8); use torch_sparse for it')
+    # __getitem__, narrow, index_select, ... are attached by select.py / cat.py / diag.py / mul.py /
+    # reduce.py / sample.py, like the reference attaches its method modules
 
     def __repr__(self) -> str:
         row, col, value = self.coo()

@@ -284,3 +284,24 @@ def test_values_stay_differentiable(ts):
     total.backward()
     assert value.grad is not None and bool(torch.isfinite(value.grad).all())
     assert float(value.grad.abs().sum()) > 0
+
+
+def test_bandwidth_and_rcm(ts):
+    import scipy.sparse as sp
+    A, S, _ = _random(ts, 3_000, 3_000, 30_000, 12)
+    coo = S.tocoo()
+    d = np.abs(coo.row.astype(np.int64) - coo.col)
+    assert A.bandwidth() == int(d.max())
+    assert abs(A.avg_bandwidth() - float(d.mean())) < 1e-3 * d.mean()
+    assert abs(A.bandwidth_proportion(100) - float((d <= 100).mean())) < 1e-12
+    out, perm = ts.reverse_cuthill_mckee(A)
+    sym = (S + S.T).tocsr()
+    want_perm = sp.csgraph.reverse_cuthill_mckee(sym, symmetric_mode=True)
+    np.testing.assert_array_equal(perm.cpu().numpy(), want_perm)
+    want = sym[want_perm][:, want_perm].tocsr()
+    want.sort_indices()
+    rowptr, col, value = out.csr()
+    np.testing.assert_array_equal(rowptr.cpu().numpy(), want.indptr)
+    np.testing.assert_array_equal(col.cpu().numpy(), want.indices)
+    np.testing.assert_array_equal(value.cpu().numpy(), want.data)
+    assert out.bandwidth() < A.to_symmetric().bandwidth()
