@@ -35,6 +35,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace tsamd {
 namespace {
@@ -518,11 +519,17 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
     val[0] = head_val[(plane + q) * K + k];
     arg[0] = kNoArg;
     if constexpr (RED != RED_ADD) arg[0] = ws.head_arg[(plane + q) * K + k];
+    // A hub row is cut into hundreds of pieces; folding their fp32 partial sums in fp64 keeps the
+    // error of a long row at that of one piece (costs nothing: a few records per cut row).
+    constexpr bool kWideFold = RED == RED_ADD && std::is_same<A, float>::value;
+    double wide = kWideFold ? (double)val[0] : 0.0;
 #pragma unroll 4
     for (int64_t i = 0; i < run; ++i) {
       const uint64_t o = (plane + (q - 1 - i)) * K + k;
       const A v = tail_val[o];
-      if constexpr (RED == RED_ADD) {
+      if constexpr (kWideFold) {
+        wide += (double)v;
+      } else if constexpr (RED == RED_ADD) {
         val[0] += v;
       } else {
         const int64_t a = ws.tail_arg[o];
@@ -533,6 +540,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
         }
       }
     }
+    if constexpr (kWideFold) val[0] = (A)wide;
     const uint64_t o = ((uint64_t)b * M + R) * K + k;
     write_row<T, 1, RED>(out + o, arg_out + o, val, arg, deg, mean, E);
   }
