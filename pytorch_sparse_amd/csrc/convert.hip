@@ -2,6 +2,7 @@
 // Replaces ind2ptr_cuda / ptr2ind_cuda (csrc/cuda/convert_cuda.cu:9-67) and
 // ind2ptr_cpu / ptr2ind_cpu (csrc/cpu/convert_cpu.cpp:7-57) of the reference.
 #include "common.h"
+#include "expand.h"
 
 namespace tsamd {
 namespace {
@@ -17,26 +18,26 @@ __global__ void ind2ptr_kernel(const int64_t *__restrict__ ind, int64_t *__restr
   for (int64_t i = lo; i <= hi; ++i) out[i] = t;
 }
 
-constexpr int kRowsPerBlock = 256;
-
-// A workgroup owns 256 consecutive rows: their pointers go to LDS, then the
-// block streams over the rows' edge range with coalesced stores, each thread
-// locating its edge's row by a binary search in LDS (hub rows cost nothing extra).
+// Balanced by output entries (expand.h): a tile of 2048 consecutive entries per workgroup, the rows
+// that intersect it staged in LDS, one LDS binary search per entry, coalesced stores.  Hub rows are
+// spread over many workgroups (a row-per-workgroup mapping took 65 ms on a 30 M-entry row).
 __global__ __launch_bounds__(256) void ptr2ind_kernel(const int64_t *__restrict__ ptr,
-                                                      int64_t *__restrict__ out, int64_t M) {
-  __shared__ int64_t sp[kRowsPerBlock + 1];
-  const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
-  const int nrows = (int)((M - r0) < kRowsPerBlock ? (M - r0) : kRowsPerBlock);
-  for (int i = threadIdx.x; i <= nrows; i += blockDim.x) sp[i] = ptr[r0 + i];
-  __syncthreads();
-  const int64_t e0 = sp[0], e1 = sp[nrows];
-  for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-    int lo = 0, hi = nrows;  // last i with sp[i] <= e
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (sp[mid] <= e) lo = mid; else hi = mid;
-    }
-    out[e] = r0 + lo;
+                                                      int64_t *__restrict__ out, int64_t M, int64_t E) {
+  __shared__ int64_t sp[kExpandTile];
+  __shared__ int64_t span[2];
+  const int64_t e0 = (int64_t)blockIdx.x * kExpandTile;
+  const int64_t e1 = e0 + kExpandTile < E ? e0 + kExpandTile : E;
+  int64_t lo, hi;
+  tile_span(ptr, M, e0, e1, span, &lo, &hi);
+  const int64_t S = hi - lo + 1;
+  if (S <= kExpandTile) {
+    for (int i = threadIdx.x; i < (int)S; i += blockDim.x) sp[i] = ptr[lo + i];
+    __syncthreads();
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x)
+      out[e] = lo + segment_of_lds(sp, (int)S, e);
+  } else {  // more rows than entries in this tile (long runs of empty rows): search in place
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x)
+      out[e] = lo + segment_of(ptr + lo, S, e);
   }
 }
 
@@ -65,8 +66,8 @@ extern "C" int tsamd_ptr2ind(const int64_t *ptr, int64_t M, int64_t E, int64_t *
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || E < 0 || !ptr || (E > 0 && !out)) return TSAMD_ERR_INVALID;
   if (E == 0 || M == 0) return TSAMD_OK;
-  hipLaunchKernelGGL(ptr2ind_kernel, dim3((unsigned int)ceil_div(M, kRowsPerBlock)), dim3(256), 0,
-                     stream, ptr, out, M);
+  hipLaunchKernelGGL(ptr2ind_kernel, dim3((unsigned int)ceil_div(E, kExpandTile)), dim3(256), 0,
+                     stream, ptr, out, M, E);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }

@@ -15,6 +15,7 @@
 //             (row, col) and the source positions
 // Pure index work, HBM-bound; order preserving, so sorted input gives sorted output.
 #include "common.h"
+#include "expand.h"
 #include "scan.h"
 
 namespace tsamd {
@@ -37,35 +38,44 @@ __global__ void select_count_kernel(const int64_t *__restrict__ ptr, int64_t S,
   cnt[i] = ptr[j + 1] - ptr[j];
 }
 
-constexpr int kSegPerBlock = 256;
-
-// A workgroup owns 256 consecutive OUTPUT segments: their output offsets and source starts go
-// to LDS, then the block streams over its output range with coalesced stores; each thread
-// finds its segment by a binary search in LDS (8 steps), so hub segments cost nothing extra.
+// Balanced by output entries (expand.h): a tile of 2048 consecutive output entries per workgroup;
+// the output offsets and source starts of the segments that intersect it go to LDS, every thread
+// finds the segment of its entries by an LDS binary search; coalesced stores.
 __global__ __launch_bounds__(256) void select_fill_kernel(
     const int64_t *__restrict__ ptr, int64_t S, const int64_t *__restrict__ ind,
-    const int64_t *__restrict__ idx, int64_t K, const int64_t *__restrict__ out_ptr,
+    const int64_t *__restrict__ idx, int64_t K, const int64_t *__restrict__ out_ptr, int64_t total,
     int64_t *__restrict__ seg_out, int64_t *__restrict__ ind_out, int64_t *__restrict__ pos_out) {
-  __shared__ int64_t so[kSegPerBlock + 1];
-  __shared__ int64_t ss[kSegPerBlock];
-  const int64_t s0 = (int64_t)blockIdx.x * kSegPerBlock;
-  const int nseg = (int)((K - s0) < kSegPerBlock ? (K - s0) : kSegPerBlock);
-  for (int i = threadIdx.x; i <= nseg; i += blockDim.x) so[i] = out_ptr[s0 + i];
-  for (int i = threadIdx.x; i < nseg; i += blockDim.x) {
-    int64_t j = idx[s0 + i];
-    if (j < 0) j += S;
-    ss[i] = (j >= 0 && j < S) ? ptr[j] : 0;
-  }
-  __syncthreads();
-  const int64_t e0 = so[0], e1 = so[nseg];
-  for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-    int lo = 0, hi = nseg;  // last i with so[i] <= e
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (so[mid] <= e) lo = mid; else hi = mid;
+  __shared__ int64_t so[kExpandTile];
+  __shared__ int64_t ss[kExpandTile];
+  __shared__ int64_t span[2];
+  const int64_t e0 = (int64_t)blockIdx.x * kExpandTile;
+  const int64_t e1 = e0 + kExpandTile < total ? e0 + kExpandTile : total;
+  int64_t lo, hi;
+  tile_span(out_ptr, K, e0, e1, span, &lo, &hi);
+  const int64_t n = hi - lo + 1;
+  const bool staged = n <= kExpandTile;
+  if (staged) {
+    for (int i = threadIdx.x; i < (int)n; i += blockDim.x) {
+      so[i] = out_ptr[lo + i];
+      int64_t j = idx[lo + i];
+      if (j < 0) j += S;
+      ss[i] = (j >= 0 && j < S) ? ptr[j] : 0;
     }
-    const int64_t src = ss[lo] + (e - so[lo]);
-    if (seg_out) seg_out[e] = s0 + lo;
+    __syncthreads();
+  }
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    int64_t seg, src;
+    if (staged) {
+      const int i = segment_of_lds(so, (int)n, e);
+      seg = lo + i;
+      src = ss[i] + (e - so[i]);
+    } else {  // long runs of empty picks: search the global offsets in place
+      seg = lo + segment_of(out_ptr + lo, n, e);
+      int64_t j = idx[seg];
+      if (j < 0) j += S;
+      src = ((j >= 0 && j < S) ? ptr[j] : 0) + (e - out_ptr[seg]);
+    }
+    if (seg_out) seg_out[e] = seg;
     if (ind_out) ind_out[e] = ind[src];
     if (pos_out) pos_out[e] = src;
   }
@@ -226,8 +236,8 @@ extern "C" int tsamd_select_fill(const int64_t *ptr, int64_t S, const int64_t *i
   if (S < 0 || K < 0 || total < 0) return TSAMD_ERR_INVALID;
   if (K == 0 || total == 0) return TSAMD_OK;
   if (!ptr || !idx || !out_ptr || (ind_out && !ind)) return TSAMD_ERR_INVALID;
-  hipLaunchKernelGGL(select_fill_kernel, dim3((unsigned int)ceil_div(K, kSegPerBlock)), dim3(256), 0,
-                     stream, ptr, S, ind, idx, K, out_ptr, seg_out, ind_out, pos_out);
+  hipLaunchKernelGGL(select_fill_kernel, dim3((unsigned int)ceil_div(total, kExpandTile)), dim3(256), 0,
+                     stream, ptr, S, ind, idx, K, out_ptr, total, seg_out, ind_out, pos_out);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }
