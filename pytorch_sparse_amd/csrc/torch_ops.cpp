@@ -360,21 +360,53 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> coalesce_index(Tensor row, Tensor col
 }
 
 // out[j] = REDUCE_{i in [seg_ptr[j], seg_ptr[j+1])} value[perm ? perm[i] : i]   (dim 0)
-Tensor segment_reduce(Tensor value, OptTensor perm, Tensor seg_ptr, int64_t nseg,
-                      std::string reduce) {
+// balanced = false: one thread per (segment, feature) -- right for the short runs of duplicates
+//   that coalesce reduces.
+// balanced = true: the segments are the rows / columns of a matrix (hubs with 1e5+ entries on
+//   power-law graphs, where one thread per segment took 13-37 ms for 40 M entries): the reduction
+//   is A * 1, so it runs on the merge-path SpMM kernel (entry-balanced, deterministic, fp64 fold of
+//   cut rows) with a one-row matrix of ones; every entry "gathers" that row through an all-zero
+//   column array.  Costs 8 B per entry of extra reads for an order of magnitude in time.
+Tensor segment_reduce(Tensor value, OptTensor perm, Tensor seg_ptr, int64_t nseg, std::string reduce,
+                      bool balanced) {
   check_gpu(value, "value");
   check_index(seg_ptr, "seg_ptr");
   if (perm.has_value()) check_index(perm.value(), "perm");
   TORCH_CHECK(value.dim() >= 1, "value must have at least one dimension");
+  TORCH_CHECK(seg_ptr.numel() >= nseg + 1, "seg_ptr shorter than nseg + 1");
   c10::hip::HIPGuard guard(value.get_device());
   value = value.contiguous();
   seg_ptr = seg_ptr.contiguous();
   auto sizes = value.sizes().vec();
-  const int64_t D = value.size(0) > 0 ? value.numel() / value.size(0) : 1;
+  const int64_t E = value.size(0);
+  const int64_t D = E > 0 ? value.numel() / E : 1;
   sizes[0] = nseg;
+  const int red = reduce_code(reduce);
+  if (balanced && E >= 32768 && D >= 1 && D <= 8 && nseg > 0) {
+    Tensor v = perm.has_value() ? value.index_select(0, perm.value()) : value;
+    Tensor v2 = v.reshape({E, D});
+    Tensor rp = seg_ptr.narrow(0, 0, nseg + 1);
+    Tensor zero_col = torch::zeros({E}, seg_ptr.options());
+    Tensor ones = torch::ones({1, 1}, value.options().requires_grad(false));
+    // integer means: torch_scatter floors, the SpMM kernel truncates like the reference's spmm ->
+    // take the sum here and floor-divide below
+    const bool int_mean = red == TSAMD_MEAN && !value.is_floating_point();
+    const std::string op = int_mean ? "sum" : reduce;
+    std::vector<Tensor> cols;
+    for (int64_t d = 0; d < D; ++d) {
+      OptTensor vd = D == 1 ? v2.reshape({E}) : v2.select(1, d).contiguous();
+      cols.push_back(std::get<0>(spmm_fw(rp, zero_col, vd, ones, op)));
+    }
+    Tensor out = D == 1 ? cols[0] : torch::cat(cols, 1);
+    if (int_mean) {
+      Tensor cnt = (rp.narrow(0, 1, nseg) - rp.narrow(0, 0, nseg)).clamp_min(1).to(out.scalar_type());
+      out = torch::div(out, cnt.unsqueeze(1), "floor");
+    }
+    return out.reshape(sizes);
+  }
   Tensor out = torch::empty(sizes, value.options().requires_grad(false));
   Tensor p = perm.has_value() ? perm.value().contiguous() : Tensor();
-  check_status(tsamd_segment_reduce(dtype_code(value), reduce_code(reduce), value.data_ptr(),
+  check_status(tsamd_segment_reduce(dtype_code(value), red, value.data_ptr(),
                                     perm.has_value() ? p.data_ptr<int64_t>() : nullptr,
                                     seg_ptr.data_ptr<int64_t>(), nseg, D, out.data_ptr(),
                                     current_stream(value)),

@@ -44,8 +44,8 @@ def reduction(src: SparseTensor, dim: Optional[int] = None, reduce: str = 'sum')
             return (st.rowcount() if dim == 1 else st.colcount()).to(src.dtype())
         return torch.ones(src.size(dim == 0), dtype=src.dtype(), device=src.device())
     if dim == 1:
-        return segment_reduce(value, None, st.rowptr(), src.size(0), reduce)
-    return segment_reduce(value, st.csr2csc(), st.colptr(), src.size(1), reduce)
+        return segment_reduce(value, None, st.rowptr(), src.size(0), reduce, balanced=True)
+    return segment_reduce(value, st.csr2csc(), st.colptr(), src.size(1), reduce, balanced=True)
 
 
 def sum(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:

@@ -17,9 +17,10 @@ def _expand(t: Tensor, like: Tensor) -> Tensor:
 
 class _SegmentReduce(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, value: Tensor, perm: Optional[Tensor], seg_ptr: Tensor, nseg: int, reduce: str):
-        out = torch.ops.tsamd.segment_reduce(value.detach(), perm, seg_ptr, nseg, reduce)
-        ctx.reduce, ctx.nseg = reduce, nseg
+    def forward(ctx, value: Tensor, perm: Optional[Tensor], seg_ptr: Tensor, nseg: int, reduce: str,
+                balanced: bool):
+        out = torch.ops.tsamd.segment_reduce(value.detach(), perm, seg_ptr, nseg, reduce, balanced)
+        ctx.reduce, ctx.nseg, ctx.balanced = reduce, nseg, balanced
         ctx.has_perm = perm is not None
         saved = [seg_ptr, value if reduce in ('min', 'max') else value.new_empty(0),
                  out if reduce in ('min', 'max') else value.new_empty(0)]
@@ -47,7 +48,7 @@ class _SegmentReduce(torch.autograd.Function):
             hit = v == out.index_select(0, seg_id)
             pos = _expand(torch.arange(E, device=v.device), v).expand_as(v)
             cand = torch.where(hit, pos, torch.full_like(pos, E)).contiguous()
-            arg = torch.ops.tsamd.segment_reduce(cand, None, seg_ptr, nseg, 'min')  # first hit
+            arg = torch.ops.tsamd.segment_reduce(cand, None, seg_ptr, nseg, 'min', ctx.balanced)  # first hit
             empty = _expand(ptr[1:] == ptr[:-1], arg)
             arg = torch.where(empty, torch.full_like(arg, E), arg)  # empty segments feed nobody
             g = grad_out.new_zeros((E + 1, ) + tuple(grad_out.shape[1:]))
@@ -55,11 +56,13 @@ class _SegmentReduce(torch.autograd.Function):
             g = g[:E]
         if perm is not None:  # entry i of the segmented order is value[perm[i]]
             g = torch.zeros_like(g).index_copy_(0, perm, g)
-        return g, None, None, None, None
+        return g, None, None, None, None, None
 
 
-def segment_reduce(value: Tensor, perm: Optional[Tensor], seg_ptr: Tensor, nseg: int, reduce: str) -> Tensor:
-    """REDUCE over value[perm][seg_ptr[j]:seg_ptr[j+1]] for j < nseg; differentiable w.r.t. value."""
+def segment_reduce(value: Tensor, perm: Optional[Tensor], seg_ptr: Tensor, nseg: int, reduce: str,
+                   balanced: bool = False) -> Tensor:
+    """REDUCE over value[perm][seg_ptr[j]:seg_ptr[j+1]] for j < nseg; differentiable w.r.t. value.
+    balanced=True when the segments are matrix rows / columns (possibly hubs): entry-balanced path."""
     if value.requires_grad and torch.is_grad_enabled():
-        return _SegmentReduce.apply(value, perm, seg_ptr, nseg, reduce)
-    return torch.ops.tsamd.segment_reduce(value, perm, seg_ptr, nseg, reduce)
+        return _SegmentReduce.apply(value, perm, seg_ptr, nseg, reduce, balanced)
+    return torch.ops.tsamd.segment_reduce(value, perm, seg_ptr, nseg, reduce, balanced)

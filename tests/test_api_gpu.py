@@ -447,3 +447,57 @@ def test_coalesce_gradients(op):
     value.grad = None
     A.coalesce(reduce=op if op != 'add' else 'sum').storage.value().sum().backward()
     assert value.grad is not None and float(value.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64, torch.bfloat16, torch.int64, torch.int32])
+def test_reductions_hub_rows_balanced_path(ts, dev, dtype):
+    """Row / column reductions of a power-law matrix run on the entry-balanced path (A * 1 on the SpMM
+    kernel).  Small-integer values make every sum exact in every dtype, so the result must equal
+    both torch.scatter_reduce and the thread-per-segment kernel bit for bit (means: floor for ints)."""
+    from pytorch_sparse_amd import synth
+    rp, c = synth.rmat_csr(16, 20, seed=1)
+    n, E = rp.numel() - 1, c.numel()
+    assert E > 32768 and int((rp[1:] - rp[:-1]).max()) > 2000  # hubs present, balanced path taken
+    g = torch.Generator().manual_seed(0)
+    for D in (1, 3):
+        shape = (E, ) if D == 1 else (E, D)
+        v64 = torch.randint(-8, 9, shape, generator=g)
+        value = v64.to(dtype).to(dev)
+        A = ts.SparseTensor(rowptr=rp.to(dev), col=c.to(dev), value=value, sparse_sizes=(n, n), is_sorted=True)
+        st = A.storage
+        for dim in (1, 0):
+            ptr = st.rowptr() if dim == 1 else st.colptr()
+            perm = None if dim == 1 else st.csr2csc()
+            index = (st.row() if dim == 1 else st.col())
+            idx = index.view((-1, ) + (1, ) * (D > 1)).expand(shape)
+            cnt = (ptr[1:] - ptr[:-1])
+            for reduce in ('sum', 'mean', 'min', 'max'):
+                got = getattr(A, reduce)(dim=dim)
+                slow = torch.ops.tsamd.segment_reduce(value, perm, ptr, n, reduce, False)
+                red = {'sum': 'sum', 'mean': 'sum', 'min': 'amin', 'max': 'amax'}[reduce]
+                ref = torch.zeros((n, ) + shape[1:], dtype=torch.float64, device=dev).scatter_reduce(
+                    0, idx, v64.to(dev).double(), red, include_self=False)
+                if reduce == 'mean':
+                    c_ = cnt.clamp(min=1).view((-1, ) + (1, ) * (D > 1)).double()
+                    ref = torch.floor(ref / c_) if not dtype.is_floating_point else ref / c_
+                if reduce == 'mean' and dtype.is_floating_point:
+                    tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
+                    assert torch.allclose(got.double(), ref, rtol=tol, atol=tol), (dim, reduce, D)
+                    assert torch.allclose(got.double(), slow.double(), rtol=tol, atol=tol)
+                else:
+                    if dtype == torch.bfloat16 and reduce == 'sum':  # hub sums exceed bf16's 8 bits
+                        assert torch.allclose(got.double(), ref, rtol=1e-2, atol=1.0)
+                        continue
+                    assert torch.equal(got.double(), ref), (dim, reduce, D, dtype)
+                    assert torch.equal(got, slow), (dim, reduce, D, dtype)
+    # gradients flow through the balanced path too
+    val = torch.randn(E, generator=g, dtype=torch.float64).to(dev).requires_grad_()
+    A = ts.SparseTensor(rowptr=rp.to(dev), col=c.to(dev), value=val, sparse_sizes=(n, n), is_sorted=True)
+    gout = torch.randn(n, generator=g, dtype=torch.float64).to(dev)
+    for reduce, red in (('sum', 'sum'), ('max', 'amax')):
+        val.grad = None
+        getattr(A, reduce)(dim=1).backward(gout)
+        ref_v = val.detach().clone().requires_grad_()
+        torch.zeros(n, dtype=torch.float64, device=dev).scatter_reduce(0, A.storage.row(), ref_v, red,
+                                                                         include_self=False).backward(gout)
+        torch.testing.assert_close(val.grad, ref_v.grad, rtol=1e-12, atol=1e-12)
