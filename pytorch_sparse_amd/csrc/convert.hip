@@ -7,15 +7,33 @@
 namespace tsamd {
 namespace {
 
-// Thread t in [0, E] owns the boundary between ind[t-1] and ind[t] and fills
-// every row pointer that falls into it (empty rows make the run longer than 1).
+// Thread t in [0, E] owns the boundary between ind[t-1] and ind[t] and fills every row pointer
+// that falls into it (empty rows make the run longer than 1).  Runs of more than kLongRun empty rows
+// are left at the -1 the output was pre-set to and resolved by ind2ptr_long_kernel, one thread per
+// row pointer with a binary search: a single thread filling a 32 M-row gap took 840 ms.
+constexpr int64_t kLongRun = 1024;
+
 __global__ void ind2ptr_kernel(const int64_t *__restrict__ ind, int64_t *__restrict__ out,
                                int64_t M, int64_t E) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t > E) return;
   const int64_t lo = t == 0 ? 0 : ind[t - 1] + 1;
   const int64_t hi = t == E ? M : ind[t];
+  if (hi - lo >= kLongRun) return;
   for (int64_t i = lo; i <= hi; ++i) out[i] = t;
+}
+
+// out[i] = number of entries with ind < i  (first e with ind[e] >= i), only where still unset
+__global__ void ind2ptr_long_kernel(const int64_t *__restrict__ ind, int64_t *__restrict__ out,
+                                    int64_t M, int64_t E) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > M || out[i] >= 0) return;
+  int64_t lo = 0, hi = E;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (ind[mid] < i) lo = mid + 1; else hi = mid;
+  }
+  out[i] = lo;
 }
 
 // Balanced by output entries (expand.h): a tile of 2048 consecutive entries per workgroup, the rows
@@ -55,8 +73,12 @@ extern "C" int tsamd_ind2ptr(const int64_t *ind, int64_t M, int64_t E, int64_t *
     return TSAMD_OK;
   }
   const int64_t n = E + 1;
+  TSAMD_HIP_TRY(hipMemsetAsync(out, 0xff, sizeof(int64_t) * (size_t)(M + 1), stream));  // -1 = unset
   hipLaunchKernelGGL(ind2ptr_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
                      ind, out, M, E);
+  TSAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ind2ptr_long_kernel, dim3((unsigned int)ceil_div(M + 1, 256)), dim3(256), 0,
+                     stream, ind, out, M, E);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }

@@ -56,3 +56,13 @@ for name, p in cases.items():
     ms = gpu_ms(lambda: torch.ops.tsamd.select_segments(p, ind, idx, True, True))
     print(json.dumps(dict(bench='select_all_segments', case=name, E=E, ms=round(ms, 3),
                           gbs=round(E * 32 / ms / 1e6, 1))), flush=True)
+
+# ind2ptr: sorted row ids -> row pointer, incl. a matrix whose entries all sit in the last of 2^25 rows
+row21 = torch.ops.torch_sparse.ptr2ind(cases['rmat21'], int(cases['rmat21'][-1]))
+ind_cases = {'rmat21': (row21, 1 << 21),
+             'all_in_last_row_of_2^25': (torch.full((1 << 20, ), (1 << 25) - 1, dtype=torch.int64, device=dev), 1 << 25),
+             'every_1000th_row': (torch.arange(1 << 20, device=dev) * 1000, (1 << 20) * 1000),
+             'few_rows_many_entries': (torch.arange(1 << 25, device=dev) // (1 << 15), 1 << 10)}
+for name, (ind, Mrows) in ind_cases.items():
+    ms = gpu_ms(lambda: torch.ops.torch_sparse.ind2ptr(ind, Mrows))
+    print(json.dumps(dict(bench='ind2ptr', case=name, rows=Mrows, E=ind.numel(), ms=round(ms, 3))), flush=True)

@@ -305,3 +305,15 @@ def test_bandwidth_and_rcm(ts):
     np.testing.assert_array_equal(col.cpu().numpy(), want.indices)
     np.testing.assert_array_equal(value.cpu().numpy(), want.data)
     assert out.bandwidth() < A.to_symmetric().bandwidth()
+
+
+def test_select_with_long_runs_of_empty_rows(ts):
+    """A tile of output entries that spans more segments than it has entries takes the in-place search
+    path of select_fill / ptr2ind."""
+    A, S, rng = _random(ts, 3_000_000, 1_000, 6_000, 13)
+    idx = np.arange(3_000_000)
+    _same(A.index_select(0, torch.from_numpy(idx).to(DEV)), S)
+    pick = rng.integers(0, 3_000_000, 500_000)
+    _same(A.index_select(0, torch.from_numpy(pick).to(DEV)), S[pick])
+    adj, n_id = A.sparse_resize((3_000_000, 3_000_000)).sample_adj(torch.from_numpy(pick[:100_000]).unique().to(DEV), -1)
+    assert adj.nnz() == int(S[np.unique(pick[:100_000])].nnz)

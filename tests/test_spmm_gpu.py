@@ -213,6 +213,20 @@ def test_ind2ptr_ptr2ind(dev):
     assert np.array_equal(row.cpu().numpy(), oc.ptr2ind(rp.numpy(), c.numel()))
     back = nat.ind2ptr(row, 1 << 14)
     assert torch.equal(back.cpu(), rp)
+    # skewed laws: hub rows spread over many workgroups, long runs of empty rows (both kernels have a
+    # separate path for them), entries only in the first / last row
+    rng = np.random.RandomState(3)
+    for M, ind in ((3_000_000, np.sort(rng.randint(0, 3_000_000, 4000))),          # tiles span > 2048 rows
+                   (2_000_000, np.full(100_000, 1_999_999)),                        # all in the last row
+                   (2_000_000, np.zeros(100_000, np.int64)),                        # all in the first row
+                   (5000, np.sort(np.concatenate([np.full(3_000_000, 777), rng.randint(0, 5000, 20_000)]))),
+                   (1_500_000, np.sort(np.concatenate([rng.randint(0, 10, 50_000),
+                                                       rng.randint(1_400_000, 1_500_000, 50_000)])))):
+        ind = ind.astype(np.int64)
+        want = oc.ind2ptr(ind, M)
+        got = nat.ind2ptr(torch.from_numpy(ind).to(dev), M)
+        assert np.array_equal(got.cpu().numpy(), want)
+        assert np.array_equal(nat.ptr2ind(got, ind.size).cpu().numpy(), ind)
 
 
 def test_determinism(dev):
