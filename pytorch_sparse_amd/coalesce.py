@@ -44,7 +44,8 @@ def coalesce(index: Tensor, value: Optional[Tensor], m: int, n: int,
     row, col, perm, seg_ptr, n_u = sorted_unique(index[0], index[1], m, n)
     if value is not None:
         if seg_ptr is not None:
-            value = segment_reduce(value, perm, seg_ptr, n_u, op)  # differentiable, like segment_csr
+            # differentiable, like segment_csr; long runs of duplicates go the entry-balanced way
+            value = segment_reduce(value, perm, seg_ptr, n_u, op, balanced=index.size(1) > 8 * max(n_u, 1))
         elif perm is not None:
             value = value[perm]
     return torch.stack([row, col], dim=0), value

@@ -298,7 +298,8 @@ class SparseStorage(object):
         value = self._value
         if value is not None:
             from .segment import segment_reduce
-            value = segment_reduce(value, None, seg_ptr, n, reduce)
+            # heavy duplication (few distinct pairs, long runs): take the entry-balanced path
+            value = segment_reduce(value, None, seg_ptr, n, reduce, balanced=nnz > 8 * max(n, 1))
         return SparseStorage(row=row_u[:n].clone(), col=col_u[:n].clone(), value=value,
                              sparse_sizes=self._sparse_sizes, is_sorted=True, trust_data=True)
 

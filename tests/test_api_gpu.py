@@ -501,3 +501,27 @@ def test_reductions_hub_rows_balanced_path(ts, dev, dtype):
         torch.zeros(n, dtype=torch.float64, device=dev).scatter_reduce(0, A.storage.row(), ref_v, red,
                                                                          include_self=False).backward(gout)
         torch.testing.assert_close(val.grad, ref_v.grad, rtol=1e-12, atol=1e-12)
+
+
+def test_coalesce_heavy_duplication(ts, dev):
+    """A handful of distinct pairs repeated a million times: the duplicate runs are long, the values
+    are reduced on the entry-balanced path; exact with small integers."""
+    g = torch.Generator().manual_seed(9)
+    nnz = 1_500_000
+    row = torch.randint(0, 3, (nnz, ), generator=g)
+    col = torch.randint(0, 2, (nnz, ), generator=g)
+    val = torch.randint(-4, 5, (nnz, 2), generator=g).float()
+    for op in ('add', 'mean', 'min', 'max'):
+        oi, ov = ts.coalesce(torch.stack([row, col]).to(dev), val.to(dev), 3, 2, op=op)
+        key = row * 2 + col
+        uniq, inv = key.unique(return_inverse=True)
+        red = {'add': 'sum', 'mean': 'mean', 'min': 'amin', 'max': 'amax'}[op]
+        want = torch.zeros(uniq.numel(), 2, dtype=torch.float64).scatter_reduce(
+            0, inv.view(-1, 1).expand(-1, 2), val.double(), red, include_self=False)
+        assert torch.equal((oi[0] * 2 + oi[1]).cpu(), uniq)
+        assert torch.allclose(ov.cpu().double(), want, rtol=1e-6, atol=1e-6), op
+    A = ts.SparseTensor(row=row.to(dev), col=col.to(dev), value=val[:, 0].contiguous().to(dev), sparse_sizes=(3, 2))
+    C = A.coalesce('sum')
+    assert C.nnz() == uniq.numel()
+    want = torch.zeros(uniq.numel(), dtype=torch.float64).scatter_reduce(0, inv, val[:, 0].double(), 'sum')
+    assert torch.equal(C.storage.value().cpu().double(), want)
