@@ -301,6 +301,13 @@ int tsamd_non_diag_mask(const int64_t *row, const int64_t *col, int64_t E, int64
                         int64_t k, uint8_t *mask, void *stream);
 int tsamd_insert_diag(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
                       int64_t k, int64_t *row_out, int64_t *col_out, int64_t *src_out, void *stream);
+/* Fused remove + insert (set_diag / fill_diag in one pass over a pattern that may still have
+ * entries on the k-th diagonal): pos[E + 1] from tsamd_filter_plan(TSAMD_KEEP_OFF_DIAG, ..., a = k);
+ * outputs have pos[E] + tsamd_num_diag(M, N, k) entries; src_out[p] = input position of a kept
+ * entry, or E + j for the j-th diagonal entry. */
+int tsamd_set_diag_apply(const int64_t *pos, const int64_t *row, const int64_t *col, int64_t E,
+                         int64_t M, int64_t N, int64_t k, int64_t *row_out, int64_t *col_out,
+                         int64_t *src_out, void *stream);
 
 /* ------------------------------------------------------------------------
  * Mini-batch producers.  CPU-only in the reference except the walk.

@@ -202,6 +202,44 @@ __global__ void insert_diag_fill_kernel(const int64_t *__restrict__ row,
   src_out[p] = E + j;
 }
 
+// fused set_diag on a pattern that may still hold entries on the k-th diagonal: `pos` is the
+// exclusive scan of the OFF_DIAG keep flags (tsamd_filter_plan).  Kept entry i lands at
+// pos[i] + (diagonal slots before it); entries on the diagonal are dropped.
+__global__ void set_diag_move_kernel(const int64_t *__restrict__ pos, const int64_t *__restrict__ row,
+                                     const int64_t *__restrict__ col, int64_t E, int64_t k,
+                                     int64_t start, int64_t num_diag, int64_t *__restrict__ row_out,
+                                     int64_t *__restrict__ col_out, int64_t *__restrict__ src_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  const int64_t q = pos[i];
+  if (pos[i + 1] == q) return;
+  const int64_t r = row[i], c = col[i];
+  const int64_t p = q + diag_before(r, c, k, start, num_diag);
+  row_out[p] = r;
+  col_out[p] = c;
+  src_out[p] = i;
+}
+
+// diagonal entry j: kept entries before (d, d + k) = pos[lower_bound of (d, d + k) in the input]
+__global__ void set_diag_fill_kernel(const int64_t *__restrict__ pos, const int64_t *__restrict__ row,
+                                     const int64_t *__restrict__ col, int64_t E, int64_t k,
+                                     int64_t start, int64_t num_diag, int64_t *__restrict__ row_out,
+                                     int64_t *__restrict__ col_out, int64_t *__restrict__ src_out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= num_diag) return;
+  const int64_t d = start + j, c = d + k;
+  int64_t lo = 0, hi = E;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    const int64_t r = row[mid];
+    if (r < d || (r == d && col[mid] < c)) lo = mid + 1; else hi = mid;
+  }
+  const int64_t p = pos[lo] + j;
+  row_out[p] = d;
+  col_out[p] = c;
+  src_out[p] = E + j;
+}
+
 }  // namespace
 }  // namespace tsamd
 
@@ -342,6 +380,28 @@ extern "C" int tsamd_insert_diag(const int64_t *row, const int64_t *col, int64_t
   if (num_diag > 0) {
     hipLaunchKernelGGL(insert_diag_fill_kernel, dim3((unsigned int)ceil_div(num_diag, 256)), dim3(256),
                        0, stream, row, col, E, k, start, num_diag, row_out, col_out, src_out);
+    TSAMD_LAUNCH_CHECK();
+  }
+  return TSAMD_OK;
+}
+
+extern "C" int tsamd_set_diag_apply(const int64_t *pos, const int64_t *row, const int64_t *col,
+                                    int64_t E, int64_t M, int64_t N, int64_t k, int64_t *row_out,
+                                    int64_t *col_out, int64_t *src_out, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (E < 0 || M < 0 || N < 0 || !pos) return TSAMD_ERR_INVALID;
+  int64_t start, num_diag;
+  diag_extent(M, N, k, &start, &num_diag);
+  if (E + num_diag == 0) return TSAMD_OK;
+  if (!row_out || !col_out || !src_out || (E > 0 && (!row || !col))) return TSAMD_ERR_INVALID;
+  if (E > 0) {
+    hipLaunchKernelGGL(set_diag_move_kernel, dim3((unsigned int)ceil_div(E, 256)), dim3(256), 0, stream,
+                       pos, row, col, E, k, start, num_diag, row_out, col_out, src_out);
+    TSAMD_LAUNCH_CHECK();
+  }
+  if (num_diag > 0) {
+    hipLaunchKernelGGL(set_diag_fill_kernel, dim3((unsigned int)ceil_div(num_diag, 256)), dim3(256), 0,
+                       stream, pos, row, col, E, k, start, num_diag, row_out, col_out, src_out);
     TSAMD_LAUNCH_CHECK();
   }
   return TSAMD_OK;

@@ -691,6 +691,35 @@ std::tuple<Tensor, Tensor, Tensor> insert_diag(Tensor row, Tensor col, int64_t M
   return std::make_tuple(row_out, col_out, src);
 }
 
+// set_diag in one pass: sorted (row, col), possibly with entries on the k-th diagonal ->
+// (row, col, src) of the pattern with the full diagonal, old diagonal entries dropped;
+// src[p] = input position, or E + j for the j-th diagonal entry.  One host sync.
+std::tuple<Tensor, Tensor, Tensor> set_diag_pattern(Tensor row, Tensor col, int64_t M, int64_t N,
+                                                    int64_t k) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  auto iopt = row.options().requires_grad(false);
+  void *stream = current_stream(row);
+  Tensor pos = torch::empty({E + 1}, iopt), cnt = torch::empty({1}, iopt);
+  Tensor ws = workspace(tsamd_filter_workspace_bytes(E), row);
+  check_status(tsamd_filter_plan(TSAMD_KEEP_OFF_DIAG, row.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                                 nullptr, nullptr, E, k, 0, pos.data_ptr<int64_t>(),
+                                 cnt.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
+               "tsamd_filter_plan");
+  const int64_t T = cnt.item<int64_t>() + tsamd_num_diag(M, N, k);  // the one sync
+  Tensor row_out = torch::empty({T}, iopt), col_out = torch::empty({T}, iopt), src = torch::empty({T}, iopt);
+  check_status(tsamd_set_diag_apply(pos.data_ptr<int64_t>(), row.data_ptr<int64_t>(),
+                                    col.data_ptr<int64_t>(), E, M, N, k, row_out.data_ptr<int64_t>(),
+                                    col_out.data_ptr<int64_t>(), src.data_ptr<int64_t>(), stream),
+               "tsamd_set_diag_apply");
+  return std::make_tuple(row_out, col_out, src);
+}
+
 // ---- mini-batch producers (include/tsamd.h) -----------------------------
 // walk with the uniform floats handed in: out[n, L+1] is a pure function of the inputs
 Tensor random_walk_with_rand(Tensor rowptr, Tensor col, Tensor start, Tensor rand) {
@@ -990,6 +1019,7 @@ static auto registry = torch::RegisterOperators()
                            .op("tsamd::scatter_rows", &scatter_rows)
                            .op("torch_sparse::non_diag_mask", &non_diag_mask)
                            .op("tsamd::insert_diag", &insert_diag)
+                           .op("tsamd::set_diag_pattern", &set_diag_pattern)
                            .op("torch_sparse::random_walk", &random_walk)
                            .op("tsamd::random_walk_with_rand", &random_walk_with_rand)
                            .op("torch_sparse::sample_adj", &sample_adj)

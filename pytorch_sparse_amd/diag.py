@@ -2,9 +2,10 @@
 torch_sparse/diag.py).  ``fill_diag(adj, 1)`` is the self-loop step of GCN normalisation, i.e. the op
 right before the ``sum(dim=1)`` / ``mul`` / SpMM chain.
 
-``remove_diag`` is one ``tsamd::filter_coo`` compaction; ``set_diag`` merges the full k-th diagonal
-into the sorted pattern with ``tsamd::insert_diag`` (two launches, no host sync) instead of the
-reference's ``non_diag_mask`` + four boolean-mask scatters; the values of old and new entries are
+``remove_diag`` is one ``tsamd::filter_coo`` compaction; ``set_diag`` drops the old diagonal entries and
+merges the full k-th diagonal in one fused pass (``tsamd::set_diag_pattern``: flags + scan, one move
+kernel with closed-form slots, one binary-search kernel for the diagonal) instead of the reference's
+``remove_diag`` + ``non_diag_mask`` + four boolean-mask scatters; the values of old and new entries are
 assembled with one differentiable gather.  ``torch.ops.torch_sparse.non_diag_mask`` itself is also
 provided with the reference's schema.
 """
@@ -30,11 +31,14 @@ def remove_diag(src: SparseTensor, k: int = 0) -> SparseTensor:
 
 
 def set_diag(src: SparseTensor, values: Optional[Tensor] = None, k: int = 0) -> SparseTensor:
-    src = remove_diag(src, k=k)
+    """Reference diag.py:37-79 (remove_diag, non_diag_mask, four boolean-mask scatters), fused: one
+    flag + scan pass, one move kernel, one kernel for the diagonal, one gather of the values."""
     row, col, value = src.coo()
+    if not col.is_cuda:
+        raise RuntimeError('pytorch_sparse_amd has no CPU implementation: move the SparseTensor to the GPU')
     M, N = src.sparse_sizes()
-    new_row, new_col, gather = torch.ops.tsamd.insert_diag(row, col, M, N, k)
-    num_diag = new_row.numel() - row.numel()
+    new_row, new_col, gather = torch.ops.tsamd.set_diag_pattern(row, col, M, N, k)
+    num_diag = max(min(M + k, N) if k < 0 else min(M, N - k), 0)
 
     new_value: Optional[Tensor] = None
     if value is not None:
