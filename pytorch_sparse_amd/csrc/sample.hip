@@ -139,7 +139,8 @@ __global__ void relabel_seed_kernel(const int64_t *__restrict__ idx, int64_t n, 
     atomicAdd(err, 1ull);
     return;
   }
-  slot[v] = -(i + 1);
+  // a node listed twice keeps its LAST position, as the reference's sequential map insert does
+  atomicMin(reinterpret_cast<long long *>(&slot[v]), (long long)(-(i + 1)));
 }
 
 __global__ void relabel_first_kernel(const int64_t *__restrict__ nbr, int64_t T, int64_t M,
@@ -191,7 +192,7 @@ __global__ void assoc_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t
     atomicAdd(err, 1ull);
     return;
   }
-  assoc[v] = i;
+  atomicMax(reinterpret_cast<long long *>(&assoc[v]), (long long)i);  // duplicates: last position wins
 }
 
 }  // namespace

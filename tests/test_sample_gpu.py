@@ -338,3 +338,25 @@ def test_neighbor_sample_properties(big, replace):
     np.testing.assert_array_equal(host(r2), v)
     np.testing.assert_array_equal(host(c2), i)
     np.testing.assert_array_equal(host(e2), pos)
+
+
+def test_duplicate_seed_ids_keep_their_last_position(big):
+    """The reference's sequential map insert lets a node that is listed twice keep its LAST position;
+    the numpy restatement agrees with the compiled reference on that (checked on the CPU), and so
+    must the GPU relabel / SAINT kernels."""
+    rowptr, col = big
+    n = rowptr.size - 1
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, n, 5_000)  # duplicates
+    assert np.unique(idx).size < idx.size
+    rp, c = dev(rowptr), dev(col)
+    row = torch.ops.torch_sparse.ptr2ind(rp, col.size)
+    cols = col[rng.integers(0, col.size, 100_000)]
+    for g, w in zip(torch.ops.torch_sparse.relabel(dev(cols), dev(idx)), npo.relabel(cols, idx)):
+        np.testing.assert_array_equal(host(g), w)
+    for g, w in zip(torch.ops.torch_sparse.saint_subgraph(dev(idx), rp, row, c), npo.saint_subgraph(idx, rowptr, col)):
+        np.testing.assert_array_equal(host(g), w)
+    g_rp, g_c, _, g_idx = torch.ops.torch_sparse.relabel_one_hop(rp, c, None, dev(idx), True)
+    w_rp, w_c, _, w_idx = npo.relabel_one_hop(rowptr, col, idx, True)
+    np.testing.assert_array_equal(host(g_c), w_c)
+    np.testing.assert_array_equal(host(g_idx), w_idx)
