@@ -100,3 +100,29 @@ def test_argument_validation_returns_status_codes():
     big = L.tsamd_spmm_workspace_bytes(0, 0, i64(1), i64(1 << 21), i64(1 << 21), i64(128), i64(40 << 20))
     halo = L.tsamd_spmm_workspace_bytes(0, 0, i64(1), i64(1 << 21), i64(1 << 24), i64(128), i64(40 << 20))
     assert small < (1 << 22) and big > (1 << 30) and halo < (1 << 28)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, 'pytorch_sparse_amd', 'lib')
+    exe = str(tmp_path / 'spmm_cabi')
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', os.path.join(root, 'examples', 'spmm_cabi.c'),
+           '-I' + os.path.join(root, 'include'), '-I/opt/rocm/include', '-L' + libdir, '-ltsamd', '-L/opt/rocm/lib',
+           '-lamdhip64', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_plain_c_client_builds(tmp_path):
+    """examples/spmm_cabi.c -- C99, gcc, no torch, no C++ -- compiles and links against
+    include/tsamd.h + libtsamd.so: the boundary really is a C-ABI."""
+    assert os.path.exists(_build_c_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_plain_c_client_runs(tmp_path):
+    import subprocess
+    out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'C-ABI example OK' in out.stdout
