@@ -144,6 +144,18 @@ int tsamd_ind2ptr(const int64_t *ind, int64_t M, int64_t E, int64_t *out,
 int tsamd_ptr2ind(const int64_t *ptr, int64_t M, int64_t E, int64_t *out,
                   void *stream);
 
+/* ------------------------------------------------------------------------
+ * Entry-balanced segmented reduction (csrc/segreduce.hip): same result as tsamd_segment_reduce,
+ * for segments that may be very long (rows / columns of a power-law matrix:
+ * SparseTensor.sum/mean/min/max(dim), torch_sparse/reduce.py:8-67 -> torch_scatter.segment_csr).
+ * Work is split by entries, not by segments; deterministic, no atomics; fp32 partial sums of a
+ * segment that spans several chunks fold in fp64.  Needs seg_ptr[0] = 0 and seg_ptr[nseg] = E.
+ * ------------------------------------------------------------------------ */
+size_t tsamd_segment_reduce_balanced_workspace_bytes(int dtype, int64_t E, int64_t D);
+int tsamd_segment_reduce_balanced(int dtype, int reduce, const void *value, const int64_t *perm,
+                                  const int64_t *seg_ptr, int64_t nseg, int64_t E, int64_t D,
+                                  void *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * COO ordering / sorting / coalescing.  Replace the Python + ATen +
  * torch_scatter compositions of SparseStorage (torch_sparse/storage.py):

@@ -21,6 +21,7 @@ SYMBOLS = [
     'tsamd_ind2ptr', 'tsamd_ptr2ind',
     'tsamd_coo_order', 'tsamd_sort_coo_workspace_bytes', 'tsamd_sort_coo',
     'tsamd_coalesce_workspace_bytes', 'tsamd_coalesce_index', 'tsamd_segment_reduce',
+    'tsamd_segment_reduce_balanced_workspace_bytes', 'tsamd_segment_reduce_balanced',
     'tsamd_exclusive_scan_workspace_bytes', 'tsamd_exclusive_scan_i64',
     'tsamd_spspmm_plan_workspace_bytes', 'tsamd_spspmm_plan', 'tsamd_spspmm_rows_workspace_bytes',
     'tsamd_spspmm_rows', 'tsamd_spspmm_compact',

@@ -24,7 +24,7 @@ OBJDIR = os.path.join(ROOT, 'build', 'obj')
 ARCH = 'gfx950'
 
 HIP_SOURCES = ['api.hip', 'spmm.hip', 'spmm_bw.hip', 'convert.hip', 'scan.hip', 'sort.hip',
-               'coalesce.hip', 'spspmm.hip', 'select.hip', 'sample.hip']
+               'coalesce.hip', 'spspmm.hip', 'select.hip', 'sample.hip', 'segreduce.hip']
 OPS_SOURCES = ['torch_ops.cpp']
 
 

@@ -363,10 +363,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> coalesce_index(Tensor row, Tensor col
 // balanced = false: one thread per (segment, feature) -- right for the short runs of duplicates
 //   that coalesce reduces.
 // balanced = true: the segments are the rows / columns of a matrix (hubs with 1e5+ entries on
-//   power-law graphs, where one thread per segment took 13-37 ms for 40 M entries): the reduction
-//   is A * 1, so it runs on the merge-path SpMM kernel (entry-balanced, deterministic, fp64 fold of
-//   cut rows) with a one-row matrix of ones; every entry "gathers" that row through an all-zero
-//   column array.  Costs 8 B per entry of extra reads for an order of magnitude in time.
+//   power-law graphs, where one thread per segment took 13-37 ms for 40 M entries): the
+//   entry-balanced kernel of csrc/segreduce.hip.
 Tensor segment_reduce(Tensor value, OptTensor perm, Tensor seg_ptr, int64_t nseg, std::string reduce,
                       bool balanced) {
   check_gpu(value, "value");
@@ -378,36 +376,23 @@ Tensor segment_reduce(Tensor value, OptTensor perm, Tensor seg_ptr, int64_t nseg
   value = value.contiguous();
   seg_ptr = seg_ptr.contiguous();
   auto sizes = value.sizes().vec();
-  const int64_t E = value.size(0);
-  const int64_t D = E > 0 ? value.numel() / E : 1;
+  const int64_t E = perm.has_value() ? perm.value().numel() : value.size(0);
+  const int64_t D = value.size(0) > 0 ? value.numel() / value.size(0) : 1;
   sizes[0] = nseg;
   const int red = reduce_code(reduce);
-  if (balanced && E >= 32768 && D >= 1 && D <= 8 && nseg > 0) {
-    Tensor v = perm.has_value() ? value.index_select(0, perm.value()) : value;
-    Tensor v2 = v.reshape({E, D});
-    Tensor rp = seg_ptr.narrow(0, 0, nseg + 1);
-    Tensor zero_col = torch::zeros({E}, seg_ptr.options());
-    Tensor ones = torch::ones({1, 1}, value.options().requires_grad(false));
-    // integer means: torch_scatter floors, the SpMM kernel truncates like the reference's spmm ->
-    // take the sum here and floor-divide below
-    const bool int_mean = red == TSAMD_MEAN && !value.is_floating_point();
-    const std::string op = int_mean ? "sum" : reduce;
-    std::vector<Tensor> cols;
-    for (int64_t d = 0; d < D; ++d) {
-      OptTensor vd = D == 1 ? v2.reshape({E}) : v2.select(1, d).contiguous();
-      cols.push_back(std::get<0>(spmm_fw(rp, zero_col, vd, ones, op)));
-    }
-    Tensor out = D == 1 ? cols[0] : torch::cat(cols, 1);
-    if (int_mean) {
-      Tensor cnt = (rp.narrow(0, 1, nseg) - rp.narrow(0, 0, nseg)).clamp_min(1).to(out.scalar_type());
-      out = torch::div(out, cnt.unsqueeze(1), "floor");
-    }
-    return out.reshape(sizes);
-  }
   Tensor out = torch::empty(sizes, value.options().requires_grad(false));
   Tensor p = perm.has_value() ? perm.value().contiguous() : Tensor();
-  check_status(tsamd_segment_reduce(dtype_code(value), red, value.data_ptr(),
-                                    perm.has_value() ? p.data_ptr<int64_t>() : nullptr,
+  const int64_t *pp = perm.has_value() ? p.data_ptr<int64_t>() : nullptr;
+  if (balanced && E >= 32768 && D <= 65535) {
+    const int dt = dtype_code(value);
+    Tensor ws = workspace(tsamd_segment_reduce_balanced_workspace_bytes(dt, E, D), value);
+    check_status(tsamd_segment_reduce_balanced(dt, red, value.data_ptr(), pp, seg_ptr.data_ptr<int64_t>(),
+                                               nseg, E, D, out.data_ptr(), ws.data_ptr(),
+                                               (size_t)ws.numel(), current_stream(value)),
+                 "tsamd_segment_reduce_balanced");
+    return out;
+  }
+  check_status(tsamd_segment_reduce(dtype_code(value), red, value.data_ptr(), pp,
                                     seg_ptr.data_ptr<int64_t>(), nseg, D, out.data_ptr(),
                                     current_stream(value)),
                "tsamd_segment_reduce");
