@@ -6,7 +6,7 @@ torch.sparse conversions, and -- patched in by the sibling modules -- ``matmul/s
 partitioners of the reference are outside this package's scope and raise
 ``NotImplementedError``.
 """
-from typing import Any, List, Optional, Tuple, Union
+from typing import List, Optional, Tuple, Union
 
 import torch
 from torch import Tensor
