@@ -568,9 +568,24 @@ void plan_partition(int64_t M, int64_t E, int64_t *P, int64_t *items) {
 // Cost: one read + one write of mat (2 * N rows); gain: ~30 % of the time to gather E rows.
 // It therefore needs E >= ~7 N; 8 N is used (a row-sharded block with few edges per column of
 // the gathered X -- the multi-GPU case -- does not qualify).
+//
+// Only rows whose byte size is a power of two (>= 128 B) camp on memory channels: with hub ids
+// that are multiples of big powers of two, `id * pitch` keeps its low address bits zero only if the
+// pitch is a power of two itself.  Same-box A/B on the north-star graph (scripts/bench_fsweep.py,
+// TSAMD_SPMM_RELABEL=0/1): F = 32 / 64 / 128 / 256 fp32 gain 8 / 10 / 26 / 30 % from the copy,
+// F = 24 / 40 / 48 / 80 / 96 / 112 / 160 / 192 LOSE 13-25 % (they spread by themselves and only pay
+// for the copy and the hashing), 64-byte rows lose 2-10 %.  TSAMD_SPMM_RELABEL=1 still forces it.
+bool relabel_forced() {
+  const char *env = getenv("TSAMD_SPMM_RELABEL");
+  return env != nullptr && env[0] == '1';
+}
+
 bool relabel_possible(int dtype, int64_t N, int64_t K, int64_t E) {
-  return E >= (1 << 20) && N >= 4096 && N < ((int64_t)1 << 32) && E >= 8 * N &&
-         (K * (int64_t)dtype_size(dtype)) % 16 == 0;
+  const int64_t row_bytes = K * (int64_t)dtype_size(dtype);
+  const bool size_ok = E >= (1 << 20) && N >= 4096 && N < ((int64_t)1 << 32) && E >= 8 * N &&
+                       row_bytes % 16 == 0;
+  const bool camps = row_bytes >= 128 && (row_bytes & (row_bytes - 1)) == 0;
+  return size_ok && (camps || relabel_forced());
 }
 
 size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,
