@@ -72,6 +72,12 @@ def check_spmm(out, arg, rowptr, col, value, mat, reduce):
             assert torch.equal(arg.cpu(), ea), 'arg_out mismatch (%s, %s)' % (dtype, reduce)
     else:
         ex, l1 = exact_sum_and_l1(rowptr, col, value, mat, reduce)
-        err = np.abs(out.detach().cpu().double().numpy() - ex)
+        got = out.detach().cpu().double().numpy()
         bound = SUM_TOL[dtype] * l1 + SUM_ATOL[dtype]
+        if dtype == torch.float16:  # results beyond the fp16 range must overflow to +-inf, not be "close"
+            big = np.abs(ex) > 65504.0 * (1 + 2.0 ** -11)
+            assert (np.isinf(got[big]) & (np.sign(got[big]) == np.sign(ex[big]))).all(), 'fp16 overflow'
+            near = np.abs(ex) > 65504.0 * (1 - 2.0 ** -9)  # within rounding distance of the limit: either way
+            got, ex, bound = got[~big & ~near], ex[~big & ~near], bound[~big & ~near]
+        err = np.abs(got - ex)
         assert (err <= bound).all(), 'max err/bound %.3g (%s, %s)' % ((err / bound).max(), dtype, reduce)
