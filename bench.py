@@ -194,12 +194,37 @@ def main():
         return torch.ops.torch_sparse.spmm_max(rp, c, v, x)[0]
 
     x_sizes = [m_local] * world
-    if world > 1 and args.exchange == 'pipelined':
-        sharded = PipelinedHaloSpMM(rowptr, col, value, x_sizes, None, op_spmm, chunks=args.chunks)
-    elif world > 1 and args.exchange == 'halo':
-        sharded = HaloShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm)
+
+    def build(mode):  # plans the exchange once
+        if world > 1 and mode == 'pipelined':
+            return PipelinedHaloSpMM(rowptr, col, value, x_sizes, None, op_spmm, chunks=args.chunks)
+        if world > 1 and mode == 'halo':
+            return HaloShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm)
+        return RowShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm)
+
+    # The requested exchange first; if its planning or a trial step raises on ANY rank (the ranks
+    # agree through an all_reduce), fall back to the simpler ones and say so in the JSON line.
+    requested, fallback_reason = args.exchange, None
+    for mode in [requested] + [m for m in ('halo', 'allgather') if m != requested]:
+        err = None
+        try:
+            sharded = build(mode)
+            with torch.no_grad():
+                sharded(x_local, args.reduce)
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            err = '%s: %s' % (type(exc).__name__, str(exc)[:200])
+        failed = torch.tensor([0 if err is None else 1], device=dev)
+        if world > 1:
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed) == 0:
+            args.exchange = mode
+            break
+        fallback_reason = fallback_reason or ('%s failed (%s)' % (mode, err or 'on another rank'))
+        if world == 1:
+            raise RuntimeError(err)
     else:
-        sharded = RowShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm)  # plans the exchange once
+        raise RuntimeError('no exchange mode works: %s' % fallback_reason)
     comm_rows = getattr(sharded, 'n_needed', n_global) if world > 1 else 0
 
     def step():
@@ -278,6 +303,8 @@ def main():
                                 graph='R-MAT(0.57,0.19,0.19,0.05) scale %d edge factor %d, coalesced' % (scale, ef),
                                 parallelism='row-sharded x%d%s' % (world, (', RCCL %s of X rows (%d rows in per rank)' % ({'halo': 'all_to_all', 'pipelined': 'all_to_all in %d overlapped pieces' % args.chunks, 'allgather': 'all_gather'}[args.exchange], comm_rows)) if world > 1 else '')),
                     roofline=roofline)
+        if fallback_reason is not None:
+            line['config']['exchange_fallback'] = 'requested %s; %s' % (requested, fallback_reason)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rowptr, col_k, value, x_full, args.reduce, out)
         print(json.dumps(line), flush=True)
