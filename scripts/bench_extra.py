@@ -125,3 +125,25 @@ if 'c1' in which:
     ref = torch.zeros(m, 16, device=dev).index_add_(0, row, val[:, None] * x[col])
     print(json.dumps(dict(bench='c1_legacy_spmm_1k', legacy_spmm_ms_wall=round(t_legacy, 4), matmul_ms_wall=round(t_mm, 4),
                           matmul_ms_gpu=round(t_k, 4), max_abs_err=float((out - ref).abs().max()))), flush=True)
+
+if 'prelabel' in which:
+    # The per-call relabelled copy of X disappears when the graph itself is stored in
+    # a channel-friendly node order: relabel the nodes ONCE (adj.permute(perm), x[perm]) -- any random
+    # permutation does -- and tsamd_spmm's probe finds nothing to fix.  Same matrix up to that
+    # symmetric permutation: out' = (P A P^T)(P X) = P (A X).
+    scale, K = 21, 128
+    rp, c = synth.rmat_csr(scale, 20, seed=0, device=dev); n = 1 << scale; E = c.numel()
+    v = synth.values(E, device=dev); x = synth.features(n, K, device=dev)
+    t0 = gpu_time(lambda: nat.spmm(rp, c, v, x, 'sum'), iters=10)
+    A = ts.SparseTensor(rowptr=rp, col=c, value=v, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0)).to(dev)
+    t_perm = wall(lambda: A.permute(perm), iters=3)
+    Ap = A.permute(perm); xp = x[perm]
+    rpp, cp, vp = Ap.csr()
+    t1 = gpu_time(lambda: nat.spmm(rpp, cp, vp, xp, 'sum'), iters=10)
+    ref = nat.spmm(rp, c, v, x, 'sum')[0][perm]
+    got = nat.spmm(rpp, cp, vp, xp, 'sum')[0]
+    balg = E * (8 + 4 + K * 4) + (n + 1) * 8 + n * K * 4
+    print(json.dumps(dict(bench='ns_pre_permuted_graph', as_given_ms=round(t0, 3), pre_permuted_ms=round(t1, 3),
+                          one_time_permute_ms=round(t_perm, 2), frac_hbm_pre_permuted=round(balg / t1 / 1e6 / 8000, 3),
+                          max_rel_diff=float(((got - ref).abs().max() / ref.abs().max())))), flush=True)
