@@ -7,11 +7,12 @@
 //   * relabel(_one_hop)  csrc/cpu/relabel_cpu.cpp:5-155
 // Here:
 //   * walks: one lane per walk, `rand` handed in (so the result is a pure function of its inputs);
-//   * draws: one lane per (row, j).  Without replacement the j-th draw of a row is pi_row(j) for a
-//     keyed pseudo-random BIJECTION pi_row of [0, deg) (add / odd-multiply / xor-shift rounds on
-//     ceil(log2 deg) bits + cycle walking, keys from Philox4x32-10 of (seed, row)): distinct by
-//     construction, O(1) state, no per-row set, hubs and leaves cost the same.  With replacement a
-//     Philox draw per (row, j);
+//   * draws: one lane per (row, j).  Without replacement the j-th draw of a row with more than 64
+//     neighbours is pi_row(j) for a keyed pseudo-random BIJECTION pi_row of [0, deg) (6-round
+//     Feistel network with Philox4x32-10 round keys of (seed, row) + cycle walking): distinct by
+//     construction, O(1) state, no per-row set, hubs cost the same as anything else.  Rows with at
+//     most 64 neighbours take an exactly uniform k-subset by Floyd's algorithm with the set in a
+//     64-bit mask (one lane per row).  With replacement: a Philox draw per (row, j);
 //   * relabel: a dense slot[] array over the node ids (8 B per node of the graph): seeds hold
 //     -(i+1), every other drawn node the minimum draw position (atomicMin) = its FIRST OCCURRENCE in
 //     row-major order; flags + device scan rank the first occurrences -> new ids n, n+1, ... in the
@@ -64,25 +65,37 @@ __device__ inline U4 philox(uint64_t seed, uint64_t c_lo, uint32_t c2, uint32_t 
 
 __device__ inline uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
 
-// j -> pi(j): keyed bijection of [0, deg), deg >= 2, j < deg
+__device__ inline uint32_t fmix32(uint32_t h) {  // MurmurHash3 finaliser
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+// j -> pi(j): keyed pseudo-random bijection of [0, deg), used for deg > 64: a balanced 6-round
+// Feistel network on 2 * ceil(b / 2) bits (b = bits of deg - 1) whose round function is a strong
+// 32-bit mixer of the right half and a Philox-derived round key, cycle-walked back into range
+// (the domain is < 4 deg: < 4 rounds expected).  (Mitchell et al., "Bandwidth-optimal random
+// shuffling for GPUs", use the same construction.)
 __device__ inline uint64_t permute_index(uint64_t j, uint64_t deg, uint64_t seed, uint64_t row) {
-  const int b = 64 - __clzll((long long)(deg - 1));  // 2^(b-1) < deg <= 2^b
-  const uint64_t mask = b >= 64 ? ~0ull : ((1ull << b) - 1);
-  const int s = b > 1 ? b / 2 : 1;
+  const int b = 64 - __clzll((long long)(deg - 1));
+  const int h = (b + 1) >> 1;  // half width, 4..32 here
+  const uint64_t hmask = (1ull << h) - 1;
   const U4 a = philox(seed, row, 0u, 0x5A17u), c = philox(seed, row, 1u, 0x5A17u);
-  const uint64_t k0 = u64(a.x, a.y), k1 = u64(a.z, a.w) | 1ull;
-  const uint64_t k2 = u64(c.x, c.y), k3 = u64(c.z, c.w) | 1ull;
+  const uint32_t key[6] = {a.x, a.y, a.z, a.w, c.x, c.y};
   uint64_t x = j;
-  do {  // cycle walking: < 2 rounds expected, the domain is less than twice deg
-    x = (x + k0) & mask;
-    x = (x * k1) & mask;
-    x ^= x >> s;
-    x = (x + k2) & mask;
-    x = (x * k3) & mask;
-    x ^= x >> s;
-    x = (x * 0x9E3779B97F4A7C15ull) & mask;
-    x ^= x >> s;
-    x = (x + (k0 >> 7)) & mask;
+  do {
+    uint64_t L = x >> h, R = x & hmask;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const uint32_t f = fmix32((uint32_t)R * 0x9E3779B1u + key[r]);  // R has at most 32 bits
+      const uint64_t nR = (L ^ (uint64_t)(f >> (32 - h))) & hmask;
+      L = R;
+      R = nR;
+    }
+    x = (L << h) | R;
   } while (x >= deg);
   return x;
 }
@@ -122,8 +135,26 @@ __global__ void sample_draw_kernel(const int64_t *__restrict__ rowptr, const int
   if (replace) {
     const U4 r = philox(seed, (uint64_t)i, (uint32_t)j, 0xD4A3u ^ (uint32_t)((uint64_t)j >> 32));
     p = (int64_t)__umul64hi(u64(r.x, r.y), (uint64_t)deg);
+  } else if (deg <= k) {
+    p = j;  // the whole row, in stored order
+  } else if (deg <= 64) {
+    // small rows: an exactly uniform k-subset by Floyd's algorithm, the set kept in a 64-bit mask;
+    // the lane of draw 0 does the whole row (k <= 64 steps)
+    if (j != 0) return;
+    uint64_t used = 0;
+    int64_t cnt = 0;
+    for (int64_t t = deg - k; t < deg; ++t) {
+      const U4 r = philox(seed, (uint64_t)i, (uint32_t)t, 0xF10Du);
+      const uint64_t pick0 = __umul64hi(u64(r.x, r.y), (uint64_t)(t + 1));  // uniform in [0, t]
+      const uint64_t pick = ((used >> pick0) & 1ull) ? (uint64_t)t : pick0;
+      used |= 1ull << pick;
+      e_id[o + cnt] = s + (int64_t)pick;
+      nbr[o + cnt] = col[s + (int64_t)pick];
+      ++cnt;
+    }
+    return;
   } else {
-    p = deg <= k ? j : (int64_t)permute_index((uint64_t)j, (uint64_t)deg, seed, (uint64_t)i);
+    p = (int64_t)permute_index((uint64_t)j, (uint64_t)deg, seed, (uint64_t)i);
   }
   e_id[o + j] = s + p;
   nbr[o + j] = col[s + p];

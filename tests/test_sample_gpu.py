@@ -360,3 +360,31 @@ def test_duplicate_seed_ids_keep_their_last_position(big):
     w_rp, w_c, _, w_idx = npo.relabel_one_hop(rowptr, col, idx, True)
     np.testing.assert_array_equal(host(g_c), w_c)
     np.testing.assert_array_equal(host(g_idx), w_idx)
+
+
+@pytest.mark.parametrize('D,k', [(3, 1), (3, 2), (5, 2), (8, 3), (8, 5), (16, 4), (64, 2), (65, 2), (100, 2), (129, 2),
+                                 (70, 3)])
+def test_sample_adj_every_subset_equally_likely(D, k):
+    """Stronger than equal inclusion frequencies: all C(D, k) k-subsets of a row must be drawn equally
+    often (chi-square over the subsets).  Rows with <= 64 neighbours use Floyd's exact algorithm,
+    longer rows the keyed Feistel bijection; a first version of the bijection (multiply / xor-shift
+    rounds) passed the inclusion test and failed this one by orders of magnitude."""
+    import itertools
+    R = 400_000 if D <= 64 else 2_000_000
+    rowptr = np.concatenate([np.arange(R + 1) * D, np.full(D, R * D)]).astype(np.int64)
+    col = np.tile(np.arange(R, R + D), R).astype(np.int64)
+    torch.manual_seed(1)
+    _, _, _, e_id = torch.ops.torch_sparse.sample_adj(dev(rowptr), dev(col), torch.arange(R, device=DEV), k, False)
+    pos = np.sort((host(e_id) % D).reshape(R, k), axis=1)
+    assert np.all(pos[:, 1:] > pos[:, :-1]) if k > 1 else True  # distinct
+    key = np.zeros(R, np.int64)
+    for j in range(k):
+        key = key * D + pos[:, j]
+    nsub = len(list(itertools.combinations(range(D), k))) if D <= 16 else int(np.prod([D - j for j in range(k)]) // np.prod(range(1, k + 1)))
+    _, counts = np.unique(key, return_counts=True)
+    cnt = np.zeros(nsub)
+    cnt[:counts.size] = counts
+    expect = R / nsub
+    chi2 = ((cnt - expect) ** 2 / expect).sum()
+    dof = nsub - 1
+    assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof) + 5, (chi2, dof)
