@@ -255,6 +255,42 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    # N > 1: the exchange alone (one-shot fetch of the rows this rank's block references) and the
+    # local SpMM alone, timed after the headline region, next to the xGMI model of the exchange
+    exchange_info = None
+    if world > 1:
+        if isinstance(sharded, RowShardedSpMM):
+            fetch = lambda: sharded.gather(x_local)  # noqa: E731
+            rows_in = n_global - m_local
+        else:
+            plan = sharded if isinstance(sharded, HaloShardedSpMM) else ref_plan
+            fetch = lambda: plan.exchange(x_local)  # noqa: E731
+            rows_in = int(plan.n_needed - plan.recv_counts[rank])  # rows that cross a link
+        reps = max(3, min(args.steps, 10))
+        t_parts = []
+        for fn in (fetch, lambda: op_spmm(rowptr, col_k, value, x_full, args.reduce)):
+            with torch.no_grad():
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                for _ in range(reps):
+                    fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_parts.append((time.perf_counter() - t1) / reps * 1e3)
+        part = torch.tensor(t_parts + [float(rows_in)], dtype=torch.float64, device=dev)
+        dist.all_reduce(part, op=dist.ReduceOp.MAX)
+        bytes_in = float(part[2]) * F * 4
+        # every peer's share arrives over its own xGMI link (7 links x ~153 GB/s peak per GPU)
+        link_gbs = 153.0
+        exchange_info = dict(mode=args.exchange, exchange_only_ms=round(float(part[0]), 3),
+                             spmm_only_ms=round(float(part[1]), 3), max_rows_in_per_rank=int(part[2]),
+                             max_bytes_in_per_rank=int(bytes_in),
+                             modelled_exchange_ms=round(bytes_in / (world - 1) / (link_gbs * 1e9) * 1e3, 3),
+                             model='bytes_in / (N - 1) peers, each over its own xGMI link at %.0f GB/s peak' % link_gbs)
+
     stats = torch.tensor([elapsed, float(E)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats.clone()
@@ -303,6 +339,8 @@ def main():
                                 graph='R-MAT(0.57,0.19,0.19,0.05) scale %d edge factor %d, coalesced' % (scale, ef),
                                 parallelism='row-sharded x%d%s' % (world, (', RCCL %s of X rows (%d rows in per rank)' % ({'halo': 'all_to_all', 'pipelined': 'all_to_all in %d overlapped pieces' % args.chunks, 'allgather': 'all_gather'}[args.exchange], comm_rows)) if world > 1 else '')),
                     roofline=roofline)
+        if exchange_info is not None:
+            line['exchange'] = exchange_info
         if fallback_reason is not None:
             line['config']['exchange_fallback'] = 'requested %s; %s' % (requested, fallback_reason)
         if world == 1 and not args.no_cpu_baseline:

@@ -525,3 +525,39 @@ def test_coalesce_heavy_duplication(ts, dev):
     assert C.nnz() == uniq.numel()
     want = torch.zeros(uniq.numel(), dtype=torch.float64).scatter_reduce(0, inv, val[:, 0].double(), 'sum')
     assert torch.equal(C.storage.value().cpu().double(), want)
+
+
+@pytest.mark.parametrize('P', [2, 4, 8])
+def test_row_shards_as_logical_ranks_on_one_gpu(ts, dev, P):
+    """SURVEY.md 8e validation: the sharded path with P logical ranks run one after the other on one
+    device.  Every rank owns a row block of A (narrow_rows, nnz-balanced) with global column ids and
+    (i) multiplies it with the full X, (ii) multiplies the column-compacted block with only the rows
+    of X it references (what the halo exchange delivers).  Stacked, both must equal the unsharded
+    SpMM: bit for bit for max, and to fp32 rounding for sum / mean (where a long row is cut by the
+    merge-path partition depends on the block it sits in, so its partial sums associate differently)."""
+    from pytorch_sparse_amd import _native as nat
+    from pytorch_sparse_amd import synth
+    from pytorch_sparse_amd.parallel import narrow_rows, partition_rows
+    rp, c = synth.rmat_csr(15, 16, seed=4)
+    n, E = rp.numel() - 1, c.numel()
+    rp, c = rp.to(dev), c.to(dev)
+    v = synth.values(E, device=dev)
+    x = synth.features(n, 48, device=dev)
+    ranges = partition_rows(rp, P, 'nnz')
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+    nnz = [int(rp[e] - rp[s]) for s, e in ranges]
+    assert max(nnz) - min(nnz) <= int((rp[1:] - rp[:-1]).max())  # balanced up to one row
+    for reduce in ('sum', 'mean', 'max'):
+        full = nat.spmm(rp, c, v, x, reduce)[0]
+        direct, halo = [], []
+        for s, e in ranges:
+            rpl, cl, vl = narrow_rows(rp, c, v, s, e)
+            direct.append(nat.spmm(rpl.contiguous(), cl, vl, x, reduce)[0])
+            needed = torch.unique(cl)                      # rows of X this block references
+            compact = torch.searchsorted(needed, cl)       # column ids = positions in the fetched rows
+            halo.append(nat.spmm(rpl.contiguous(), compact, vl, x[needed].contiguous(), reduce)[0])
+        if reduce == 'max':
+            assert torch.equal(torch.cat(direct), full) and torch.equal(torch.cat(halo), full)
+        else:
+            assert torch.allclose(torch.cat(direct), full, rtol=1e-5, atol=1e-5), reduce
+            assert torch.equal(torch.cat(halo), torch.cat(direct)), reduce  # same blocks, relabelled columns
