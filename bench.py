@@ -181,7 +181,8 @@ def main():
     value = synth.values(E, seed=1 + rank, device=dev)
     x_local = synth.features(m_local, F, seed=2 + rank, device=dev)
     import pytorch_sparse_amd  # noqa: F401  (registers torch.ops.torch_sparse.*)
-    from pytorch_sparse_amd.parallel import HaloShardedSpMM, PipelinedHaloSpMM, RowShardedSpMM
+    from pytorch_sparse_amd.parallel import (HaloShardedSpMM, RowShardedSpMM, build_with_fallback,
+                                             exchange_breakdown)
 
     def op_spmm(rp, c, v, x, reduce):
         # the drop-in path: the reference's own operator names, served by the HIP kernels
@@ -195,36 +196,12 @@ def main():
 
     x_sizes = [m_local] * world
 
-    def build(mode):  # plans the exchange once
-        if world > 1 and mode == 'pipelined':
-            return PipelinedHaloSpMM(rowptr, col, value, x_sizes, None, op_spmm, chunks=args.chunks)
-        if world > 1 and mode == 'halo':
-            return HaloShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm)
-        return RowShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm)
-
-    # The requested exchange first; if its planning or a trial step raises on ANY rank (the ranks
-    # agree through an all_reduce), fall back to the simpler ones and say so in the JSON line.
-    requested, fallback_reason = args.exchange, None
-    for mode in [requested] + [m for m in ('halo', 'allgather') if m != requested]:
-        err = None
-        try:
-            sharded = build(mode)
-            with torch.no_grad():
-                sharded(x_local, args.reduce)
-            torch.cuda.synchronize()
-        except Exception as exc:  # noqa: BLE001
-            err = '%s: %s' % (type(exc).__name__, str(exc)[:200])
-        failed = torch.tensor([0 if err is None else 1], device=dev)
-        if world > 1:
-            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-        if int(failed) == 0:
-            args.exchange = mode
-            break
-        fallback_reason = fallback_reason or ('%s failed (%s)' % (mode, err or 'on another rank'))
-        if world == 1:
-            raise RuntimeError(err)
-    else:
-        raise RuntimeError('no exchange mode works: %s' % fallback_reason)
+    # The requested exchange first; if its planning or a trial step raises on ANY rank, the ranks fall
+    # back together (pipelined -> halo -> allgather) and the JSON line says so.
+    requested = args.exchange
+    sharded, args.exchange, fallback_reason = build_with_fallback(
+        rowptr, col, value, x_sizes, x_local, args.reduce, op_spmm, requested, chunks=args.chunks,
+        sync=torch.cuda.synchronize)
     comm_rows = getattr(sharded, 'n_needed', n_global) if world > 1 else 0
 
     def step():
@@ -255,41 +232,14 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # N > 1: the exchange alone (one-shot fetch of the rows this rank's block references) and the
-    # local SpMM alone, timed after the headline region, next to the xGMI model of the exchange
+    # N > 1: the exchange alone and the local SpMM alone, timed after the headline region, next to the
+    # xGMI model of the exchange
     exchange_info = None
     if world > 1:
-        if isinstance(sharded, RowShardedSpMM):
-            fetch = lambda: sharded.gather(x_local)  # noqa: E731
-            rows_in = n_global - m_local
-        else:
-            plan = sharded if isinstance(sharded, HaloShardedSpMM) else ref_plan
-            fetch = lambda: plan.exchange(x_local)  # noqa: E731
-            rows_in = int(plan.n_needed - plan.recv_counts[rank])  # rows that cross a link
-        reps = max(3, min(args.steps, 10))
-        t_parts = []
-        for fn in (fetch, lambda: op_spmm(rowptr, col_k, value, x_full, args.reduce)):
-            with torch.no_grad():
-                fn()
-            torch.cuda.synchronize()
-            dist.barrier()
-            t1 = time.perf_counter()
-            with torch.no_grad():
-                for _ in range(reps):
-                    fn()
-            torch.cuda.synchronize()
-            dist.barrier()
-            t_parts.append((time.perf_counter() - t1) / reps * 1e3)
-        part = torch.tensor(t_parts + [float(rows_in)], dtype=torch.float64, device=dev)
-        dist.all_reduce(part, op=dist.ReduceOp.MAX)
-        bytes_in = float(part[2]) * F * 4
-        # every peer's share arrives over its own xGMI link (7 links x ~153 GB/s peak per GPU)
-        link_gbs = 153.0
-        exchange_info = dict(mode=args.exchange, exchange_only_ms=round(float(part[0]), 3),
-                             spmm_only_ms=round(float(part[1]), 3), max_rows_in_per_rank=int(part[2]),
-                             max_bytes_in_per_rank=int(bytes_in),
-                             modelled_exchange_ms=round(bytes_in / (world - 1) / (link_gbs * 1e9) * 1e3, 3),
-                             model='bytes_in / (N - 1) peers, each over its own xGMI link at %.0f GB/s peak' % link_gbs)
+        exchange_info = exchange_breakdown(
+            sharded, None if isinstance(sharded, (RowShardedSpMM, HaloShardedSpMM)) else ref_plan, x_local,
+            lambda: op_spmm(rowptr, col_k, value, x_full, args.reduce), n_global, F * 4,
+            reps=max(3, min(args.steps, 10)), sync=torch.cuda.synchronize)
 
     stats = torch.tensor([elapsed, float(E)], dtype=torch.float64, device=dev)
     if world > 1:

@@ -321,3 +321,83 @@ def shard_matrix(rowptr: Tensor, col: Tensor, value: Optional[Tensor], n_cols: i
     rp, c, v = narrow_rows(rowptr, col, value, s, e)
     cls = {'allgather': RowShardedSpMM, 'halo': HaloShardedSpMM, 'pipelined': PipelinedHaloSpMM}[exchange]
     return cls(rp, c, v, x_sizes, group, spmm_fn), (s, e)
+
+
+# ---------------------------------------------------------------------------------------------
+# orchestration helpers of the multi-GPU benchmark (bench.py); backend agnostic so that the control
+# flow is exercised by the gloo tests (tests/test_parallel_cpu.py)
+# ---------------------------------------------------------------------------------------------
+EXCHANGES = {'allgather': RowShardedSpMM, 'halo': HaloShardedSpMM, 'pipelined': PipelinedHaloSpMM}
+
+
+def build_with_fallback(rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
+                        x_local: Tensor, reduce: str, spmm_fn: Callable, requested: str, chunks: int = 8,
+                        group=None, sync: Optional[Callable] = None):
+    """Plan the requested exchange and run one trial step; if that raises (an unsupported collective,
+    an allocation that does not fit ...) the ranks agree through an all_reduce and fall back together:
+    requested -> halo -> allgather.  Meant for failures every rank hits at the same point; a rank that
+    dies in the middle of a collective sequence leaves its peers waiting, nothing recovers from that.
+    -> (sharded operator, mode actually used, None or the reason of the first fall-back)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    sync = sync or (lambda: None)
+    reason = None
+    for mode in [requested] + [m for m in ('halo', 'allgather') if m != requested]:
+        err = None
+        try:
+            cls = EXCHANGES[mode] if world > 1 else RowShardedSpMM
+            kw = dict(chunks=chunks) if cls is PipelinedHaloSpMM else {}
+            sharded = cls(rowptr, col, value, x_sizes, group, spmm_fn, **kw)
+            with torch.no_grad():
+                sharded(x_local, reduce)
+            sync()
+        except Exception as exc:  # noqa: BLE001
+            err = '%s: %s' % (type(exc).__name__, str(exc)[:200])
+        failed = torch.tensor([0 if err is None else 1], device=x_local.device)
+        if world > 1:
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=group)
+        if int(failed) == 0:
+            return sharded, mode, reason
+        reason = reason or ('%s failed (%s)' % (mode, err or 'on another rank'))
+        if world == 1:
+            raise RuntimeError(err)
+    raise RuntimeError('no exchange mode works: %s' % reason)
+
+
+def exchange_breakdown(sharded, ref_plan, x_local: Tensor, spmm_call: Callable, n_global: int,
+                       row_bytes: int, reps: int = 5, group=None, sync: Optional[Callable] = None,
+                       link_gbs: float = 153.0) -> dict:
+    """N > 1 only: time the exchange alone (one-shot fetch of the rows this rank's block references)
+    and the local SpMM alone (`spmm_call()`), max over ranks, and put the xGMI model of the exchange
+    next to it: every peer's share arrives over its own link at `link_gbs` GB/s peak."""
+    import time
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sync = sync or (lambda: None)
+    if isinstance(sharded, RowShardedSpMM):
+        fetch = lambda: sharded.gather(x_local)  # noqa: E731
+        rows_in = n_global - x_local.size(0)
+        mode = 'allgather'
+    else:
+        plan = sharded if isinstance(sharded, HaloShardedSpMM) else ref_plan
+        fetch = lambda: plan.exchange(x_local)  # noqa: E731
+        rows_in = int(plan.n_needed - plan.recv_counts[rank])  # rows that cross a link
+        mode = 'halo' if isinstance(sharded, HaloShardedSpMM) else 'pipelined'
+    t_parts = []
+    for fn in (fetch, spmm_call):
+        with torch.no_grad():
+            fn()
+        sync()
+        dist.barrier(group)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(reps):
+                fn()
+        sync()
+        dist.barrier(group)
+        t_parts.append((time.perf_counter() - t1) / reps * 1e3)
+    part = torch.tensor(t_parts + [float(rows_in)], dtype=torch.float64, device=x_local.device)
+    dist.all_reduce(part, op=dist.ReduceOp.MAX, group=group)
+    bytes_in = float(part[2]) * row_bytes
+    return dict(mode=mode, exchange_only_ms=round(float(part[0]), 3), spmm_only_ms=round(float(part[1]), 3),
+                max_rows_in_per_rank=int(part[2]), max_bytes_in_per_rank=int(bytes_in),
+                modelled_exchange_ms=round(bytes_in / (world - 1) / (link_gbs * 1e9) * 1e3, 3),
+                model='bytes_in / (N - 1) peers, each over its own xGMI link at %.0f GB/s peak' % link_gbs)

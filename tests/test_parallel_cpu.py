@@ -153,3 +153,90 @@ def test_bench_local_block_shapes():
                 share = torch.bincount(c // m, minlength=world).float() / c.numel()
                 assert (share > 0.5 / world).all()
     assert bench.b_alg(10, 4, 8, 4, True, False) == 10 * (8 + 4 + 32) + 5 * 8 + 4 * 8 * 4
+
+
+def _orchestration_worker(rank, world, port, q):
+    """The N > 1 control flow of bench.py (parallel.build_with_fallback / exchange_breakdown) on gloo:
+    same per-rank workload generator, the C oracle as the local multiply."""
+    import importlib.util
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pytorch_sparse_amd.parallel import (HaloShardedSpMM, RowShardedSpMM, build_with_fallback,
+                                                 exchange_breakdown)
+        spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(
+            os.path.abspath(__file__))), 'bench.py'))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        rp, c, m, n = bench.local_block(9, 8, world, rank, 'cpu')
+        v = synth.values(c.numel(), seed=1 + rank)
+        x_local = synth.features(m, 6, seed=2 + rank)
+        res = {}
+        # 1. the requested mode works: it is the one used, no fall-back reason
+        sharded, mode, reason = build_with_fallback(rp, c, v, [m] * world, x_local, 'sum', oracle_spmm, 'pipelined',
+                                                    chunks=3)
+        res['plain'] = (mode, reason, type(sharded).__name__)
+        ref = RowShardedSpMM(rp, c, v, [m] * world, None, oracle_spmm)(x_local, 'sum')
+        res['pipelined_equals_allgather'] = bool(torch.allclose(sharded(x_local, 'sum'), ref, rtol=1e-5, atol=1e-5))
+        ref_plan = HaloShardedSpMM(rp, c, v, [m] * world, None, oracle_spmm)
+        x_full = ref_plan.exchange(x_local)
+        info = exchange_breakdown(sharded, ref_plan, x_local, lambda: oracle_spmm(rp, ref_plan.col, v, x_full, 'sum'),
+                                  n, 6 * 4, reps=2)
+        res['info'] = info
+        res['rows_in_expected'] = int(ref_plan.n_needed - ref_plan.recv_counts[rank])
+
+        # 2. the pipelined step raises (on every rank, at the same point -- the case the hedge is for:
+        #    an unsupported collective / allocation failure; a one-sided failure in the middle of a
+        #    collective sequence cannot be recovered from): every rank falls back to the same mode
+        def flaky(rowptr, col, value, x, reduce):
+            if flaky.broken:
+                raise RuntimeError('injected failure')
+            return oracle_spmm(rowptr, col, value, x, reduce)
+        flaky.broken = True
+        sharded2, mode2, reason2 = None, None, None
+        HaloShardedSpMM_call = HaloShardedSpMM.__call__
+        try:
+            def halo_call(self, x, reduce='sum'):  # the local multiply works again for the simpler exchange
+                flaky.broken = False
+                return HaloShardedSpMM_call(self, x, reduce)
+            HaloShardedSpMM.__call__ = halo_call
+            sharded2, mode2, reason2 = build_with_fallback(rp, c, v, [m] * world, x_local, 'sum', flaky, 'pipelined',
+                                                           chunks=3)
+        finally:
+            HaloShardedSpMM.__call__ = HaloShardedSpMM_call
+        res['fallback'] = (mode2, reason2, type(sharded2).__name__)
+        res['fallback_result_ok'] = bool(torch.allclose(sharded2(x_local, 'sum'), ref, rtol=1e-5, atol=1e-5))
+        info2 = exchange_breakdown(sharded2, None, x_local, lambda: oracle_spmm(rp, sharded2.col, v, x_full, 'sum'),
+                                   n, 6 * 4, reps=1)
+        res['info2_mode'] = info2['mode']
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_orchestration_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_orchestration_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results.items():
+        assert res['plain'] == ('pipelined', None, 'PipelinedHaloSpMM'), res['plain']
+        assert res['pipelined_equals_allgather']
+        info = res['info']
+        assert info['mode'] == 'pipelined' and info['exchange_only_ms'] > 0 and info['spmm_only_ms'] > 0
+        assert info['max_bytes_in_per_rank'] == info['max_rows_in_per_rank'] * 24
+        assert info['modelled_exchange_ms'] >= 0
+        mode2, reason2, cls2 = res['fallback']
+        assert mode2 == 'halo' and cls2 == 'HaloShardedSpMM', res['fallback']
+        assert reason2.startswith('pipelined failed'), reason2
+        assert res['fallback_result_ok'] and res['info2_mode'] == 'halo'
+    # the reported maximum is the same on every rank and covers each rank's own count
+    assert results[0]['info']['max_rows_in_per_rank'] == results[1]['info']['max_rows_in_per_rank']
+    assert results[0]['info']['max_rows_in_per_rank'] == max(r['rows_in_expected'] for r in results.values())
+    assert all('injected failure' in r['fallback'][1] for r in results.values())
