@@ -124,6 +124,12 @@ def index_select(src: SparseTensor, dim: int, idx: Tensor) -> SparseTensor:
         _gpu(src)
         st = src.storage
         K = idx.size(0)
+        if K > 0 and bool(((idx[1:] > idx[:-1]).all() & (idx[0] >= 0) & (idx[-1] < src.sparse_size(1)))):
+            # strictly increasing ids (a sorted subset, e.g. nonzero(mask)): the selection keeps the
+            # stored order, so it is a column mask -- one compaction, no CSC view, no re-sort
+            mask = torch.zeros(src.sparse_size(1), dtype=torch.bool, device=idx.device)
+            mask[idx] = True
+            return masked_select(src, 1, mask)
         csr2csc = st.csr2csc()
         row_csc = st.row().index_select(0, csr2csc)
         colptr, col, row, pos = torch.ops.tsamd.select_segments(st.colptr(), row_csc, idx, True, True)

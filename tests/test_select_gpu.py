@@ -317,3 +317,19 @@ def test_select_with_long_runs_of_empty_rows(ts):
     _same(A.index_select(0, torch.from_numpy(pick).to(DEV)), S[pick])
     adj, n_id = A.sparse_resize((3_000_000, 3_000_000)).sample_adj(torch.from_numpy(pick[:100_000]).unique().to(DEV), -1)
     assert adj.nnz() == int(S[np.unique(pick[:100_000])].nnz)
+
+
+def test_index_select_cols_sorted_subset_fast_path(ts):
+    """Strictly increasing column ids take the order-preserving compaction; same result as scipy and
+    as the general CSC path (forced by repeating one id)."""
+    A, S, rng = _random(ts, 20_000, 30_000, 1_000_000, 14)
+    idx = np.sort(rng.choice(30_000, 12_000, replace=False))
+    out = A.index_select(1, torch.from_numpy(idx).to(DEV))
+    _same(out, S[:, idx])
+    assert not out.storage.has_csc2csr()          # came through the mask path
+    idx2 = np.concatenate([idx, idx[-1:]])         # not strictly increasing -> general path
+    out2 = A.index_select(1, torch.from_numpy(idx2).to(DEV))
+    _same(out2, S[:, idx2])
+    assert out2.storage.has_csc2csr()
+    with pytest.raises(IndexError):
+        A.index_select(1, torch.tensor([5, 30_000], device=DEV))
