@@ -380,6 +380,7 @@ Tensor segment_reduce(Tensor value, OptTensor perm, Tensor seg_ptr, int64_t nseg
   const int64_t D = value.size(0) > 0 ? value.numel() / value.size(0) : 1;
   sizes[0] = nseg;
   const int red = reduce_code(reduce);
+  if (E == 0) return torch::zeros(sizes, value.options().requires_grad(false));  // every segment is empty
   Tensor out = torch::empty(sizes, value.options().requires_grad(false));
   Tensor p = perm.has_value() ? perm.value().contiguous() : Tensor();
   const int64_t *pp = perm.has_value() ? p.data_ptr<int64_t>() : nullptr;

@@ -24,7 +24,9 @@ container (it cannot travel to the GPU box; the fixtures can).
   part 5  py5_*.npz             : multi-hop neighbor_sample (csrc/cpu/neighbor_sample_cpu.cpp), the
                                   take-all cases, on the CSC view of the part-4 graph.
 
-Usage:  python tests/golden/make_golden.py [part1] ... [part5]   (needs /root/reference)
+  part 6  py6_random_cases.npz  : 460 randomised small cases of the whole Python surface (cases6.py).
+
+Usage:  python tests/golden/make_golden.py [part1] ... [part6]   (needs /root/reference)
 """
 import os
 import subprocess
@@ -372,9 +374,59 @@ def part5():
     subprocess.check_call([sys.executable, '-c', PART5], env=env)
 
 
+PART6 = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ['TS_SCRATCH'])
+sys.path.insert(0, os.environ['TS_GOLDEN'])
+import torch_sparse
+import cases6
+out_dir = os.environ['TS_OUT']
+N = int(os.environ.get('TS_NCASES', '460'))
+blob, raised = {}, []
+for i in range(N):
+    c = cases6.make_case(i)
+    try:
+        outs = cases6.run_case(torch_sparse, c, 'cpu')
+    except Exception as e:
+        raised.append('%d:%s(%s)' % (i, c['op'], type(e).__name__))
+        continue
+    for k, v in c.items():
+        blob['c%d_%s' % (i, k)] = np.asarray(v)
+    for j, o in enumerate(outs):
+        blob['o%d_%d' % (i, j)] = o
+    blob['n%d' % i] = np.array(len(outs))
+np.savez_compressed(os.path.join(out_dir, 'py6_random_cases.npz'), **blob)
+print('part 6: %d random cases stored, the reference raised for %d: %s' % (N - len(raised), len(raised), ' '.join(raised)))
+"""
+
+
+def part6():
+    """py6_random_cases.npz: several hundred randomised small cases (tests/golden/cases6.py) through the
+    reference package."""
+    mods = ['transpose', 'coalesce', 'narrow', 'select', 'index_select', 'masked_select', 'permute', 'cat',
+            'diag', 'add', 'mul', 'reduce', 'matmul', 'sample', 'saint']
+    srcs = SPMM_SRCS + ('diag.cpp', 'cpu/diag_cpu.cpp', 'sample.cpp', 'cpu/sample_cpu.cpp', 'saint.cpp',
+                        'cpu/saint_cpu.cpp')
+    scratch, pkg = make_scratch(mods, srcs)
+    with open(os.path.join(pkg, '__init__.py'), 'w') as f:
+        f.write("import os, torch\n"
+                "torch.ops.load_library(os.path.join(os.path.dirname(__file__), '_ops_cpu.so'))\n"
+                "from .storage import SparseStorage\nfrom .tensor import SparseTensor\n"
+                "from .transpose import t\nfrom .narrow import narrow, __narrow_diag__\n"
+                "from .select import select\nfrom .index_select import index_select, index_select_nnz\n"
+                "from .masked_select import masked_select, masked_select_nnz\nfrom .permute import permute\n"
+                "from .diag import remove_diag, set_diag, fill_diag, get_diag\n"
+                "from .add import add, add_, add_nnz, add_nnz_\nfrom .mul import mul, mul_, mul_nnz, mul_nnz_\n"
+                "from .reduce import sum, mean, min, max\nfrom .matmul import matmul\nfrom .cat import cat\n"
+                "from .sample import sample, sample_adj\nfrom .saint import saint_subgraph\n"
+                "from .coalesce import coalesce\nfrom .transpose import transpose\n")
+    env = dict(os.environ, TS_SCRATCH=scratch, TS_OUT=HERE, TS_GOLDEN=HERE, OMP_NUM_THREADS='1')
+    subprocess.check_call([sys.executable, '-c', PART6], env=env)
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree %s not present' % REF)
-    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4', 'part5']
+    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4', 'part5', 'part6']
     for name in todo:  # e.g. `make_golden.py part3` regenerates only the py3_* fixtures
-        {'part1': part1, 'part2': part2, 'part3': part3, 'part4': part4, 'part5': part5}[name]()
+        {'part1': part1, 'part2': part2, 'part3': part3, 'part4': part4, 'part5': part5, 'part6': part6}[name]()
