@@ -11,7 +11,8 @@ import torch
 
 OPS = ['narrow', 'index_select', 'masked_select', 'remove_diag', 'set_diag', 'fill_diag', 'get_diag', 'cat',
        'permute', 'mul_dense', 'add_dense', 'add_sparse', 'mul_sparse', 'reduce', 'transpose', 'coalesce',
-       'masked_select_nnz', 'index_select_nnz', 'to_symmetric', 'getitem', 'saint', 'sample_all', 'eye_matmul']
+       'masked_select_nnz', 'index_select_nnz', 'to_symmetric', 'getitem', 'saint', 'sample_all', 'eye_matmul',
+       'f_spmm', 'f_coalesce', 'f_transpose', 'f_spspmm', 'matmul_grad']
 
 
 def _rand_matrix(rng, m, n, coalesced=True, vdim=None):
@@ -40,12 +41,14 @@ def make_case(seed):
     vdim = [None, 1, 1, 3][int(rng.integers(0, 4))]
     if op in ('mul_sparse', 'coalesce', 'reduce', 'eye_matmul') and vdim is None:
         vdim = 1
-    if op in ('reduce', 'eye_matmul', 'mul_sparse'):
+    if op in ('reduce', 'eye_matmul', 'mul_sparse', 'f_spmm', 'f_spspmm', 'matmul_grad'):
+        vdim = 1
+    if op in ('f_coalesce', 'f_transpose') and vdim is None:
         vdim = 1
     if op in ('mul_dense', 'add_dense') and vdim == 3:  # the reference's in-place broadcast rejects these
         vdim = 1
     # duplicates only where the reference's result does not depend on an unstable sort
-    coalesced = op not in ('coalesce', 'reduce', 'narrow') or rng.random() < 0.5
+    coalesced = op not in ('coalesce', 'reduce', 'narrow', 'f_spmm', 'f_coalesce') or rng.random() < 0.5
     A = _rand_matrix(rng, m, n, coalesced, vdim)
     c = dict(op=op, seed=seed, **{'A_' + k: v for k, v in A.items()})
     if op == 'narrow':
@@ -90,6 +93,16 @@ def make_case(seed):
         c.update(idx=rng.permutation(m)[:int(rng.integers(0, m + 1))].astype(np.int64))
     elif op == 'eye_matmul':
         c.update(x=(rng.integers(-4, 5, (n, 3)) / 2).astype(np.float32),
+                 reduce=['sum', 'mean', 'min', 'max'][int(rng.integers(0, 4))])
+    elif op in ('f_spmm', 'f_coalesce', 'f_transpose'):
+        c.update(shuffle=rng.permutation(A['row'].size).astype(np.int64), x=(rng.integers(-4, 5, (n, 2)) / 2).astype(np.float32),
+                 reduce=['add', 'mean', 'min', 'max'][int(rng.integers(0, 4))])
+    elif op == 'f_spspmm':
+        B = _rand_matrix(rng, n, int(rng.integers(1, 14)), True, 1)
+        c.update(**{'B_' + k: v for k, v in B.items()})
+    elif op == 'matmul_grad':
+        c.update(x=(rng.integers(-4, 5, (2, n, 3)) / 2).astype(np.float32),
+                 gout=(rng.integers(-4, 5, (2, m, 3)) / 2).astype(np.float32),
                  reduce=['sum', 'mean', 'min', 'max'][int(rng.integers(0, 4))])
     return c
 
@@ -169,4 +182,30 @@ def run_case(ts, c, device):
         return _dump(out) + [n_id.cpu().numpy()]
     if op == 'eye_matmul':
         return _dump(A.matmul(t(c['x']), reduce=str(c['reduce'])))
+    if op in ('f_spmm', 'f_coalesce', 'f_transpose'):  # functional API on raw, shuffled (index, value)
+        sh = t(c['shuffle'])
+        index = torch.stack([t(c['A_row'])[sh], t(c['A_col'])[sh]])
+        value = t(c['A_val'])[sh]
+        m, n = int(c['A_m']), int(c['A_n'])
+        if op == 'f_spmm':
+            return [ts.spmm(index, value, m, n, t(c['x'])).cpu().numpy()]
+        if op == 'f_coalesce':
+            oi, ov = ts.coalesce(index, value, m, n, op=str(c['reduce']))
+        else:
+            oi, ov = ts.transpose(index, value, m, n)
+        return [oi.cpu().numpy(), ov.cpu().numpy()]
+    if op == 'f_spspmm':
+        ia = torch.stack([t(c['A_row']), t(c['A_col'])])
+        ib = torch.stack([t(c['B_row']), t(c['B_col'])])
+        oi, ov = ts.spspmm(ia, t(c['A_val']), ib, t(c['B_val']), int(c['A_m']), int(c['A_n']), int(c['B_n']))
+        return [oi.cpu().numpy(), ov.cpu().numpy()]
+    if op == 'matmul_grad':
+        value = t(c['A_val']).clone().requires_grad_()
+        x = t(c['x']).clone().requires_grad_()
+        A2 = ts.SparseTensor(row=t(c['A_row']), col=t(c['A_col']), value=value,
+                             sparse_sizes=(int(c['A_m']), int(c['A_n'])), is_sorted=True)
+        out = A2.matmul(x, reduce=str(c['reduce']))
+        out.backward(t(c['gout']))
+        gv = value.grad if value.grad is not None else torch.zeros_like(value)
+        return [out.detach().cpu().numpy(), gv.cpu().numpy(), x.grad.cpu().numpy()]
     raise ValueError(op)

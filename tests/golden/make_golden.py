@@ -24,7 +24,7 @@ container (it cannot travel to the GPU box; the fixtures can).
   part 5  py5_*.npz             : multi-hop neighbor_sample (csrc/cpu/neighbor_sample_cpu.cpp), the
                                   take-all cases, on the CSC view of the part-4 graph.
 
-  part 6  py6_random_cases.npz  : 460 randomised small cases of the whole Python surface (cases6.py).
+  part 6  py6_random_cases.npz  : 672 randomised small cases of the whole Python surface (cases6.py).
 
 Usage:  python tests/golden/make_golden.py [part1] ... [part6]   (needs /root/reference)
 """
@@ -381,7 +381,7 @@ sys.path.insert(0, os.environ['TS_GOLDEN'])
 import torch_sparse
 import cases6
 out_dir = os.environ['TS_OUT']
-N = int(os.environ.get('TS_NCASES', '460'))
+N = int(os.environ.get('TS_NCASES', '672'))
 blob, raised = {}, []
 for i in range(N):
     c = cases6.make_case(i)
@@ -404,7 +404,7 @@ def part6():
     """py6_random_cases.npz: several hundred randomised small cases (tests/golden/cases6.py) through the
     reference package."""
     mods = ['transpose', 'coalesce', 'narrow', 'select', 'index_select', 'masked_select', 'permute', 'cat',
-            'diag', 'add', 'mul', 'reduce', 'matmul', 'sample', 'saint']
+            'diag', 'add', 'mul', 'reduce', 'matmul', 'sample', 'saint', 'spmm', 'spspmm']
     srcs = SPMM_SRCS + ('diag.cpp', 'cpu/diag_cpu.cpp', 'sample.cpp', 'cpu/sample_cpu.cpp', 'saint.cpp',
                         'cpu/saint_cpu.cpp')
     scratch, pkg = make_scratch(mods, srcs)
@@ -419,7 +419,8 @@ def part6():
                 "from .add import add, add_, add_nnz, add_nnz_\nfrom .mul import mul, mul_, mul_nnz, mul_nnz_\n"
                 "from .reduce import sum, mean, min, max\nfrom .matmul import matmul\nfrom .cat import cat\n"
                 "from .sample import sample, sample_adj\nfrom .saint import saint_subgraph\n"
-                "from .coalesce import coalesce\nfrom .transpose import transpose\n")
+                "from .coalesce import coalesce\nfrom .transpose import transpose\n"
+                "from .spmm import spmm\nfrom .spspmm import spspmm\n")
     env = dict(os.environ, TS_SCRATCH=scratch, TS_OUT=HERE, TS_GOLDEN=HERE, OMP_NUM_THREADS='1')
     subprocess.check_call([sys.executable, '-c', PART6], env=env)
 

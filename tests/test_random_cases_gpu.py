@@ -1,6 +1,6 @@
-"""460 randomised small cases of the whole Python surface (narrow / index_select / masked_select / diag /
+"""672 randomised small cases of the whole Python surface (narrow / index_select / masked_select / diag /
 cat / permute / element-wise / reductions / transpose / coalesce / to_symmetric / __getitem__ / SAINT /
-take-all sample_adj / matmul) against the outputs of the REFERENCE package on the same inputs
+take-all sample_adj / matmul forward and backward / the functional spmm, coalesce, transpose, spspmm) against the outputs of the REFERENCE package on the same inputs
 (tests/golden/py6_random_cases.npz, written by make_golden.py part 6 from tests/golden/cases6.py)."""
 import os
 import sys
@@ -33,13 +33,13 @@ def _case(i):
     return c, outs
 
 
-N_CASES = 460
+N_CASES = 672
 
 
-@pytest.mark.parametrize('chunk', range(0, N_CASES, 23))
+@pytest.mark.parametrize('chunk', range(0, N_CASES, 28))
 def test_random_cases_match_the_reference(chunk):
     import pytorch_sparse_amd as ts
-    for i in range(chunk, min(chunk + 23, N_CASES)):
+    for i in range(chunk, min(chunk + 28, N_CASES)):
         if ('n%d' % i) not in _blob():
             continue  # the reference raised for this draw
         c, want = _case(i)
