@@ -555,11 +555,18 @@ int ilog2_ceil(uint32_t x) {
   return l;
 }
 
-void plan_partition(int64_t M, int64_t E, int64_t *P, int64_t *items) {
+// Items (row ends + entries) per wave.  Same-box A/B on the north-star graph (scripts/variants.py,
+// TSAMD_ITEMS_MAX = 64..2048): 256 items beat 1024 by 5-18 % for rows up to 512 bytes (F = 16..128
+// fp32, every f16/bf16 width up to 256: more, shorter waves fill the machine better and the tail is
+// shorter), 1024 items beat 256 by 4-8 % for rows of 1 KB and more (F = 256/512 fp32: every partition
+// pays a K-wide carry record and a fix-up).  TSAMD_ITEMS_MAX caps both.
+void plan_partition(int64_t M, int64_t E, int64_t row_bytes, int64_t *P, int64_t *items) {
   const int64_t total = M + E > 0 ? M + E : 1;
+  int64_t cap = row_bytes <= 512 ? 256 : (row_bytes < 1024 ? 512 : 1024);
+  if (cap > TSAMD_ITEMS_MAX) cap = TSAMD_ITEMS_MAX;
   int64_t it = ceil_div(total, (int64_t)TSAMD_TARGET_WAVES);
   if (it < TSAMD_ITEMS_MIN) it = TSAMD_ITEMS_MIN;
-  if (it > TSAMD_ITEMS_MAX) it = TSAMD_ITEMS_MAX;
+  if (it > cap) it = cap;
   *items = it;
   *P = ceil_div(total, it);
 }
@@ -591,7 +598,7 @@ bool relabel_possible(int dtype, int64_t N, int64_t K, int64_t E) {
 size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,
              int64_t E, Workspace *ws) {
   int64_t P, items;
-  plan_partition(M, E, &P, &items);
+  plan_partition(M, E, K * (int64_t)dtype_size(dtype), &P, &items);
   const bool minmax = reduce == TSAMD_MIN || reduce == TSAMD_MAX;
   char *p = reinterpret_cast<char *>(base);
   size_t off = 0;
