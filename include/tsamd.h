@@ -287,6 +287,23 @@ int tsamd_filter_apply(const int64_t *pos, const int64_t *row, const int64_t *co
                        int64_t col_shift, int64_t *row_out, int64_t *col_out, int64_t *src_out,
                        void *stream);
 
+/* The same filter in two passes over the INPUTS instead of flags + positions per entry (what
+ * filter_coo uses; tsamd_filter_plan / _apply stay for callers that need the positions themselves:
+ * the mask rank map and the fused set_diag):
+ *   tsamd_filter_count  kept entries per 2048-entry tile -> exclusive scan in `workspace`, *count.
+ *   host reads *count, allocates.
+ *   tsamd_filter_write  re-evaluates the predicate (same arguments!) and writes the kept entries in
+ *                       input order at tile offset + rank inside the tile. */
+size_t tsamd_filter_tiles_workspace_bytes(int64_t n);
+int tsamd_filter_count(int pred, const int64_t *row, const int64_t *col, const uint8_t *mask,
+                       const int64_t *map, int64_t n, int64_t a, int64_t b, int64_t *count,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int tsamd_filter_write(int pred, const int64_t *row, const int64_t *col, const uint8_t *mask,
+                       const int64_t *map, int64_t n, int64_t a, int64_t b, const void *workspace,
+                       const int64_t *row_map, const int64_t *col_map, int64_t row_shift,
+                       int64_t col_shift, int64_t *row_out, int64_t *col_out, int64_t *src_out,
+                       void *stream);
+
 /* Column-wise concatenation without a sort (replaces the cat + re-sort of
  * torch_sparse/cat.py:117-165): entry i of one operand goes to slot i + delta[row[i]] of the
  * row-interleaved output, with  delta[r] = out_rowptr[r] + (entries of earlier operands in

@@ -27,6 +27,7 @@ SYMBOLS = [
     'tsamd_spspmm_rows', 'tsamd_spspmm_compact',
     'tsamd_select_workspace_bytes', 'tsamd_select_plan', 'tsamd_select_fill',
     'tsamd_filter_workspace_bytes', 'tsamd_filter_plan', 'tsamd_filter_apply',
+    'tsamd_filter_tiles_workspace_bytes', 'tsamd_filter_count', 'tsamd_filter_write',
     'tsamd_scatter_rows',
     'tsamd_num_diag', 'tsamd_non_diag_mask', 'tsamd_insert_diag', 'tsamd_set_diag_apply',
     'tsamd_random_walk', 'tsamd_sample_workspace_bytes', 'tsamd_sample_plan', 'tsamd_sample_draw',

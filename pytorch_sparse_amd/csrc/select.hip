@@ -240,6 +240,80 @@ __global__ void set_diag_fill_kernel(const int64_t *__restrict__ pos, const int6
   src_out[p] = E + j;
 }
 
+// ---- tile compaction: the same filter without an 8-byte flag / position per entry --------------
+// Pass 1 counts the kept entries of every 2048-entry tile, a scan over the (few) tile counts gives
+// each tile its output offset, pass 2 re-evaluates the predicate and places the kept entries in
+// input order (wave ballots + a 4-entry LDS prefix per 256-entry slice).  Traffic: the predicate's
+// inputs twice + the outputs once, against flags + scan + positions (5 x 8 B per entry) before.
+constexpr int kFilterTile = 2048;
+constexpr int kFilterSlices = kFilterTile / 256;
+
+__global__ __launch_bounds__(256) void filter_count_kernel(int pred, const int64_t *__restrict__ row,
+                                                           const int64_t *__restrict__ col,
+                                                           const uint8_t *__restrict__ mask,
+                                                           const int64_t *__restrict__ map, int64_t n,
+                                                           int64_t a, int64_t b, int64_t *__restrict__ tile_cnt) {
+  __shared__ int wsum[4];
+  const int64_t base = (int64_t)blockIdx.x * kFilterTile;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < kFilterSlices; ++j) {
+    const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
+    c += (i < n && keep_entry(pred, row, col, mask, map, i, a, b)) ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) c += lane_xor(c, off);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = (int64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void filter_write_kernel(
+    int pred, const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+    const uint8_t *__restrict__ mask, const int64_t *__restrict__ map, int64_t n, int64_t a, int64_t b,
+    const int64_t *__restrict__ tile_off, const int64_t *__restrict__ row_map,
+    const int64_t *__restrict__ col_map, int64_t row_shift, int64_t col_shift,
+    int64_t *__restrict__ row_out, int64_t *__restrict__ col_out, int64_t *__restrict__ src_out) {
+  __shared__ int wcnt[kFilterSlices][4];
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  const int64_t base = (int64_t)blockIdx.x * kFilterTile;
+  bool keep[kFilterSlices];
+  int before[kFilterSlices];  // kept entries of this wave's slice part in lower lanes
+#pragma unroll
+  for (int j = 0; j < kFilterSlices; ++j) {
+    const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
+    keep[j] = i < n && keep_entry(pred, row, col, mask, map, i, a, b);
+    const unsigned long long m = __ballot(keep[j]);
+    before[j] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[j][wave] = __popcll(m);
+  }
+  __syncthreads();
+  int64_t run = tile_off[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kFilterSlices; ++j) {
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int cw = wcnt[j][w];
+      wbase += w < wave ? cw : 0;
+      total += cw;
+    }
+    if (keep[j]) {
+      const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
+      const int64_t p = run + wbase + before[j];
+      if (row_out) {
+        const int64_t r = row[i];
+        row_out[p] = (row_map ? row_map[r] : r) - row_shift;
+      }
+      if (col_out) {
+        const int64_t c = col[i];
+        col_out[p] = (col_map ? col_map[c] : c) - col_shift;
+      }
+      if (src_out) src_out[p] = i;
+    }
+    run += total;
+  }
+}
+
 }  // namespace
 }  // namespace tsamd
 
@@ -404,5 +478,57 @@ extern "C" int tsamd_set_diag_apply(const int64_t *pos, const int64_t *row, cons
                        stream, pos, row, col, E, k, start, num_diag, row_out, col_out, src_out);
     TSAMD_LAUNCH_CHECK();
   }
+  return TSAMD_OK;
+}
+
+extern "C" size_t tsamd_filter_tiles_workspace_bytes(int64_t n) {
+  const int64_t tiles = ceil_div(n > 0 ? n : 1, (int64_t)kFilterTile);
+  return align_up(sizeof(int64_t) * (size_t)(tiles + 1), 256) + scan_workspace_bytes(tiles + 1);
+}
+
+static bool filter_args_ok(int pred, const int64_t *row, const int64_t *col, const uint8_t *mask,
+                           const int64_t *map, int64_t n) {
+  if (pred < TSAMD_KEEP_COL_RANGE || pred > TSAMD_KEEP_COL_MAPPED) return false;
+  const bool need_row = pred == TSAMD_KEEP_OFF_DIAG || pred == TSAMD_KEEP_MASK_ROW;
+  const bool need_col = pred == TSAMD_KEEP_COL_RANGE || pred == TSAMD_KEEP_OFF_DIAG ||
+                        pred == TSAMD_KEEP_MASK_COL || pred == TSAMD_KEEP_COL_MAPPED;
+  const bool need_mask = pred >= TSAMD_KEEP_MASK && pred <= TSAMD_KEEP_MASK_COL;
+  const bool need_map = pred == TSAMD_KEEP_COL_MAPPED;
+  return n == 0 || !((need_row && !row) || (need_col && !col) || (need_mask && !mask) || (need_map && !map));
+}
+
+extern "C" int tsamd_filter_count(int pred, const int64_t *row, const int64_t *col, const uint8_t *mask,
+                                  const int64_t *map, int64_t n, int64_t a, int64_t b, int64_t *count,
+                                  void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || !count) return TSAMD_ERR_INVALID;
+  if (pred < TSAMD_KEEP_COL_RANGE || pred > TSAMD_KEEP_COL_MAPPED) return TSAMD_ERR_UNSUPPORTED;
+  if (!filter_args_ok(pred, row, col, mask, map, n)) return TSAMD_ERR_INVALID;
+  if (!workspace || workspace_bytes < tsamd_filter_tiles_workspace_bytes(n)) return TSAMD_ERR_WORKSPACE;
+  const int64_t tiles = ceil_div(n > 0 ? n : 1, (int64_t)kFilterTile);
+  int64_t *tile_off = reinterpret_cast<int64_t *>(workspace);
+  void *scan_ws = reinterpret_cast<char *>(workspace) + align_up(sizeof(int64_t) * (size_t)(tiles + 1), 256);
+  TSAMD_HIP_TRY(hipMemsetAsync(tile_off + tiles, 0, sizeof(int64_t), stream));
+  hipLaunchKernelGGL(filter_count_kernel, dim3((unsigned int)tiles), dim3(256), 0, stream, pred, row, col,
+                     mask, map, n, a, b, tile_off);
+  TSAMD_LAUNCH_CHECK();
+  return exclusive_scan_i64(tile_off, tile_off, tiles + 1, count, scan_ws, stream);
+}
+
+extern "C" int tsamd_filter_write(int pred, const int64_t *row, const int64_t *col, const uint8_t *mask,
+                                  const int64_t *map, int64_t n, int64_t a, int64_t b,
+                                  const void *workspace, const int64_t *row_map, const int64_t *col_map,
+                                  int64_t row_shift, int64_t col_shift, int64_t *row_out,
+                                  int64_t *col_out, int64_t *src_out, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || !workspace) return TSAMD_ERR_INVALID;
+  if (n == 0) return TSAMD_OK;
+  if (!filter_args_ok(pred, row, col, mask, map, n) || (row_out && !row) || (col_out && !col))
+    return TSAMD_ERR_INVALID;
+  const int64_t tiles = ceil_div(n, (int64_t)kFilterTile);
+  hipLaunchKernelGGL(filter_write_kernel, dim3((unsigned int)tiles), dim3(256), 0, stream, pred, row, col,
+                     mask, map, n, a, b, reinterpret_cast<const int64_t *>(workspace), row_map, col_map,
+                     row_shift, col_shift, row_out, col_out, src_out);
+  TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }

@@ -591,11 +591,10 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> filter_coo(std::string pred, OptTens
                                    ws0.data_ptr(), (size_t)ws0.numel(), stream),
                  "tsamd_filter_plan");
   }
-  Tensor pos = torch::empty({n + 1}, iopt);
-  Tensor ws = workspace(tsamd_filter_workspace_bytes(n), like);
-  check_status(tsamd_filter_plan(code, rp, cp, mp, nullptr, n, a, b, pos.data_ptr<int64_t>(),
-                                 cnt.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
-               "tsamd_filter_plan");
+  Tensor ws = workspace(tsamd_filter_tiles_workspace_bytes(n), like);
+  check_status(tsamd_filter_count(code, rp, cp, mp, nullptr, n, a, b, cnt.data_ptr<int64_t>(), ws.data_ptr(),
+                                  (size_t)ws.numel(), stream),
+               "tsamd_filter_count");
   Tensor h = cnt.cpu();  // the one sync
   const int64_t kept = h.data_ptr<int64_t>()[0];
   const int64_t n_mask = remap ? h.data_ptr<int64_t>()[1] : -1;
@@ -604,13 +603,13 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> filter_coo(std::string pred, OptTens
   Tensor src = torch::empty({kept}, iopt);
   const int64_t *map = remap ? rank.data_ptr<int64_t>() : nullptr;
   check_status(
-      tsamd_filter_apply(pos.data_ptr<int64_t>(), rp, cp, n,
+      tsamd_filter_write(code, rp, cp, mp, nullptr, n, a, b, ws.data_ptr(),
                          code == TSAMD_KEEP_MASK_ROW ? map : nullptr,
                          code == TSAMD_KEEP_MASK_COL ? map : nullptr, row_shift, col_shift,
                          want_row ? row_out.data_ptr<int64_t>() : nullptr,
                          want_col ? col_out.data_ptr<int64_t>() : nullptr, src.data_ptr<int64_t>(),
                          stream),
-      "tsamd_filter_apply");
+      "tsamd_filter_write");
   return std::make_tuple(row_out, col_out, src, n_mask);
 }
 
