@@ -880,20 +880,20 @@ std::tuple<Tensor, Tensor, Tensor> induced_entries(Tensor idx, Tensor ptr, Tenso
   auto sel = select_segments(ptr, ind, idx, true, true);  // sync 1 (raises on bad ids)
   Tensor seg = std::get<1>(sel), nbr = std::get<2>(sel), pos = std::get<3>(sel);
   const int64_t T = nbr.numel();
-  Tensor keep = torch::empty({T + 1}, iopt), cnt = torch::empty({1}, iopt);
-  Tensor ws = workspace(tsamd_filter_workspace_bytes(T), ptr);
-  check_status(tsamd_filter_plan(TSAMD_KEEP_COL_MAPPED, nullptr, nbr.data_ptr<int64_t>(), nullptr,
-                                 assoc.data_ptr<int64_t>(), T, 0, 0, keep.data_ptr<int64_t>(),
-                                 cnt.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
-               "tsamd_filter_plan");
+  Tensor cnt = torch::empty({1}, iopt);
+  Tensor ws = workspace(tsamd_filter_tiles_workspace_bytes(T), ptr);
+  check_status(tsamd_filter_count(TSAMD_KEEP_COL_MAPPED, nullptr, nbr.data_ptr<int64_t>(), nullptr,
+                                  assoc.data_ptr<int64_t>(), T, 0, 0, cnt.data_ptr<int64_t>(), ws.data_ptr(),
+                                  (size_t)ws.numel(), stream),
+               "tsamd_filter_count");
   const int64_t kept = cnt.item<int64_t>();  // sync 2
   Tensor seg_out = torch::empty({kept}, iopt), map_out = torch::empty({kept}, iopt);
   Tensor src = torch::empty({kept}, iopt);
-  check_status(tsamd_filter_apply(keep.data_ptr<int64_t>(), seg.data_ptr<int64_t>(),
-                                  nbr.data_ptr<int64_t>(), T, nullptr, assoc.data_ptr<int64_t>(), 0, 0,
-                                  seg_out.data_ptr<int64_t>(), map_out.data_ptr<int64_t>(),
-                                  src.data_ptr<int64_t>(), stream),
-               "tsamd_filter_apply");
+  check_status(tsamd_filter_write(TSAMD_KEEP_COL_MAPPED, seg.data_ptr<int64_t>(), nbr.data_ptr<int64_t>(),
+                                  nullptr, assoc.data_ptr<int64_t>(), T, 0, 0, ws.data_ptr(), nullptr,
+                                  assoc.data_ptr<int64_t>(), 0, 0, seg_out.data_ptr<int64_t>(),
+                                  map_out.data_ptr<int64_t>(), src.data_ptr<int64_t>(), stream),
+               "tsamd_filter_write");
   return std::make_tuple(seg_out, map_out, pos.index_select(0, src));
 }
 
