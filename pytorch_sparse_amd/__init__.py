@@ -6,6 +6,14 @@ Drop-in surface (same names and argument meaning as ``torch_sparse``):
     SparseStorage, SparseTensor, matmul, spmm, spspmm, coalesce, transpose, t
     torch.ops.torch_sparse.{spmm_sum, spmm_mean, spmm_min, spmm_max, ind2ptr, ptr2ind, cuda_version}
 
+and, widening along SURVEY.md section 8f (the callers either side of that path):
+
+    sum / mean / min / max, mul / add (+ _ / _nnz variants), remove_diag / set_diag / fill_diag / get_diag,
+    narrow, select, index_select(_nnz), masked_select(_nnz), permute, cat, SparseTensor.__getitem__,
+    sample, sample_adj, random_walk, saint_subgraph, reverse_cuthill_mckee, eye, spadd, converters
+    torch.ops.torch_sparse.{non_diag_mask, sample_adj, neighbor_sample, random_walk, saint_subgraph,
+                            relabel, relabel_one_hop}
+
 Everything computes in hand-written HIP kernels (``lib/libtsamd.so``, C-ABI in ``include/tsamd.h``)
 reached through the torch operator library ``lib/_tsamd_ops.so``.  There is no CPU compute path:
 importing without the built libraries, or calling with CPU tensors, raises.

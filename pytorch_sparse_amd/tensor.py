@@ -1,10 +1,11 @@
 """SparseTensor: the object API over SparseStorage (reference: torch_sparse/tensor.py).
 
 Covers construction, format views (coo/csr/csc), caches, dtype/device plumbing, dense and
-torch.sparse conversions, and -- patched in by the sibling modules -- ``matmul/spmm/spspmm/@``,
-``t()`` and ``coalesce()``.  Indexing, slicing, concatenation, diagonal edits, samplers and
-partitioners of the reference are outside this package's scope and raise
-``NotImplementedError``.
+torch.sparse conversions, and -- attached by the sibling modules, as the reference does --
+``matmul/spmm/spspmm/@``, ``t()``, ``coalesce()``, reductions, element-wise ``mul/add``, diagonal
+edits, ``narrow/select/index_select/masked_select/permute/[]``, ``sample/sample_adj``,
+``random_walk``, ``saint_subgraph`` and ``reverse_cuthill_mckee``.  Not provided: the heterogeneous /
+temporal samplers and the METIS partitioner.
 """
 from typing import List, Optional, Tuple, Union
 
