@@ -63,6 +63,7 @@ from .sample import sample, sample_adj  # noqa: E402
 from .rw import random_walk  # noqa: E402
 from .saint import saint_subgraph  # noqa: E402
 from .bandwidth import reverse_cuthill_mckee  # noqa: E402
+from .metis import partition  # noqa: E402
 from .convert import to_torch_sparse, from_torch_sparse, to_scipy, from_scipy, eye, spadd  # noqa: E402
 
 __all__ = [
@@ -70,6 +71,6 @@ __all__ = [
     'sum', 'mean', 'min', 'max', 'mul', 'mul_', 'mul_nnz', 'mul_nnz_', 'add', 'add_', 'add_nnz',
     'add_nnz_', 'narrow', '__narrow_diag__', 'select', 'index_select', 'index_select_nnz',
     'masked_select', 'masked_select_nnz', 'permute', 'cat', 'remove_diag', 'set_diag', 'fill_diag',
-    'get_diag', 'sample', 'sample_adj', 'random_walk', 'saint_subgraph', 'reverse_cuthill_mckee', 'to_torch_sparse', 'from_torch_sparse', 'to_scipy', 'from_scipy', 'eye', 'spadd',
+    'get_diag', 'sample', 'sample_adj', 'random_walk', 'saint_subgraph', 'reverse_cuthill_mckee', 'partition', 'to_torch_sparse', 'from_torch_sparse', 'to_scipy', 'from_scipy', 'eye', 'spadd',
     '__version__',
 ]

@@ -86,6 +86,23 @@ def test_api_surface():
         assert hasattr(pytorch_sparse_amd.SparseTensor, m), m
 
 
+def test_every_name_the_reference_exports_is_there():
+    """torch_sparse/__init__.py:68-113 (`__all__`), verbatim."""
+    ref_all = ['SparseStorage', 'SparseTensor', 't', 'narrow', '__narrow_diag__', 'select', 'index_select',
+               'index_select_nnz', 'masked_select', 'masked_select_nnz', 'permute', 'remove_diag', 'set_diag',
+               'fill_diag', 'get_diag', 'add', 'add_', 'add_nnz', 'add_nnz_', 'mul', 'mul_', 'mul_nnz', 'mul_nnz_',
+               'sum', 'mean', 'min', 'max', 'matmul', 'cat', 'random_walk', 'partition', 'reverse_cuthill_mckee',
+               'saint_subgraph', 'to_torch_sparse', 'from_torch_sparse', 'to_scipy', 'from_scipy', 'coalesce',
+               'transpose', 'eye', 'spmm', 'spspmm', 'spadd', '__version__']
+    missing = [n for n in ref_all if not hasattr(pytorch_sparse_amd, n)]
+    assert not missing, missing
+    import pytest
+    B = pytorch_sparse_amd.SparseTensor(row=torch.tensor([0, 1]), col=torch.tensor([0, 0]), is_sorted=True)
+    assert pytorch_sparse_amd.partition(B, 1)[0] is B
+    with pytest.raises(RuntimeError, match='METIS'):
+        pytorch_sparse_amd.partition(B, 2)
+
+
 def test_view_ops_need_no_kernel():
     """narrow(0) / cat(0) / cat((0,1)) on a CSR-holding tensor are views and memcpys: they work on host
     tensors too (that is how a loader process cuts the row shards before the upload)."""
