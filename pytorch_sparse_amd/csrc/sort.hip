@@ -20,8 +20,11 @@ namespace tsamd {
 namespace {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortItems = 8;
-constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 pairs per workgroup
+#ifndef TSAMD_SORT_ITEMS
+#define TSAMD_SORT_ITEMS 16
+#endif
+constexpr int kSortItems = TSAMD_SORT_ITEMS;
+constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 pairs per workgroup (A/B: 4 / 8 / 12 / 16 items -> 0.83 / 0.61 / 0.58 / 0.56 ms for 7.5 M pairs)
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 
