@@ -122,12 +122,22 @@ int tsamd_spmm_value_bw(int dtype, int reduce, const int64_t *row,
  *
  * grad_value ([E] dtype) and grad_mat ([B,N,K] dtype) may each be NULL (not
  * requested).  Both are fully defined on return (zero where nothing lands).
- * f16/bf16 accumulate through an fp32 workspace.
+ *
+ * rowptr [M+1] is the CSR pointer of the forward call (the reference's backward does
+ * not need it; here it lets grad_value be accumulated per row in LDS and written with
+ * plain stores -- no atomics, no memset).  It may be NULL when grad_value is NULL.
+ * grad_mat is accumulated with hardware atomics (it is a scatter into the transposed
+ * pattern, which this op does not receive): fp32 / fp64 global_atomic_add; f16 / bf16
+ * packed global_atomic_pk_add on the final buffer, i.e. one rounding per addition like the
+ * reference's own narrow-type scatter_add_, in a non-deterministic order.  Odd K (or
+ * TSAMD_MINMAX_BW_SHADOW=1) accumulates narrow types in an fp32 workspace instead and
+ * rounds once; tsamd_spmm_minmax_bw_workspace_bytes() says how much that takes (0
+ * otherwise).
  * ------------------------------------------------------------------------ */
 size_t tsamd_spmm_minmax_bw_workspace_bytes(int dtype, int64_t B, int64_t N,
                                             int64_t K, int64_t E);
-int tsamd_spmm_minmax_bw(int dtype, const int64_t *col, const void *value,
-                         const void *mat, const void *grad_out,
+int tsamd_spmm_minmax_bw(int dtype, const int64_t *rowptr, const int64_t *col,
+                         const void *value, const void *mat, const void *grad_out,
                          const int64_t *arg_out, void *grad_value, void *grad_mat,
                          int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
                          void *workspace, size_t workspace_bytes, void *stream);

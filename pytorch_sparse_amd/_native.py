@@ -163,9 +163,10 @@ def spmm_value_bw(row, rowptr, col, mat, grad, reduce):
     return out
 
 
-def spmm_minmax_bw(col, value, mat, grad_out, arg_out, want_value=True, want_mat=True):
-    """C-ABI ``tsamd_spmm_minmax_bw``: (grad_value or None, grad_mat or None)."""
-    require_gpu(col, value, mat, grad_out, arg_out)
+def spmm_minmax_bw(rowptr, col, value, mat, grad_out, arg_out, want_value=True, want_mat=True):
+    """C-ABI ``tsamd_spmm_minmax_bw``: (grad_value or None, grad_mat or None).  ``rowptr`` may be
+    None when ``want_value`` is False."""
+    require_gpu(rowptr, col, value, mat, grad_out, arg_out)
     dt = dtype_code(mat.dtype)
     mat, grad_out, arg_out = mat.contiguous(), grad_out.contiguous(), arg_out.contiguous()
     E = col.numel()
@@ -178,7 +179,7 @@ def spmm_minmax_bw(col, value, mat, grad_out, arg_out, want_value=True, want_mat
     nb = L.tsamd_spmm_minmax_bw_workspace_bytes(dt, _i64(B), _i64(N), _i64(K), _i64(E))
     ws = workspace(nb, mat.device)
     with torch.cuda.device(mat.device):
-        st = L.tsamd_spmm_minmax_bw(dt, _ptr(col), _ptr(value), _ptr(mat), _ptr(grad_out),
+        st = L.tsamd_spmm_minmax_bw(dt, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(grad_out),
                                     _ptr(arg_out), _ptr(gv), _ptr(gm), _i64(B), _i64(M), _i64(N),
                                     _i64(K), _i64(E), _ptr(ws), ctypes.c_size_t(ws.numel()),
                                     stream_ptr(mat.device))

@@ -8,6 +8,7 @@
 //    (csrc/spmm.cpp:204-242, 264-302) with one fused pass.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace tsamd {
@@ -111,53 +112,222 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_value_bw_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// min/max backward: one thread per output element (b, m, k).
+// min/max backward (csrc/spmm.cpp:204-242, 264-302 of the reference):
+//   for every (b, m, k) with a = arg_out[b,m,k] != E:
+//     grad_value[a]          += mat[b, col[a], k] * grad_out[b,m,k]
+//     grad_mat[b, col[a], k] += value[a] * grad_out[b,m,k]
+//
+// grad_mat is a scatter into rows of OTHER nodes (the transposed pattern, which the op does not
+// receive), so it needs hardware atomics, and on MI355X a device-scope atomic is priced per
+// 64-BYTE SEGMENT an instruction touches: 49 ps each (20 G segments/s for the whole device),
+// whether 1 or 16 lanes fall into it, fp32 and packed bf16 alike (scripts/ubench/atomics.hip,
+// profiles/r02_ubench_atomics.csv).  The kernel is therefore laid out to touch every
+// (output row, winning entry, 64-byte segment of the target row) exactly once:
+//   * lane l of a wave owns feature k = tile * 64 + l of one output row, so that one atomic
+//     instruction covers 64 CONSECUTIVE features (a thread-pair layout (2l, 2l+1) with one
+//     instruction per pair member touches every segment twice: measured 3.4 vs 2.3 ms);
+//   * f16 / bf16 go straight into the final buffer with global_atomic_pk_add_{f16,bf16} (a
+//     256-byte row is 4 segments instead of the 8 of an fp32 shadow, no memset of the shadow, no
+//     narrowing pass): the lane adds its value in its half of the aligned 4-byte word and +0 in
+//     the other half; when both halves of a word go to the same entry the even lane adds both.
+//     This is the reference's own arithmetic class (its scatter_add_ accumulates in the narrow
+//     type, one rounding per add) in a non-deterministic order.  TSAMD_MINMAX_BW_SHADOW=1 (and
+//     buffers that are not 4-byte aligned) use the fp32 shadow, rounded once;
+//   * kBwRows rows x 2 feature tiles are in flight per wave so that the dependent chain
+//     arg -> col[arg] -> atomic is overlapped; every row has exactly K elements, so the work is
+//     balanced whatever the degrees are.
+// grad_value targets are the row's OWN entries: contributions are summed in a per-wave LDS array
+// indexed by (arg - rowptr[m]) (ds_add_f32) and every entry of the row is written once with a
+// plain store -- no global atomics, no memset.  Rows longer than the LDS array take several
+// passes over their (L2-resident) args.
 // ---------------------------------------------------------------------------
-template <typename ACC>
-__device__ inline ACC wave_sum(ACC v) {
-  for (int off = 32; off > 0; off >>= 1) v += lane_xor(v, off);
-  return v;
+constexpr int kBwRows = 2;     // row groups in flight per wave
+constexpr int kBwTiles = 2;    // 64-feature tiles in flight per row
+constexpr int kBwSlots = 512;  // LDS accumulator slots per wave (grad_value)
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void atomic_add_elem(float *p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_elem(double *p, double v) { atomicAdd(p, v); }
+// p must be 4-byte aligned; `bits` holds two narrow values (low half = lower address)
+__device__ __forceinline__ void atomic_add_pair(bf16_t *p, uint32_t bits) {
+  short2v v;
+  v.x = (short)(bits & 0xFFFFu);
+  v.y = (short)(bits >> 16);
+  __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) short2v *)p, v);
+}
+__device__ __forceinline__ void atomic_add_pair(f16_t *p, uint32_t bits) {
+  union {
+    uint32_t u;
+    half2v h;
+  } c;
+  c.u = bits;
+  __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2v *)p, c.h);
+}
+__device__ __forceinline__ uint32_t narrow_bits(bf16_t v) { return v.bits; }
+__device__ __forceinline__ uint32_t narrow_bits(f16_t v) {
+  union {
+    f16_t h;
+    uint16_t u;
+  } c;
+  c.h = v;
+  return c.u;
+}
+// value held by the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], no LDS traffic
+__device__ __forceinline__ uint32_t neighbour(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
-// One thread per output element (b, m, k).  grad_mat targets are distinct within a wave
-// (same row, consecutive k), so they go out as plain atomics.  grad_value targets repeat a lot
-// (the same neighbour usually wins many features of a row): equal targets are summed inside
-// the wave first, one atomic per distinct edge, instead of up to 64 same-address atomics.
-template <typename T, typename ACC>
-__global__ void spmm_minmax_bw_kernel(const int64_t *__restrict__ col, const T *__restrict__ value,
-                                      const T *__restrict__ mat, const T *__restrict__ grad_out,
-                                      const int64_t *__restrict__ arg_out, ACC *__restrict__ gval,
-                                      ACC *__restrict__ gmat, int64_t M, int64_t N, int64_t K,
-                                      int64_t E, int64_t total) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// TM = element type of the grad_mat accumulator: T itself (fp32 / fp64 per-element atomics,
+// packed atomics for f16 / bf16) or float (fp32 shadow of a narrow type).
+template <typename T, typename TM, bool GMAT, bool GVAL>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_minmax_bw_kernel(
+    const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
+    const T *__restrict__ value, const T *__restrict__ mat, const T *__restrict__ grad_out,
+    const int64_t *__restrict__ arg_out, T *__restrict__ gval, TM *__restrict__ gmat, int64_t B,
+    int64_t M, int64_t N, uint32_t K, int64_t E, int lgG) {
+  using A = typename Traits<T>::acc_t;
+  constexpr bool kPacked = Traits<T>::kNarrow && std::is_same<T, TM>::value;
+  __shared__ A slots_[GVAL ? kWavesPerBlock * kBwSlots : 1];
   const int lane = (int)(threadIdx.x & 63);
-  int64_t a = E;
-  if (i < total) a = arg_out[i];
-  const bool valid = a != E;  // empty row / no winner: masked out (spmm.cpp:210)
-  ACC contrib = ACC(0);
-  if (valid) {
-    const int64_t k = i % K;
-    const int64_t b = i / (M * K);
-    const int64_t c = col[a];
-    const ACC g = (ACC)Traits<T>::to_acc(grad_out[i]);
-    const uint64_t xoff = ((uint64_t)b * N + c) * K + k;
-    if (gval != nullptr) contrib = (ACC)Traits<T>::to_acc(mat[xoff]) * g;
-    if (gmat != nullptr) {
-      const ACC v = value != nullptr ? (ACC)Traits<T>::to_acc(value[a]) : ACC(1);
-      atomicAdd(&gmat[xoff], v * g);
+  const int wib = (int)(threadIdx.x >> 6);
+  const int lpr = 64 >> lgG;  // lanes per row: 64 for K >= 64 (then G = 1 and K is tiled)
+  const int g = lane >> (6 - lgG);
+  const int kl = lane & (lpr - 1);
+  const uint32_t ktiles = (K + (uint32_t)lpr - 1) / (uint32_t)lpr;
+  const int cap = kBwSlots / kBwRows >> lgG;  // LDS slots per row in flight
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+  const bool merge_pairs = kPacked && (K & 1u) == 0;  // word mates = lanes (2j, 2j+1) of one row
+
+  int64_t m[kBwRows], rs[kBwRows], deg[kBwRows];
+  bool ok[kBwRows];
+#pragma unroll
+  for (int r = 0; r < kBwRows; ++r) {
+    m[r] = ((unit * kBwRows + r) << lgG) + g;
+    ok[r] = m[r] < M;
+    rs[r] = 0;
+    deg[r] = 0;
+    if (GVAL && ok[r]) {
+      rs[r] = rowptr[m[r]];
+      deg[r] = rowptr[m[r] + 1] - rs[r];
     }
   }
-  if (gval == nullptr) return;
-  unsigned long long todo = __ballot(valid);
-  while (todo) {  // wave-uniform loop over the distinct targets
-    const int leader = __ffsll((long long)todo) - 1;
-    const int64_t a0 = lane_read(a, leader);
-    const bool mine = valid && a == a0;
-    const unsigned long long same = __ballot(mine);
-    ACC s = contrib;
-    if (__popcll(same) > 1) s = wave_sum<ACC>(mine ? contrib : ACC(0));
-    if (lane == leader) atomicAdd(&gval[a0], s);
-    todo &= ~same;
+
+  for (int64_t c0 = 0;; c0 += cap) {  // passes over the row's entries (one unless deg > cap)
+    A *slot[kBwRows];
+    if constexpr (GVAL) {
+#pragma unroll
+      for (int r = 0; r < kBwRows; ++r) {
+        slot[r] = slots_ + wib * kBwSlots + ((r << lgG) + g) * cap;
+        const int64_t n = deg[r] - c0 < cap ? deg[r] - c0 : cap;
+        for (int i = kl; i < n; i += lpr) slot[r][i] = A(0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    const bool scatter = GMAT && c0 == 0;
+    for (int64_t b = 0; b < B; ++b) {
+      for (uint32_t t0 = 0; t0 < ktiles; t0 += kBwTiles) {
+        int64_t a[kBwRows][kBwTiles];
+        T go[kBwRows][kBwTiles];
+        uint32_t kk[kBwTiles];
+#pragma unroll
+        for (int u = 0; u < kBwTiles; ++u) kk[u] = (t0 + u) * (uint32_t)lpr + (uint32_t)kl;
+#pragma unroll
+        for (int r = 0; r < kBwRows; ++r) {
+#pragma unroll
+          for (int u = 0; u < kBwTiles; ++u) {
+            a[r][u] = E;
+            go[r][u] = Traits<T>::from_acc(A(0));
+            if (ok[r] && kk[u] < K) {
+              const uint64_t off = ((uint64_t)b * M + (uint64_t)m[r]) * K + kk[u];
+              a[r][u] = arg_out[off];
+              go[r][u] = grad_out[off];
+            }
+          }
+        }
+        uint32_t c[kBwRows][kBwTiles];
+        A w[kBwRows][kBwTiles];
+#pragma unroll
+        for (int r = 0; r < kBwRows; ++r) {
+#pragma unroll
+          for (int u = 0; u < kBwTiles; ++u) {
+            const bool valid = a[r][u] != E;  // empty row / no winner: masked out (spmm.cpp:210)
+            c[r][u] = valid ? (uint32_t)col[a[r][u]] : 0u;
+            w[r][u] = A(1);
+            if (scatter && value != nullptr && valid) w[r][u] = Traits<T>::to_acc(value[a[r][u]]);
+          }
+        }
+        if constexpr (GVAL) {
+          A x[kBwRows][kBwTiles];
+#pragma unroll
+          for (int r = 0; r < kBwRows; ++r) {
+#pragma unroll
+            for (int u = 0; u < kBwTiles; ++u) {
+              const bool valid = a[r][u] != E;
+              x[r][u] = valid ? Traits<T>::to_acc(mat[((uint64_t)b * N + c[r][u]) * K + kk[u]]) : A(0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < kBwRows; ++r) {
+#pragma unroll
+            for (int u = 0; u < kBwTiles; ++u) {
+              const int64_t rel = a[r][u] - rs[r] - c0;
+              if (a[r][u] != E && rel >= 0 && rel < cap)
+                atomicAdd(&slot[r][rel], x[r][u] * Traits<T>::to_acc(go[r][u]));
+            }
+          }
+        }
+        if (scatter) {
+#pragma unroll
+          for (int r = 0; r < kBwRows; ++r) {
+#pragma unroll
+            for (int u = 0; u < kBwTiles; ++u) {
+              const bool valid = a[r][u] != E;
+              const uint64_t idx = ((uint64_t)b * N + c[r][u]) * K + kk[u];
+              if constexpr (kPacked) {
+                // the reference rounds the product to the narrow type before it is accumulated
+                uint32_t bits = narrow_bits(Traits<T>::from_acc(w[r][u] * Traits<T>::to_acc(go[r][u])));
+                bool mine = valid;
+                if (merge_pairs) {  // wave-uniform
+                  const uint32_t alo = (uint32_t)(uint64_t)a[r][u], ahi = (uint32_t)((uint64_t)a[r][u] >> 32);
+                  const uint32_t nlo = neighbour(alo), nhi = neighbour(ahi), nbits = neighbour(bits);
+                  const bool same = valid && nlo == alo && nhi == ahi;  // the mate is valid as well then
+                  if (same) {
+                    if (lane & 1) mine = false;          // the even lane adds both halves
+                    else bits |= nbits << 16;
+                  } else if (lane & 1) {
+                    bits <<= 16;
+                  }
+                } else if (idx & 1) {
+                  bits <<= 16;
+                }
+                if (mine) atomic_add_pair(gmat + (idx & ~(uint64_t)1), bits);
+              } else {
+                if (valid) atomic_add_elem(gmat + idx, (TM)(w[r][u] * Traits<T>::to_acc(go[r][u])));
+              }
+            }
+          }
+        }
+      }
+    }
+    if constexpr (!GVAL) {
+      break;
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      bool more = false;
+#pragma unroll
+      for (int r = 0; r < kBwRows; ++r) {
+        const int64_t n = deg[r] - c0 < cap ? deg[r] - c0 : cap;
+        for (int i = kl; i < n; i += lpr) gval[rs[r] + c0 + i] = Traits<T>::from_acc(slot[r][i]);
+        more = more || deg[r] > c0 + cap;
+      }
+      if (!__any(more)) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -200,16 +370,26 @@ int dispatch_value_bw(bool vec_ok, const int64_t *row, const int64_t *rowptr, co
   return launch_value_bw<T, 1>(row, rowptr, col, x, g, o, B, M, N, K, E, mean, stream);
 }
 
-template <typename T, typename ACC>
-int launch_minmax_bw(const int64_t *col, const void *value, const void *mat, const void *grad_out,
-                     const int64_t *arg_out, ACC *gval, ACC *gmat, int64_t B, int64_t M, int64_t N,
-                     int64_t K, int64_t E, hipStream_t stream) {
-  const int64_t total = B * M * K;
-  if (total == 0) return TSAMD_OK;
-  hipLaunchKernelGGL((spmm_minmax_bw_kernel<T, ACC>), dim3((unsigned int)ceil_div(total, 256)),
-                     dim3(256), 0, stream, col, reinterpret_cast<const T *>(value),
-                     reinterpret_cast<const T *>(mat), reinterpret_cast<const T *>(grad_out),
-                     arg_out, gval, gmat, M, N, K, E, total);
+template <typename T, typename TM>
+int launch_minmax_bw(const int64_t *rowptr, const int64_t *col, const void *value, const void *mat,
+                     const void *grad_out, const int64_t *arg_out, void *gval, TM *gmat, int64_t B,
+                     int64_t M, int64_t N, int64_t K, int64_t E, hipStream_t stream) {
+  if (B * M * K == 0) return TSAMD_OK;
+  const uint32_t lpr = K >= 64 ? 64u : (1u << ilog2_ceil((uint32_t)K));
+  const int lgG = 6 - ilog2_ceil(lpr);
+  const int64_t rows_per_wave = (int64_t)kBwRows << lgG;
+  const unsigned int blocks = (unsigned int)ceil_div(ceil_div(M, rows_per_wave), kWavesPerBlock);
+  const T *v = reinterpret_cast<const T *>(value), *x = reinterpret_cast<const T *>(mat),
+          *g = reinterpret_cast<const T *>(grad_out);
+  T *gv = reinterpret_cast<T *>(gval);
+#define TSAMD_BW_GO(GMAT, GVAL)                                                                     \
+  hipLaunchKernelGGL((spmm_minmax_bw_kernel<T, TM, GMAT, GVAL>), dim3(blocks),                      \
+                     dim3(kWavesPerBlock *kWave), 0, stream, rowptr, col, v, x, g, arg_out, gv, gmat, \
+                     B, M, N, (uint32_t)K, E, lgG)
+  if (gmat != nullptr && gv != nullptr) TSAMD_BW_GO(true, true);
+  else if (gmat != nullptr) TSAMD_BW_GO(true, false);
+  else if (gv != nullptr) TSAMD_BW_GO(false, true);
+#undef TSAMD_BW_GO
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }
@@ -255,55 +435,82 @@ extern "C" int tsamd_spmm_value_bw(int dtype, int reduce, const int64_t *row,
   });
 }
 
+// f16 / bf16 grad_mat: packed atomics on the final buffer unless TSAMD_MINMAX_BW_SHADOW=1 asks for
+// the fp32 shadow (round once; costs a memset, fp32 atomics on twice as many 64-byte segments and a
+// narrowing pass over [B,N,K]).
+static bool minmax_bw_shadow(int dtype) {
+  if (dtype != TSAMD_F16 && dtype != TSAMD_BF16) return false;
+  const char *env = getenv("TSAMD_MINMAX_BW_SHADOW");
+  return env != nullptr && env[0] == '1';
+}
+
 extern "C" size_t tsamd_spmm_minmax_bw_workspace_bytes(int dtype, int64_t B, int64_t N, int64_t K,
                                                        int64_t E) {
-  if (dtype == TSAMD_F16 || dtype == TSAMD_BF16)
-    return align_up(sizeof(float) * (size_t)E, 256) + align_up(sizeof(float) * (size_t)(B * N * K), 256);
+  (void)E;
+  if (minmax_bw_shadow(dtype)) return align_up(sizeof(float) * (size_t)(B * N * K), 256);
   return 0;
 }
 
-extern "C" int tsamd_spmm_minmax_bw(int dtype, const int64_t *col, const void *value,
-                                    const void *mat, const void *grad_out, const int64_t *arg_out,
-                                    void *grad_value, void *grad_mat, int64_t B, int64_t M,
-                                    int64_t N, int64_t K, int64_t E, void *workspace,
-                                    size_t workspace_bytes, void *stream_) {
+namespace {
+template <typename T>
+int run_minmax_bw(const int64_t *rowptr, const int64_t *col, const void *value, const void *mat,
+                  const void *grad_out, const int64_t *arg_out, void *grad_value, void *grad_mat,
+                  float *shadow_mat, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
+                  hipStream_t stream) {
+  if constexpr (Traits<T>::kNarrow) {
+    if (shadow_mat != nullptr || grad_mat == nullptr)
+      return launch_minmax_bw<T, float>(rowptr, col, value, mat, grad_out, arg_out, grad_value,
+                                        shadow_mat, B, M, N, K, E, stream);
+  }
+  return launch_minmax_bw<T, T>(rowptr, col, value, mat, grad_out, arg_out, grad_value,
+                                reinterpret_cast<T *>(grad_mat), B, M, N, K, E, stream);
+}
+}  // namespace
+
+extern "C" int tsamd_spmm_minmax_bw(int dtype, const int64_t *rowptr, const int64_t *col,
+                                    const void *value, const void *mat, const void *grad_out,
+                                    const int64_t *arg_out, void *grad_value, void *grad_mat,
+                                    int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
+                                    void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (dtype != TSAMD_F32 && dtype != TSAMD_F64 && dtype != TSAMD_F16 && dtype != TSAMD_BF16)
     return TSAMD_ERR_UNSUPPORTED;
+  if (N >= (int64_t)1 << 32 || K >= (int64_t)1 << 31) return TSAMD_ERR_UNSUPPORTED;
   const int64_t total = B * M * K;
   if (total > 0 && (!col || !mat || !grad_out || !arg_out)) return TSAMD_ERR_INVALID;
+  if (grad_value && E > 0 && !rowptr) return TSAMD_ERR_INVALID;  // grad_value is laid out by rows
   const size_t es = dtype_size(dtype);
   const size_t nmat = (size_t)(B * N * K);
-  if (dtype == TSAMD_F32 || dtype == TSAMD_F64) {
-    if (grad_value) TSAMD_HIP_TRY(hipMemsetAsync(grad_value, 0, es * (size_t)E, stream));
-    if (grad_mat) TSAMD_HIP_TRY(hipMemsetAsync(grad_mat, 0, es * nmat, stream));
-    if (dtype == TSAMD_F32)
-      return launch_minmax_bw<float, float>(col, value, mat, grad_out, arg_out,
-                                            reinterpret_cast<float *>(grad_value),
-                                            reinterpret_cast<float *>(grad_mat), B, M, N, K, E, stream);
-    return launch_minmax_bw<double, double>(col, value, mat, grad_out, arg_out,
-                                            reinterpret_cast<double *>(grad_value),
-                                            reinterpret_cast<double *>(grad_mat), B, M, N, K, E, stream);
+  const bool narrow = dtype == TSAMD_F16 || dtype == TSAMD_BF16;
+  bool shadow = narrow && grad_mat && minmax_bw_shadow(dtype);
+  // packed atomics work on aligned 4-byte words inside the buffer
+  if (narrow && grad_mat && !shadow && (((uintptr_t)grad_mat % 4) != 0 || (nmat % 2) != 0)) shadow = true;
+  float *shadow_mat = nullptr;
+  if (shadow) {
+    const size_t need = align_up(sizeof(float) * nmat, 256);
+    if (!workspace || workspace_bytes < need) return TSAMD_ERR_WORKSPACE;
+    shadow_mat = reinterpret_cast<float *>(workspace);
+    TSAMD_HIP_TRY(hipMemsetAsync(shadow_mat, 0, sizeof(float) * nmat, stream));
+  } else if (grad_mat) {
+    TSAMD_HIP_TRY(hipMemsetAsync(grad_mat, 0, es * nmat, stream));
   }
-  // narrow types: accumulate in an fp32 workspace, round once
-  const size_t need = tsamd_spmm_minmax_bw_workspace_bytes(dtype, B, N, K, E);
-  if (!workspace || workspace_bytes < need) return TSAMD_ERR_WORKSPACE;
-  float *wv = reinterpret_cast<float *>(workspace);
-  float *wm = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
-                                        align_up(sizeof(float) * (size_t)E, 256));
-  TSAMD_HIP_TRY(hipMemsetAsync(workspace, 0, need, stream));
-  int st;
-  if (dtype == TSAMD_F16) {
-    st = launch_minmax_bw<f16_t, float>(col, value, mat, grad_out, arg_out, grad_value ? wv : nullptr,
-                                        grad_mat ? wm : nullptr, B, M, N, K, E, stream);
-    if (st == TSAMD_OK && grad_value) st = narrow_out<f16_t>(wv, grad_value, E, stream);
-    if (st == TSAMD_OK && grad_mat) st = narrow_out<f16_t>(wm, grad_mat, (int64_t)nmat, stream);
-  } else {
-    st = launch_minmax_bw<bf16_t, float>(col, value, mat, grad_out, arg_out, grad_value ? wv : nullptr,
-                                         grad_mat ? wm : nullptr, B, M, N, K, E, stream);
-    if (st == TSAMD_OK && grad_value) st = narrow_out<bf16_t>(wv, grad_value, E, stream);
-    if (st == TSAMD_OK && grad_mat) st = narrow_out<bf16_t>(wm, grad_mat, (int64_t)nmat, stream);
+  if (total == 0 || (!grad_value && !grad_mat)) {
+    if (grad_value && E > 0) TSAMD_HIP_TRY(hipMemsetAsync(grad_value, 0, es * (size_t)E, stream));
+    return TSAMD_OK;
   }
-  return st;
+  int st = TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
+    if constexpr (std::is_integral<scalar_t>::value) {
+      return (int)TSAMD_ERR_UNSUPPORTED;
+    } else {
+      return run_minmax_bw<scalar_t>(rowptr, col, value, mat, grad_out, arg_out, grad_value, grad_mat,
+                                     shadow_mat, B, M, N, K, E, stream);
+    }
+  });
+  if (st != TSAMD_OK) return st;
+  if (shadow_mat) {
+    if (dtype == TSAMD_F16) return narrow_out<f16_t>(shadow_mat, grad_mat, (int64_t)nmat, stream);
+    return narrow_out<bf16_t>(shadow_mat, grad_mat, (int64_t)nmat, stream);
+  }
+  return TSAMD_OK;
 }

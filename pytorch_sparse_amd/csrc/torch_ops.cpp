@@ -67,6 +67,8 @@ Tensor workspace(size_t bytes, const Tensor &like) {
                       like.options().dtype(torch::kUInt8).requires_grad(false));
 }
 
+void check_index(const Tensor &t, const char *name);
+
 const void *ptr_or_null(const OptTensor &t) { return t.has_value() ? t.value().data_ptr() : nullptr; }
 
 int reduce_code(const std::string &r) {
@@ -131,11 +133,15 @@ Tensor spmm_value_bw(const Tensor &row, const Tensor &rowptr, const Tensor &col,
   c10::hip::HIPGuard guard(rowptr.get_device());
   mat = mat.contiguous();
   grad = grad.contiguous();
+  check_index(rowptr, "rowptr");
+  check_index(col, "col");
+  check_index(row, "row");
+  Tensor rp = rowptr.contiguous(), c = col.contiguous(), r = row.contiguous();
   const int64_t M = grad.size(-2), N = mat.size(-2), K = mat.size(-1), E = col.numel();
   const int64_t B = (N * K) > 0 ? mat.numel() / (N * K) : 1;
   Tensor out = torch::empty({E}, grad.options().requires_grad(false));
-  check_status(tsamd_spmm_value_bw(dtype_code(mat), reduce_code(reduce), row.data_ptr<int64_t>(),
-                                   rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+  check_status(tsamd_spmm_value_bw(dtype_code(mat), reduce_code(reduce), r.data_ptr<int64_t>(),
+                                   rp.data_ptr<int64_t>(), c.data_ptr<int64_t>(),
                                    mat.data_ptr(), grad.data_ptr(), out.data_ptr(), B, M, N, K, E,
                                    current_stream(mat)),
                "tsamd_spmm_value_bw");
@@ -208,7 +214,9 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
     auto res = spmm_fw(rowptr, col, v, mat, is_max ? "max" : "min");
     Tensor out = std::get<0>(res), arg_out = std::get<1>(res).value();
     ctx->saved_data["has_value"] = has_value;
-    ctx->save_for_backward({col, value, mat, arg_out});
+    // the reference saves {col, value, mat, arg_out} (spmm.cpp:199); rowptr is kept as well so that
+    // grad_value can be accumulated row by row (tsamd.h)
+    ctx->save_for_backward({col, value, mat, arg_out, rowptr});
     ctx->mark_non_differentiable({arg_out});
     return {out, arg_out};
   }
@@ -217,7 +225,8 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
     const bool has_value = ctx->saved_data["has_value"].toBool();
     Tensor grad_out = grad_outs[0].contiguous();
     auto s = ctx->get_saved_variables();
-    Tensor col = s[0], value = s[1], mat = s[2].contiguous(), arg_out = s[3];
+    Tensor col = s[0].contiguous(), value = s[1].contiguous(), mat = s[2].contiguous(),
+           arg_out = s[3].contiguous(), rowptr = s[4].contiguous();
     const bool want_value = has_value && needs_grad(value);
     const bool want_mat = needs_grad(mat);
     Tensor grad_value, grad_mat;
@@ -230,7 +239,8 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
       const int dt = dtype_code(mat);
       Tensor ws = workspace(tsamd_spmm_minmax_bw_workspace_bytes(dt, B, N, K, E), mat);
       check_status(
-          tsamd_spmm_minmax_bw(dt, col.data_ptr<int64_t>(), has_value ? value.data_ptr() : nullptr,
+          tsamd_spmm_minmax_bw(dt, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                               has_value ? value.data_ptr() : nullptr,
                                mat.data_ptr(), grad_out.data_ptr(), arg_out.data_ptr<int64_t>(),
                                want_value ? grad_value.data_ptr() : nullptr,
                                want_mat ? grad_mat.data_ptr() : nullptr, B, M, N, K, E,

@@ -37,7 +37,7 @@ if 'c3' in which:
         t_fw = gpu_time(lambda: nat.spmm(rp, c, v, x, 'max'))
         out, arg = nat.spmm(rp, c, v, x, 'max')
         g = synth.features(n, K, seed=3, dtype=torch.bfloat16, device=dev)
-        t_bw = gpu_time(lambda: nat.spmm_minmax_bw(c, v, x, g, arg, want_value=has_value, want_mat=True))
+        t_bw = gpu_time(lambda: nat.spmm_minmax_bw(rp, c, v, x, g, arg, want_value=has_value, want_mat=True))
         balg = E * (8 + (2 if has_value else 0) + K * 2) + (n + 1) * 8 + n * K * 2 + n * K * 8
         print(json.dumps(dict(bench='c3_spmm_max_bf16', has_value=has_value, E=E, F=K, fw_ms=round(t_fw, 3), bw_ms=round(t_bw, 3),
                               gedges_fw=round(E / t_fw / 1e6, 2), balg_gbs=round(balg / t_fw / 1e6, 1), frac_hbm=round(balg / t_fw / 1e6 / 8000, 3))), flush=True)

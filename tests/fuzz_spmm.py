@@ -107,7 +107,7 @@ def main():
                     err = np.abs(got.cpu().double().numpy() - ex)
                     assert (err <= SUM_TOL[dtype] * l1 + SUM_ATOL[dtype]).all(), 'value_bw'
                 else:
-                    gv, gm = nat.spmm_minmax_bw(ct.to(dev), None if v is None else v.to(dev), x.to(dev), gout.to(dev),
+                    gv, gm = nat.spmm_minmax_bw(rpt.to(dev), ct.to(dev), None if v is None else v.to(dev), x.to(dev), gout.to(dev),
                                                 arg, want_value=has_value, want_mat=True)
                     egv, egm = oc.spmm_minmax_bw(oc.F64, c, None if v is None else v.double().numpy(),
                                                  x.double().numpy(), gout.double().numpy(), arg.cpu().numpy(),

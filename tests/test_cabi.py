@@ -86,7 +86,7 @@ def test_argument_validation_returns_status_codes():
                                  i64(4), None) == 2  # only sum / mean have a value gradient
     assert L.tsamd_spmm_value_bw(4, 0, None, fake, fake, fake, fake, fake, i64(1), i64(4), i64(4), i64(4),
                                  i64(4), None) == 2  # integer dtypes have no gradient
-    assert L.tsamd_spmm_minmax_bw(5, fake, None, fake, fake, fake, fake, fake, i64(1), i64(4), i64(4), i64(4),
+    assert L.tsamd_spmm_minmax_bw(5, fake, fake, None, fake, fake, fake, fake, fake, i64(1), i64(4), i64(4), i64(4),
                                   i64(4), None, sz(0), None) == 2
     assert L.tsamd_ind2ptr(None, i64(4), i64(3), fake, None) == 1
     assert L.tsamd_sort_coo(fake, fake, i64(5), i64(1 << 40), i64(1 << 40), None, None, fake, fake,
