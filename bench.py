@@ -19,7 +19,11 @@ Rank 0 prints ONE JSON line (see README/DESIGN.md for the field meanings).  Timi
 steps, then K steps between barrier + torch.cuda.synchronize() on both sides, max over ranks.
 `roofline` is measured live on the SpMM merge kernel with HIP events on the launch stream
 (tsamd_spmm_profiled); `cpu_baseline` times the reference's own CPU kernel (oracle/_ref, built
-from /root/reference) on the host cores -- rank 0, N = 1 only.
+from /root/reference) on the host cores -- rank 0, N = 1 only -- and its output is compared with
+the WHOLE GPU output (`cpu_baseline.parity`).  At N = 1 the default run also carries
+  `control`    the same kernel on a uniform-degree graph of the same size (load balance vs bandwidth)
+  `secondary`  BASELINE.json configs C2 / C3 / C4 at their stated size, each with ms, roofline,
+               cpu_baseline and whole-output parity (tests/baseline_configs.py; --no-secondary skips).
 """
 import argparse
 import json
@@ -49,6 +53,12 @@ def b_alg(E, M, K, esize, has_value, minmax):
         (M * K * 8 if minmax else 0)
 
 
+def b_min(E, M, N, K, esize, has_value, minmax):
+    """Compulsory bytes: every operand read once, the result written once."""
+    return E * (8 + (esize if has_value else 0)) + (M + 1) * 8 + N * K * esize + M * K * esize + \
+        (M * K * 8 if minmax else 0)
+
+
 def local_block(scale, edge_factor, world, rank, device):
     """Rank-local row block: 2**scale rows, columns over all world * 2**scale vertices (R-MAT)."""
     from pytorch_sparse_amd import synth
@@ -70,78 +80,61 @@ def local_block(scale, edge_factor, world, rank, device):
     return rowptr, col, m, n
 
 
-def cpu_baseline(rowptr, col, value, x, reduce, out=None):
-    """The cpu_baseline leg -- the ONLY place bench.py touches oracle/: times the reference CPU kernel
-    (oracle/_ref) on the host cores, bounded to <~ 30 s, and (given the GPU result `out`) spot-checks
-    rows of the timed configuration against the C oracle."""
-    res = _cpu_baseline_timing(rowptr, col, value, x, reduce)
-    if out is not None and reduce in ('sum', 'mean'):
-        worst = parity_sample(rowptr, col, value, x, out, reduce)
-        res['parity'] = dict(rows_checked=50, max_err_over_l1=worst, tol=1e-5, ok=worst <= 1e-5)
+def cpu_baseline(rowptr, col, value, x, reduce, out):
+    """The cpu_baseline leg -- the ONLY place bench.py touches oracle/ (through
+    tests/baseline_configs.py): times the reference CPU kernel (oracle/_ref) on all host cores on the
+    full workload and on ONE core on the first 1/32 of the rows, and compares its output with the
+    whole GPU output."""
+    from tests import baseline_configs as bc
+    cores = os.cpu_count() or 1
+    rp, c, v, xx = rowptr.cpu(), col.cpu(), value.cpu(), x.cpu()
+    E, M = c.numel(), rp.numel() - 1
+    torch.set_num_threads(cores)
+    best, (ref_out, _, kind), runs = bc.cpu_time(lambda: bc.ref_spmm_cpu(rp, c, v, xx, reduce))
+    res = dict(value=round(E / best / 1e9, 4), unit='GEdges/s', cores=cores, kind=kind, ms=round(best * 1e3, 2),
+               sample='full workload (%d edges), %s, %d OpenMP threads, best of %d' % (
+                   E, 'compiled /root/reference csrc/cpu/spmm_cpu.cpp via oracle/_ref' if kind == 'reference'
+                   else 'C restatement oracle/ts_oracle.c', cores, runs))
+    ms1 = M // 32
+    e1 = int(rp[ms1])
+    torch.set_num_threads(1)
+    t1, _, _ = bc.cpu_time(lambda: bc.ref_spmm_cpu(rp[:ms1 + 1].contiguous(), c[:e1], v[:e1], xx, reduce),
+                           budget_s=10.0, max_reps=1)
+    torch.set_num_threads(cores)
+    res['one_thread'] = dict(value=round(e1 / t1 / 1e9, 4), unit='GEdges/s', cores=1, ms=round(t1 * 1e3, 2),
+                             sample='first 1/32 of the rows (%d edges)' % e1)
+    if reduce == 'sum':
+        res['parity'] = bc.sum_parity(out, rp, c, v, xx, ref_out)
     return res
 
 
-def _cpu_baseline_timing(rowptr, col, value, x, reduce):
-    cores = os.cpu_count() or 1
-    rp, c, v, xx = rowptr.cpu(), col.cpu(), value.cpu(), x.cpu()
-    E = c.numel()
-    try:
-        from oracle import ref
-        have_ref = ref.available()
-    except Exception:
-        have_ref = False
-    if have_ref:
-        r = ref.ops()
-        torch.set_num_threads(cores)
-        fn = {'sum': lambda: r.spmm_sum(None, rp, c, v, None, None, xx),
-              'mean': lambda: r.spmm_mean(None, rp, c, v, None, None, None, xx),
-              'min': lambda: r.spmm_min(rp, c, v, xx), 'max': lambda: r.spmm_max(rp, c, v, xx)}[reduce]
-        t0 = time.perf_counter()
-        fn()
-        first = time.perf_counter() - t0
-        best = first
-        reps = 0
-        while reps < 3 and (reps + 2) * first < 25.0:
-            t0 = time.perf_counter()
-            fn()
-            best = min(best, time.perf_counter() - t0)
-            reps += 1
-        return dict(value=round(E / best / 1e9, 4), unit='GEdges/s', cores=cores, kind='reference',
-                    sample='full workload (%d edges), compiled /root/reference csrc/cpu/spmm_cpu.cpp via '
-                           'oracle/_ref, %d OpenMP threads, best of %d' % (E, cores, reps + 1),
-                    ms=round(best * 1e3, 2))
-    # scalar C port on a row sample
-    from oracle import c_oracle as oc
-    M = rp.numel() - 1
-    ms = max(1, M // 16)
-    e1 = int(rp[ms])
-    t0 = time.perf_counter()
-    oc.spmm(oc.F32, reduce, rp[:ms + 1].numpy(), c[:e1].numpy(), v[:e1].numpy(), xx.numpy())
-    dt = time.perf_counter() - t0
-    return dict(value=round(e1 / dt / 1e9, 4), unit='GEdges/s', cores=1, kind='port',
-                sample='first 1/16 of the rows (%d edges), scalar C oracle' % e1, ms=round(dt * 1e3, 2))
+def secondary(dev, cpu=True):
+    """BASELINE.json configs[1..3] at their stated size (tests/baseline_configs.py): C2, C3 (value-less and
+    with values, forward + backward), C4 -- each with ms, roofline, cpu_baseline and whole-output parity."""
+    from tests import baseline_configs as bc
+    res = []
+    for fn in (lambda: bc.run_c2(dev, cpu=cpu), lambda: bc.run_c3(dev, False, cpu=cpu),
+               lambda: bc.run_c3(dev, True, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu)):
+        try:
+            res.append(fn())
+        except Exception as exc:  # a failing secondary must not take the headline down
+            res.append(dict(error='%s: %s' % (type(exc).__name__, exc)))
+        torch.cuda.empty_cache()
+    return res
 
 
-def parity_sample(rowptr, col, value, x, out, reduce, nrows=48):
-    """Spot-check rows of the timed configuration against the C oracle (fp32 rel 1e-5)."""
-    import numpy as np
-    from oracle import c_oracle as oc
-    M = rowptr.numel() - 1
-    deg = rowptr[1:] - rowptr[:-1]
-    rows = torch.cat([torch.topk(deg, 2).indices.cpu(),
-                      torch.randint(0, M, (nrows, ), generator=torch.Generator().manual_seed(0))]).unique()
-    rp = rowptr[torch.stack([rows, rows + 1], 1).to(rowptr.device)].cpu()
-    xc = x.cpu().numpy()
-    worst = 0.0
-    for i, r in enumerate(rows.tolist()):
-        s, e = int(rp[i, 0]), int(rp[i, 1])
-        c = col[s:e].cpu().numpy()
-        v = value[s:e].cpu().numpy()
-        ex, _ = oc.spmm(oc.F64, reduce, [0, e - s], c, v.astype(np.float64), xc.astype(np.float64))
-        l1, _ = oc.spmm(oc.F64, 'sum', [0, e - s], c, np.abs(v).astype(np.float64), np.abs(xc).astype(np.float64))
-        err = np.abs(out[r].cpu().double().numpy() - ex[0])
-        worst = max(worst, float((err / (l1[0] + 1e-30)).max()))
-    return worst
+def control_graph(m, deg, F, dev, nat):
+    """Uniform-degree control: exactly `deg` entries per row, uniform columns -- the same
+    kernel without load imbalance, hub reuse or channel camping."""
+    from pytorch_sparse_amd import synth
+    from tests import baseline_configs as bc
+    rp, c = synth.uniform_degree_csr(m, m, deg, seed=5, device=dev)
+    v = synth.values(c.numel(), seed=6, device=dev)
+    x = synth.features(m, F, seed=7, device=dev)
+    ms = bc.gpu_ms(lambda: nat.spmm(rp, c, v, x, 'sum'), iters=10)
+    ba = b_alg(c.numel(), m, F, 4, True, False)
+    return dict(graph='uniform degree %d, uniform columns, %d rows' % (deg, m), edges=c.numel(), ms=round(ms, 4),
+                gedges_per_s=round(c.numel() / ms / 1e6, 3), balg_over_peak=round(ba / ms / 1e6 / HBM_PEAK_GBS, 4))
 
 
 def main():
@@ -152,6 +145,7 @@ def main():
     ap.add_argument('--workload', default='ns', choices=sorted(WORKLOADS))
     ap.add_argument('--reduce', default='sum', choices=['sum', 'mean', 'min', 'max'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the C2 / C3 / C4 entries (N = 1 only)')
     ap.add_argument('--exchange', default='pipelined', choices=['pipelined', 'halo', 'allgather'],
                     help='N > 1: all_gather of X | halo = all_to_all of the referenced rows only | '
                          'pipelined = halo exchange in row pieces, overlapped with the SpMM of the previous piece')
@@ -265,21 +259,35 @@ def main():
         k_ms = sum(merge_ms) / len(merge_ms)
         balg = b_alg(E, m_local, F, 4, True, minmax)
         achieved = balg / (k_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic needs PMC counters (rocprofv3 --pmc, its own run): read from the committed
+        # summary of the same command, and say so
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+                tj = json.load(open(tfile))
+                traffic = tj.get('hbm_bytes_per_launch')
+                traffic_source = 'profiles/traffic_%s.json (%s), NOT measured in this run' % (
+                    args.workload, tj.get('source', 'rocprofv3 --pmc, builder run'))
             except Exception:
                 traffic = None
+        bmin = b_min(E, m_local, n_global, F, 4, True, minmax)
         roofline = dict(bound='hbm', kernel='tsamd::spmm_merge_kernel<float,4,ADD>', achieved=round(achieved, 1),
                         peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=traffic, algorithmic_bytes_per_launch=balg,
-                        kernel_ms=round(k_ms, 4), partition_ms=round(prof[0], 4), fixup_ms=round(prof[2], 4),
+                        balg_over_peak=round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=traffic, traffic_source=traffic_source,
+                        frac_traffic=(round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                        algorithmic_bytes_per_launch=balg, b_min=bmin,
+                        traffic_over_b_min=(round(traffic / bmin, 2) if traffic else None),
+                        kernel_ms=round(k_ms, 4), pre_ms=round(prof[0], 4), fixup_ms=round(prof[2], 4),
                         whole_op_frac=round(balg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
-                        note='achieved = algorithmic (no-reuse) bytes / kernel time; it can exceed the HBM peak because '
-                             'part of the gathered rows is served by L2 (compare traffic); whole_op_frac also counts '
-                             'the relabel copy, partition and fix-up kernels of the same tsamd_spmm call')
+                        note='achieved = ALGORITHMIC (no-reuse gather model, SURVEY 8d) bytes / kernel time, so `frac` '
+                             '(= balg_over_peak) is a throughput normalised by the HBM peak, NOT the share of HBM '
+                             'bandwidth in use: gathered rows that hit in L2 / Infinity Cache make it exceed 1. '
+                             'frac_traffic = measured fabric bytes / kernel time / peak is the physical figure '
+                             '(part of those bytes are Infinity-Cache hits); b_min = compulsory bytes; '
+                             'pre_ms = probe + relabelled copy of X + merge-path partition, fixup_ms = carry fix-up; '
+                             'whole_op_frac counts all of them')
         line = dict(metric='SpMM GEdges/s', value=round(gedges, 3), unit='GEdges/s', n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
@@ -295,6 +303,11 @@ def main():
             line['config']['exchange_fallback'] = 'requested %s; %s' % (requested, fallback_reason)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rowptr, col_k, value, x_full, args.reduce, out)
+        if world == 1 and not args.no_secondary:
+            del x_full, out, sharded
+            torch.cuda.empty_cache()
+            line['control'] = control_graph(m_local, ef, F, dev, nat)
+            line['secondary'] = secondary(dev, cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
