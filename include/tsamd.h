@@ -217,34 +217,37 @@ int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t
  * functional spspmm (torch_sparse/spspmm.py:6-33).  Result contract = what the
  * reference relies on (matmul.py:104-111): every row of C sorted by column,
  * duplicates summed, explicit zeros kept.  fp32 / fp64 only (torch.sparse.mm
- * rejects the other dtypes too).  The host allocates between the stages:
+ * rejects the other dtypes too).  Count first, write once -- the host allocates between the
+ * stages:
  *
- *   1. tsamd_spspmm_plan   prodptr[M+1] = exclusive scan of the per-row product
- *        counts (prodptr[M] = P), bins[3*M] = row ids by size class
- *        (small | medium | large, M slots each), stats (DEVICE int64[8]):
- *        [0]=P  [1]=#small  [2]=#medium  [3]=#large  [4]=products in large rows.
- *        --> host reads stats (sync), allocates colT[P], valT[P], nnzC[M].
- *   2. tsamd_spspmm_rows   fills each row's slot colT/valT[prodptr[i] ...] with
- *        its sorted, compressed entries and nnzC[i] with their number.
- *        valA / valB may be NULL (all ones); valT may be NULL (structure only).
- *   3. host: rowptrC = exclusive scan of nnzC (tsamd_exclusive_scan_i64),
- *        rowC = tsamd_ptr2ind(rowptrC), allocates colC/valC[nnz(C)].
- *   4. tsamd_spspmm_compact copies the slots to their final dense position.
+ *   1. tsamd_spspmm_plan      prod[M] = products per row of A (sum of the lengths of the B rows
+ *        it references); bins[2*M] = ids of the rows with more than 512 products by size class
+ *        (medium <= 4096 | large, M slots each; rows of <= 512 products are not listed, their
+ *        kernels run over all rows in natural order); stats (DEVICE int64[8]): [2]=#medium
+ *        [3]=#large  [4]=products in large rows.
+ *        --> host reads stats (sync 1: grid sizes and the workspace of the large rows).
+ *   2. tsamd_spspmm_symbolic  nnzC[i] = exact number of entries of row i of C (LDS hash sets for
+ *        small / medium rows; global sort + coalesce for large rows, whose sorted pattern stays in
+ *        `workspace` for stage 4).  nnzC has M entries, all written.
+ *   3. host: rowptrC = exclusive scan of nnzC over M + 1 entries (tsamd_exclusive_scan_i64, entry
+ *        M = 0), reads nnz(C) (sync 2), allocates colC / valC at their FINAL size.
+ *   4. tsamd_spspmm_numeric   every row is expanded, sorted by column (registers / LDS), its equal
+ *        columns summed in product order, and stored at rowptrC[i].  valA / valB may be NULL (all
+ *        ones); valC may be NULL (structure only).  `workspace` is the one stage 2 filled.
+ * M < 2^31, N < 2^32 - 1.
  * ------------------------------------------------------------------------ */
-size_t tsamd_spspmm_plan_workspace_bytes(int64_t M);
 int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
-                      int64_t M, int64_t *prodptr, int64_t *bins, int64_t *stats,
-                      void *workspace, size_t workspace_bytes, void *stream);
-size_t tsamd_spspmm_rows_workspace_bytes(int dtype, int64_t n_large, int64_t P_large);
-int tsamd_spspmm_rows(int dtype, const int64_t *rowptrA, const int64_t *colA, const void *valA,
-                      const int64_t *rowptrB, const int64_t *colB, const void *valB, int64_t M,
-                      int64_t N, const int64_t *prodptr, const int64_t *bins, int64_t n_small,
-                      int64_t n_medium, int64_t n_large, int64_t P_large, int64_t *colT,
-                      void *valT, int64_t *nnzC, void *workspace, size_t workspace_bytes,
-                      void *stream);
-int tsamd_spspmm_compact(int dtype, const int64_t *rowC, const int64_t *rowptrC,
-                         const int64_t *prodptr, const int64_t *colT, const void *valT,
-                         int64_t nnz, int64_t *colC, void *valC, void *stream);
+                      int64_t M, int64_t *prod, int64_t *bins, int64_t *stats, void *stream);
+size_t tsamd_spspmm_workspace_bytes(int64_t n_large, int64_t P_large);
+int tsamd_spspmm_symbolic(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
+                          const int64_t *colB, int64_t M, int64_t N, const int64_t *prod,
+                          const int64_t *bins, int64_t n_medium, int64_t n_large, int64_t P_large,
+                          int64_t *nnzC, void *workspace, size_t workspace_bytes, void *stream);
+int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int64_t *colA, const void *valA,
+                         const int64_t *rowptrB, const int64_t *colB, const void *valB, int64_t M,
+                         int64_t N, const int64_t *prod, const int64_t *bins, int64_t n_medium,
+                         int64_t n_large, int64_t P_large, const int64_t *rowptrC, int64_t *colC,
+                         void *valC, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * Sub-matrix extraction (the callers either side of the sharded

@@ -23,8 +23,7 @@ SYMBOLS = [
     'tsamd_coalesce_workspace_bytes', 'tsamd_coalesce_index', 'tsamd_segment_reduce',
     'tsamd_segment_reduce_balanced_workspace_bytes', 'tsamd_segment_reduce_balanced',
     'tsamd_exclusive_scan_workspace_bytes', 'tsamd_exclusive_scan_i64',
-    'tsamd_spspmm_plan_workspace_bytes', 'tsamd_spspmm_plan', 'tsamd_spspmm_rows_workspace_bytes',
-    'tsamd_spspmm_rows', 'tsamd_spspmm_compact',
+    'tsamd_spspmm_plan', 'tsamd_spspmm_workspace_bytes', 'tsamd_spspmm_symbolic', 'tsamd_spspmm_numeric',
     'tsamd_select_workspace_bytes', 'tsamd_select_plan', 'tsamd_select_fill',
     'tsamd_filter_workspace_bytes', 'tsamd_filter_plan', 'tsamd_filter_apply',
     'tsamd_filter_tiles_workspace_bytes', 'tsamd_filter_count', 'tsamd_filter_write',

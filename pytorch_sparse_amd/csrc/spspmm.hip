@@ -1,4 +1,4 @@
-// SpSpMM  C = A * B  (CSR x CSR -> CSR, sum) on gfx950: row-wise expand / sort / compress.
+// SpSpMM  C = A * B  (CSR x CSR -> CSR, sum) on gfx950: count first, write once.
 //
 // The reference has no native code for this: torch_sparse/matmul.py:94-111 converts both
 // operands to torch sparse COO and calls torch.sparse.mm (PyTorch's CPU SpGEMM / hipSPARSE),
@@ -6,21 +6,30 @@
 // that result shape: every row of C sorted by column, duplicates summed, explicit zeros kept.
 //
 // Pipeline (stages are separate C-ABI calls because the host allocates between them):
-//   plan     wave per row of A: products(i) = sum_{k in A_i} |B_k|; rows are binned
-//            (small <= 512 products, medium <= 4096, large) and an exclusive scan gives
-//            every row a slot of `products(i)` entries in a temporary (col, val) buffer.
-//   rows     small/medium rows: ONE workgroup (64 / 256 threads) expands the row's products
-//            straight into LDS (they never touch HBM), sorts them by column in LDS (one wave: stable
-//            radix sort with ballot ranking; 256 threads: bitonic),
-//            sums equal columns and writes the compressed row into its slot.
-//   large    rows whose products do not fit LDS are expanded to HBM and go through the
-//            global radix sort + coalesce + segmented sum (sort.hip / coalesce.hip).
-//   compact  exclusive scan of the per-row counts -> rowptrC; slots are copied to their
-//            final, dense position.
+//   plan      wave per row of A: products(i) = sum_{k in A_i} |B_k|; rows are binned (small <= 512
+//             products, medium <= 4096, large) with one atomic per wave and bin.
+//   symbolic  exact nnz of every row of C.  small / medium rows: one wave / one 256-thread
+//             workgroup expands the row's product COLUMNS straight into an LDS hash set (1 Ki / 8 Ki
+//             slots) and counts the successful inserts.  Large rows: expanded to HBM, global radix
+//             sort + coalesce (sort.hip / coalesce.hip); the sorted unique pattern stays in the
+//             workspace for the numeric stage.
+//   (host)    exclusive scan of the counts = the FINAL rowptr of C; one sync for nnz(C); colC / valC
+//             are allocated at their final size -- no per-row slot buffer of `products` entries,
+//             no compaction copy.
+//   numeric   small rows: the row's products are expanded into LDS as 32-bit keys
+//             (column << 9 | product index) next to their values, pulled into registers
+//             (1 / 2 / 4 / 8 keys per lane) and sorted by a wave-level bitonic network -- min/max
+//             on unique keys, DPP / swizzle / bpermute exchanges, no LDS allocation, no barriers,
+//             no data-dependent step -- written back, equal columns summed in product order
+//             (deterministic) and the compressed row stored at its final position.  When
+//             ceil(log2 N) > 23 the keys do not fit 32 bits: LDS radix sort of (column, value)
+//             pairs instead.  Medium rows: 256-thread bitonic sort of pairs in LDS.  Large rows:
+//             values expanded to HBM and summed through the permutation of the symbolic stage.
 #include "common.h"
 #include "scan.h"
 
 #include <type_traits>
+#include <utility>
 
 extern "C" int tsamd_sort_coo(const int64_t *, const int64_t *, int64_t, int64_t, int64_t,
                               int64_t *, int64_t *, int64_t *, void *, size_t, void *);
@@ -36,45 +45,50 @@ constexpr int kSmallCap = 512;    // products handled by one wave (LDS radix sor
 constexpr int kMediumCap = 4096;  // products handled by one 256-thread workgroup
 
 // stats layout (device int64[8])
-enum { ST_P = 0, ST_NSMALL = 1, ST_NMEDIUM = 2, ST_NLARGE = 3, ST_PLARGE = 4, ST_NNZC = 5 };
+enum { ST_NMEDIUM = 2, ST_NLARGE = 3, ST_PLARGE = 4 };
+
+// products(i) = sum over the entries k of row i of A of |B_k|.  8 lanes per row (32 rows per
+// 256-thread workgroup): rows of a few dozen entries keep most lanes busy, hub rows just loop.
+constexpr int kCountLanes = 8;
 
 __global__ __launch_bounds__(256) void spspmm_count_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
     const int64_t *__restrict__ rowptrB, int64_t M, int64_t *__restrict__ prod) {
-  const int lane = (int)(threadIdx.x & 63);
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= M) return;
-  const int64_t s = rowptrA[i], e = rowptrA[i + 1];
+  const int sub = (int)(threadIdx.x & (kCountLanes - 1));
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / kCountLanes;
   int64_t p = 0;
-  for (int64_t k = s + lane; k < e; k += 64) {
-    const int64_t c = colA[k];
-    p += rowptrB[c + 1] - rowptrB[c];
+  if (i < M) {
+    const int64_t s = rowptrA[i], e = rowptrA[i + 1];
+    for (int64_t k = s + sub; k < e; k += kCountLanes) {
+      const int64_t c = colA[k];
+      p += rowptrB[c + 1] - rowptrB[c];
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) p += lane_xor(p, off);
-  if (lane == 0) prod[i] = p;
+#pragma unroll
+  for (int off = kCountLanes / 2; off > 0; off >>= 1) p += lane_xor(p, off);
+  if (i < M && sub == 0) prod[i] = p;
 }
 
-// Bin rows by product count.  One thread per row; a wave reserves its slots in each bin with a
-// single atomic (ballot + popcount) instead of one atomic per row on three hot counters.
+// Rows of more than kSmallCap products are listed by size class (medium | large); small rows are
+// not listed: their kernels run over all rows in natural order and skip the others (better locality
+// of the A rows and of the output, and no atomics at all when every row is small).  One thread per
+// row; a wave reserves its slots in a list with a single atomic (ballot + popcount).
 __global__ __launch_bounds__(256) void spspmm_bin_kernel(const int64_t *__restrict__ prod, int64_t M,
                                                         int64_t *__restrict__ bins,
                                                         unsigned long long *stats) {
   const int lane = (int)(threadIdx.x & 63);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t p = i < M ? prod[i] : 0;
-  const int b = p == 0 ? -1 : (p <= kSmallCap ? 0 : (p <= kMediumCap ? 1 : 2));
-  for (int bin = 0; bin < 3; ++bin) {
+  const int b = p <= kSmallCap ? -1 : (p <= kMediumCap ? 0 : 1);
+  for (int bin = 0; bin < 2; ++bin) {
     const unsigned long long m = __ballot(b == bin);
     if (m == 0) continue;
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&stats[ST_NSMALL + bin], (unsigned long long)__popcll(m));
+    if (lane == 0) base = atomicAdd(&stats[ST_NMEDIUM + bin], (unsigned long long)__popcll(m));
     base = (unsigned long long)lane_read((int64_t)base, 0);
     if (b == bin) bins[(int64_t)bin * M + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = i;
   }
-  if (b == 2) {
-    int64_t pl = p;  // products in large rows (few rows: per-row atomics are fine)
-    atomicAdd(&stats[ST_PLARGE], (unsigned long long)pl);
-  }
+  if (b == 1) atomicAdd(&stats[ST_PLARGE], (unsigned long long)p);  // few rows: per-row atomics are fine
 }
 
 template <int NW>
@@ -182,40 +196,36 @@ __device__ inline void wave_radix_sort_lds(uint32_t *&ka, A *&va, uint32_t *&kb,
   }
 }
 
-// One workgroup per row: expand into LDS, sort by column, compress, write.
-template <typename T, int BLOCK, int CAP>
-__global__ __launch_bounds__(BLOCK) void spspmm_row_kernel(
-    const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
-    const T *__restrict__ valA, const int64_t *__restrict__ rowptrB,
-    const int64_t *__restrict__ colB, const T *__restrict__ valB,
-    const int64_t *__restrict__ prodptr, const int64_t *__restrict__ rows,
-    int64_t *__restrict__ colT, T *__restrict__ valT, int64_t *__restrict__ nnzC, int passes) {
+// ---------------------------------------------------------------------------
+// expand: the A row is read in 64-entry chunks (one entry per lane: column, start and length
+// of the B row, value); the chunk's products are then a flat index space that the whole
+// workgroup strides over, each thread locating its B row by a binary search over the chunk's
+// prefix sums in LDS -- independent gathers, several in flight per thread (walking the B rows
+// one after the other serialises a global-load latency per A entry).
+// emit(q, col, value) is called once per product: q = its index in expansion order (A entry
+// order, then B entry order), col = its column (32 bits), value = a * b (1 without values).
+// The B entries are fetched kExpandBatch at a time per thread: all their addresses are resolved
+// first, then the loads are issued back to back and only then consumed (a load / use / LDS-store
+// chain per product costs one global-memory latency per product).
+// ---------------------------------------------------------------------------
+constexpr int kExpandBatch = 4;
+
+template <typename A>
+struct ExpandScratch {
+  int off[65];
+  int64_t bs[64];
+  A av[64];
+};
+
+template <typename T, int BLOCK, bool WITH_VAL, typename Emit>
+__device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, const T *__restrict__ valA,
+                                          const int64_t *__restrict__ rowptrB,
+                                          const int64_t *__restrict__ colB, const T *__restrict__ valB,
+                                          int64_t as, int64_t ae,
+                                          ExpandScratch<typename Traits<T>::acc_t> &sc, Emit emit) {
   using A = typename Traits<T>::acc_t;
-  __shared__ uint32_t scol_[CAP];
-  __shared__ A sval_[CAP];
-  __shared__ uint32_t scol2_[BLOCK == 64 ? CAP : 1];  // ping-pong buffers of the wave radix sort
-  __shared__ A sval2_[BLOCK == 64 ? CAP : 1];
-  __shared__ uint32_t scnt[BLOCK == 64 ? 256 : 1];
-  __shared__ int sscan[8];
-  uint32_t *scol = scol_, *scol2 = scol2_;
-  A *sval = sval_, *sval2 = sval2_;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
-  const int64_t i = rows[blockIdx.x];
-  const int64_t as = rowptrA[i], ae = rowptrA[i + 1];
-  const int64_t slot = prodptr[i];
-  const int p = (int)(prodptr[i + 1] - slot);
-  int n2 = 2;
-  while (n2 < p) n2 <<= 1;
-
-  // ---- expand: the A row is read in 64-entry chunks (one entry per lane: column, start and
-  //      length of the B row, value); the chunk's products are then a flat index space that the
-  //      whole workgroup strides over, each thread locating its B row by a binary search over the
-  //      chunk's prefix sums in LDS -- independent gathers, several in flight per thread (walking
-  //      the B rows one after the other serialises a global-load latency per A entry) ----
-  __shared__ int s_off[65];
-  __shared__ int64_t s_bs[64];
-  __shared__ A s_av[64];
   int filled = 0;
   for (int64_t e0 = as; e0 < ae; e0 += 64) {
     const int64_t e = e0 + lane;
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void spspmm_row_kernel(
       const int64_t c = colA[e];
       bs = rowptrB[c];
       d = (int)(rowptrB[c + 1] - bs);
-      if (valA != nullptr) av = Traits<T>::to_acc(valA[e]);
+      if (WITH_VAL && valA != nullptr) av = Traits<T>::to_acc(valA[e]);
     }
     int incl = d;
 #pragma unroll
@@ -235,75 +245,366 @@ __global__ __launch_bounds__(BLOCK) void spspmm_row_kernel(
       if (lane >= off) incl += o;
     }
     if (tid < 64) {  // every wave holds the same chunk; the first one publishes it
-      s_off[lane] = incl - d;
-      s_bs[lane] = bs;
-      s_av[lane] = av;
-      if (lane == 63) s_off[64] = incl;
+      sc.off[lane] = incl - d;
+      sc.bs[lane] = bs;
+      if (WITH_VAL) sc.av[lane] = av;
+      if (lane == 63) sc.off[64] = incl;
     }
     __syncthreads();
-    const int total = s_off[64];
-#pragma unroll 4
-    for (int q = tid; q < total; q += BLOCK) {
-      int lo = 0, hi = 64;  // last entry whose offset is <= q (zero-length entries are skipped)
+    const int total = sc.off[64];
+    for (int q0 = tid; q0 < total; q0 += BLOCK * kExpandBatch) {
+      int64_t src[kExpandBatch];
+      A a[kExpandBatch];
 #pragma unroll
-      for (int step = 0; step < 6; ++step) {
-        const int mid = (lo + hi) >> 1;
-        if (s_off[mid] <= q) lo = mid; else hi = mid;
+      for (int u = 0; u < kExpandBatch; ++u) {
+        const int qq = q0 + u * BLOCK;
+        const int q = qq < total ? qq : total - 1;
+        int lo = 0, hi = 64;  // last entry whose offset is <= q (zero-length entries are skipped)
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+          const int mid = (lo + hi) >> 1;
+          if (sc.off[mid] <= q) lo = mid; else hi = mid;
+        }
+        src[u] = sc.bs[lo] + (q - sc.off[lo]);
+        a[u] = WITH_VAL ? sc.av[lo] : A(1);
       }
-      const int64_t src = s_bs[lo] + (q - s_off[lo]);
-      scol[filled + q] = (uint32_t)colB[src];
-      sval[filled + q] = valB != nullptr ? s_av[lo] * Traits<T>::to_acc(valB[src]) : s_av[lo];
+      uint32_t c[kExpandBatch];
+      A b[kExpandBatch];
+#pragma unroll
+      for (int u = 0; u < kExpandBatch; ++u) {
+        c[u] = (uint32_t)colB[src[u]];
+        b[u] = (WITH_VAL && valB != nullptr) ? Traits<T>::to_acc(valB[src[u]]) : A(1);
+      }
+#pragma unroll
+      for (int u = 0; u < kExpandBatch; ++u) {
+        const int qq = q0 + u * BLOCK;
+        if (qq < total) emit(filled + qq, c[u], a[u] * b[u]);
+      }
     }
     filled += total;
     __syncthreads();
   }
-  if constexpr (BLOCK == 64) {
-    wave_radix_sort_lds<A>(scol, sval, scol2, sval2, p, passes, scnt);
-  } else {
-  for (int j = p + tid; j < n2; j += BLOCK) {
-    scol[j] = 0xFFFFFFFFu;
-    sval[j] = A(0);
-  }
-  __syncthreads();
+  return filled;
+}
 
-  // ---- bitonic sort by column (pairs) ----
-  for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (n2 >> 1); t += BLOCK) {
-        const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two
-        const int b = a + j;
-        const bool up = (a & k) == 0;
-        const uint32_t ca = scol[a], cb = scol[b];
-        if ((ca > cb) == up && ca != cb) {
-          scol[a] = cb;
-          scol[b] = ca;
-          const A va = sval[a];
-          sval[a] = sval[b];
-          sval[b] = va;
-        }
+// ---------------------------------------------------------------------------
+// symbolic: number of distinct columns among the row's products (LDS hash set)
+// ---------------------------------------------------------------------------
+constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;  // column ids are < 2^32 - 1
+
+template <int BLOCK, int LOG_T>
+__global__ __launch_bounds__(BLOCK) void spspmm_symbolic_kernel(
+    const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
+    const int64_t *__restrict__ rowptrB, const int64_t *__restrict__ colB,
+    const int64_t *__restrict__ prod, const int64_t *__restrict__ rows, int64_t *__restrict__ nnzC) {
+  constexpr int kT = 1 << LOG_T;
+  __shared__ uint32_t tab[kT];
+  __shared__ ExpandScratch<float> sc;
+  __shared__ int s_cnt[BLOCK / 64];
+  const int tid = (int)threadIdx.x;
+  int64_t i;
+  if constexpr (BLOCK == 64) {  // small rows: every row in natural order, the others are skipped
+    i = blockIdx.x;
+    const int64_t p = prod[i];
+    if (p == 0 || p > kSmallCap) return;
+  } else {
+    i = rows[blockIdx.x];
+  }
+  for (int t = tid; t < kT; t += BLOCK) tab[t] = kEmptyKey;
+  __syncthreads();
+  int fresh = 0;
+  expand_row<float, BLOCK, false>(colA, nullptr, rowptrB, colB, nullptr, rowptrA[i], rowptrA[i + 1], sc,
+                                  [&](int, uint32_t c, float) {
+    uint32_t h = (c * 0x9E3779B1u) >> (32 - LOG_T);
+    for (;;) {
+      const uint32_t old = atomicCAS(&tab[h], kEmptyKey, c);
+      if (old == kEmptyKey) {
+        ++fresh;
+        break;
       }
-      __syncthreads();
+      if (old == c) break;
+      h = (h + 1) & (kT - 1);
+    }
+  });
+  for (int off = 32; off > 0; off >>= 1) fresh += lane_xor(fresh, off);
+  if constexpr (BLOCK == 64) {
+    if (tid == 0) nnzC[i] = fresh;
+  } else {
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = fresh;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+#pragma unroll
+      for (int w = 0; w < BLOCK / 64; ++w) t += s_cnt[w];
+      nnzC[i] = t;
     }
   }
-  }
+}
 
-  // ---- compress equal columns, write the row into its slot ----
+// ---------------------------------------------------------------------------
+// wave-level bitonic sort of 64 * I unique 32-bit keys held in registers, element
+// e = lane * I + j.  "Flip + butterfly" form: every compare-exchange leaves the minimum at the
+// lower position, so no direction bits are needed; strides below I stay inside a lane
+// (v_min / v_max on registers), the others exchange with lane ^ mask through DPP (masks 1, 2, 3,
+// 7, 15), ds_swizzle (4, 8, 16, 31) or ds_bpermute (32, 63) -- none of which allocates LDS.
+// ---------------------------------------------------------------------------
+template <int MASK>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane) {
+  if constexpr (MASK == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  else if constexpr (MASK == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+  else if constexpr (MASK == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, true);
+  else if constexpr (MASK == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+  else if constexpr (MASK == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+  else if constexpr (MASK < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (MASK << 10) | 0x1F);
+  else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, (int)v);
+}
+
+__device__ __forceinline__ void cmpswap(uint32_t &a, uint32_t &b) {
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+
+template <int I>
+__device__ __forceinline__ void intra_butterflies(uint32_t (&key)[I], int first_stride) {
+#pragma unroll
+  for (int s = I / 2; s >= 1; s >>= 1) {
+    if (s > first_stride) continue;
+#pragma unroll
+    for (int j = 0; j < I; ++j)
+      if ((j & s) == 0) cmpswap(key[j], key[j | s]);
+  }
+}
+
+// one merge phase whose blocks span 2^B lanes (k = I * 2^B)
+template <int I, int B>
+__device__ __forceinline__ void cross_phase(uint32_t (&key)[I], int lane) {
+  {  // flip: partner element = e ^ (k - 1): lane ^ (2^B - 1), item I - 1 - j
+    const bool lower = ((lane >> (B - 1)) & 1) == 0;
+    uint32_t p[I];
+#pragma unroll
+    for (int j = 0; j < I; ++j) p[j] = xor_lane<(1 << B) - 1>(key[I - 1 - j], lane);
+#pragma unroll
+    for (int j = 0; j < I; ++j) {
+      const uint32_t lo = key[j] < p[j] ? key[j] : p[j], hi = key[j] < p[j] ? p[j] : key[j];
+      key[j] = lower ? lo : hi;
+    }
+  }
+  auto butterfly = [&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if constexpr (t <= B - 2) {
+      const bool lower = ((lane >> t) & 1) == 0;
+#pragma unroll
+      for (int j = 0; j < I; ++j) {
+        const uint32_t q = xor_lane<(1 << t)>(key[j], lane);
+        const uint32_t lo = key[j] < q ? key[j] : q, hi = key[j] < q ? q : key[j];
+        key[j] = lower ? lo : hi;
+      }
+    }
+  };
+  butterfly(std::integral_constant<int, 4>{});
+  butterfly(std::integral_constant<int, 3>{});
+  butterfly(std::integral_constant<int, 2>{});
+  butterfly(std::integral_constant<int, 1>{});
+  butterfly(std::integral_constant<int, 0>{});
+  intra_butterflies<I>(key, I / 2);
+}
+
+template <int I>
+__device__ __forceinline__ void bitonic_sort_regs(uint32_t (&key)[I], int lane) {
+  // merge phases inside a lane: k = 2 .. I
+#pragma unroll
+  for (int k = 2; k <= I; k <<= 1) {
+#pragma unroll
+    for (int j = 0; j < I; ++j) {
+      const int jj = j ^ (k - 1);
+      if (j < jj) cmpswap(key[j], key[jj]);
+    }
+    intra_butterflies<I>(key, k / 4);
+  }
+  cross_phase<I, 1>(key, lane);
+  cross_phase<I, 2>(key, lane);
+  cross_phase<I, 3>(key, lane);
+  cross_phase<I, 4>(key, lane);
+  cross_phase<I, 5>(key, lane);
+  cross_phase<I, 6>(key, lane);
+}
+
+template <int I>
+__device__ __forceinline__ void sort_lds_keys(uint32_t *skey, int lane) {
+  uint32_t key[I];
+  if constexpr (I >= 4) {
+#pragma unroll
+    for (int v = 0; v < I / 4; ++v) {
+      const Pack<uint32_t, 4> k4 = *reinterpret_cast<const Pack<uint32_t, 4> *>(skey + lane * I + 4 * v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) key[4 * v + j] = k4.v[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < I; ++j) key[j] = skey[lane * I + j];
+  }
+  bitonic_sort_regs<I>(key, lane);
+  __syncthreads();  // all reads of the unsorted keys are done (one wave: orders the LDS traffic)
+  if constexpr (I >= 4) {
+#pragma unroll
+    for (int v = 0; v < I / 4; ++v) {
+      Pack<uint32_t, 4> k4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k4.v[j] = key[4 * v + j];
+      *reinterpret_cast<Pack<uint32_t, 4> *>(skey + lane * I + 4 * v) = k4;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < I; ++j) skey[lane * I + j] = key[j];
+  }
+}
+
+// Sum equal columns of the sorted row and store it at its final position.
+// col_at(idx) / val_at(idx) read entry idx of the sorted row.
+template <typename T, int BLOCK, typename ColAt, typename ValAt>
+__device__ __forceinline__ void compress_and_store(int p, int64_t out, int64_t *__restrict__ colC,
+                                                   T *__restrict__ valC, int *sscan, ColAt col_at,
+                                                   ValAt val_at) {
+  using A = typename Traits<T>::acc_t;
+  const int tid = (int)threadIdx.x;
   int base = 0;
   for (int c0 = 0; c0 < p; c0 += BLOCK) {
     const int idx = c0 + tid;
-    const bool head = idx < p && (idx == 0 || scol[idx] != scol[idx - 1]);
+    uint32_t c = 0;
+    bool head = false;
+    if (idx < p) {
+      c = col_at(idx);
+      head = idx == 0 || col_at(idx - 1) != c;
+    }
     int tot;
     const int pos = base + block_exclusive_scan_small<BLOCK / 64>(head ? 1 : 0, sscan, &tot);
     if (head) {
-      A acc = sval[idx];
-      const uint32_t c = scol[idx];
-      for (int q = idx + 1; q < p && scol[q] == c; ++q) acc += sval[q];
-      colT[slot + pos] = (int64_t)c;
-      if (valT != nullptr) valT[slot + pos] = Traits<T>::from_acc(acc);
+      colC[out + pos] = (int64_t)c;
+      if (valC != nullptr) {
+        A acc = val_at(idx);
+        for (int q = idx + 1; q < p && col_at(q) == c; ++q) acc += val_at(q);
+        valC[out + pos] = Traits<T>::from_acc(acc);
+      }
     }
     base += tot;
   }
-  if (tid == 0) nnzC[i] = base;
+}
+
+// ---------------------------------------------------------------------------
+// numeric, small rows (<= 512 products), column ids below 2^23: one wave per row
+// ---------------------------------------------------------------------------
+constexpr int kIdxBits = 9;  // log2(kSmallCap)
+
+template <typename T>
+__global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
+    const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
+    const T *__restrict__ valA, const int64_t *__restrict__ rowptrB,
+    const int64_t *__restrict__ colB, const T *__restrict__ valB,
+    const int64_t *__restrict__ prod, const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC,
+    T *__restrict__ valC) {
+  using A = typename Traits<T>::acc_t;
+  __shared__ alignas(16) uint32_t skey[kSmallCap];
+  __shared__ A sval[kSmallCap];
+  __shared__ ExpandScratch<A> sc;
+  __shared__ int sscan[8];
+  const int lane = (int)threadIdx.x;
+  const int64_t i = blockIdx.x;
+  if (prod[i] == 0 || prod[i] > kSmallCap) return;
+  const int p = (int)prod[i];
+  const bool with_val = valC != nullptr;
+  const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : 8));  // keys per lane
+  for (int q = p + lane; q < 64 * items; q += 64) skey[q] = kEmptyKey;   // padding sorts last
+  if (with_val) {
+    expand_row<T, 64, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+                            [&](int q, uint32_t c, A v) {
+      skey[q] = (c << kIdxBits) | (uint32_t)q;
+      sval[q] = v;
+    });
+  } else {
+    expand_row<T, 64, false>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+                             [&](int q, uint32_t c, A) { skey[q] = (c << kIdxBits) | (uint32_t)q; });
+  }
+  __syncthreads();
+  if (items == 1) sort_lds_keys<1>(skey, lane);
+  else if (items == 2) sort_lds_keys<2>(skey, lane);
+  else if (items == 4) sort_lds_keys<4>(skey, lane);
+  else sort_lds_keys<8>(skey, lane);
+  __syncthreads();
+  compress_and_store<T, 64>(
+      p, rowptrC[i], colC, valC, sscan, [&](int idx) { return skey[idx] >> kIdxBits; },
+      [&](int idx) { return sval[skey[idx] & (uint32_t)(kSmallCap - 1)]; });
+}
+
+// ---------------------------------------------------------------------------
+// numeric, (column, value) pairs sorted in LDS: medium rows (256 threads, bitonic) and small
+// rows of matrices with more than 2^23 columns (one wave, stable LSD radix sort)
+// ---------------------------------------------------------------------------
+template <typename T, int BLOCK, int CAP>
+__global__ __launch_bounds__(BLOCK) void spspmm_numeric_pairs_kernel(
+    const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
+    const T *__restrict__ valA, const int64_t *__restrict__ rowptrB,
+    const int64_t *__restrict__ colB, const T *__restrict__ valB,
+    const int64_t *__restrict__ prod, const int64_t *__restrict__ rows,
+    const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC, T *__restrict__ valC, int passes) {
+  using A = typename Traits<T>::acc_t;
+  __shared__ uint32_t scol_[CAP];
+  __shared__ A sval_[CAP];
+  __shared__ uint32_t scol2_[BLOCK == 64 ? CAP : 1];  // ping-pong buffers of the wave radix sort
+  __shared__ A sval2_[BLOCK == 64 ? CAP : 1];
+  __shared__ uint32_t scnt[BLOCK == 64 ? 256 : 1];
+  __shared__ ExpandScratch<A> sc;
+  __shared__ int sscan[8];
+  uint32_t *scol = scol_, *scol2 = scol2_;
+  A *sval = sval_, *sval2 = sval2_;
+  const int tid = (int)threadIdx.x;
+  int64_t i;
+  if constexpr (BLOCK == 64) {
+    i = blockIdx.x;
+    if (prod[i] == 0 || prod[i] > kSmallCap) return;
+  } else {
+    i = rows[blockIdx.x];
+  }
+  const int p = (int)prod[i];
+  expand_row<T, BLOCK, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+                             [&](int q, uint32_t c, A v) {
+    scol[q] = c;
+    sval[q] = v;
+  });
+  if constexpr (BLOCK == 64) {
+    wave_radix_sort_lds<A>(scol, sval, scol2, sval2, p, passes, scnt);
+  } else {
+    int n2 = 2;
+    while (n2 < p) n2 <<= 1;
+    for (int j = p + tid; j < n2; j += BLOCK) {
+      scol[j] = 0xFFFFFFFFu;
+      sval[j] = A(0);
+    }
+    __syncthreads();
+    // bitonic sort by column (pairs); equal columns keep no particular order among themselves
+    // beyond what the network does, which is a fixed function of their positions
+    for (int k = 2; k <= n2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (n2 >> 1); t += BLOCK) {
+          const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two
+          const int b = a + j;
+          const bool up = (a & k) == 0;
+          const uint32_t ca = scol[a], cb = scol[b];
+          if ((ca > cb) == up && ca != cb) {
+            scol[a] = cb;
+            scol[b] = ca;
+            const A va = sval[a];
+            sval[a] = sval[b];
+            sval[b] = va;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  compress_and_store<T, BLOCK>(
+      p, rowptrC[i], colC, valC, sscan, [&](int idx) { return scol[idx]; },
+      [&](int idx) { return sval[idx]; });
 }
 
 // Large rows: expand (row, col, val) triples to HBM at lp[r] (exclusive scan of their products).
@@ -321,10 +622,12 @@ __global__ __launch_bounds__(256) void spspmm_expand_large_kernel(
   for (int64_t e = rowptrA[i]; e < rowptrA[i + 1]; ++e) {
     const int64_t c = colA[e];
     const int64_t bs = rowptrB[c], d = rowptrB[c + 1] - bs;
-    const A av = valA != nullptr ? Traits<T>::to_acc(valA[e]) : A(1);
+    const A av = (eval != nullptr && valA != nullptr) ? Traits<T>::to_acc(valA[e]) : A(1);
     for (int64_t j = tid; j < d; j += 256) {
-      erow[out + j] = i;
-      ecol[out + j] = colB[bs + j];
+      if (erow != nullptr) {
+        erow[out + j] = i;
+        ecol[out + j] = colB[bs + j];
+      }
       if (eval != nullptr)
         eval[out + j] = Traits<T>::from_acc(valB != nullptr ? av * Traits<T>::to_acc(valB[bs + j]) : av);
     }
@@ -332,13 +635,32 @@ __global__ __launch_bounds__(256) void spspmm_expand_large_kernel(
   }
 }
 
-__global__ void gather_prod_kernel(const int64_t *__restrict__ rows, const int64_t *__restrict__ prodptr,
+__global__ void gather_prod_kernel(const int64_t *__restrict__ rows, const int64_t *__restrict__ prod,
                                    int64_t n, int64_t *__restrict__ out) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) out[r] = prodptr[rows[r] + 1] - prodptr[rows[r]];
+  if (r < n) out[r] = prod[rows[r]];
 }
 
-// unique (row, col) of the large rows -> their slots; T values summed through perm/seg_ptr
+// unique (row, col) of the large rows: entry q is the j-th entry of its row
+__device__ __forceinline__ int64_t rank_in_row(const int64_t *__restrict__ row_u, int64_t q) {
+  const int64_t r = row_u[q];
+  int64_t lo = 0, hi = q;  // first q' with row_u[q'] == r
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (row_u[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  return q - lo;
+}
+
+__global__ void spspmm_count_large_kernel(const int64_t *__restrict__ row_u,
+                                          const int64_t *__restrict__ nuniq,
+                                          int64_t *__restrict__ nnzC, int64_t cap) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = *nuniq;
+  if (q >= n || q >= cap) return;
+  if (q == n - 1 || row_u[q + 1] != row_u[q]) nnzC[row_u[q]] = rank_in_row(row_u, q) + 1;
+}
+
 template <typename T>
 __global__ void spspmm_scatter_large_kernel(const int64_t *__restrict__ row_u,
                                             const int64_t *__restrict__ col_u,
@@ -346,66 +668,20 @@ __global__ void spspmm_scatter_large_kernel(const int64_t *__restrict__ row_u,
                                             const int64_t *__restrict__ perm,
                                             const T *__restrict__ eval,
                                             const int64_t *__restrict__ nuniq,
-                                            const int64_t *__restrict__ prodptr,
-                                            int64_t *__restrict__ colT, T *__restrict__ valT,
-                                            int64_t *__restrict__ nnzC, int64_t cap) {
+                                            const int64_t *__restrict__ rowptrC,
+                                            int64_t *__restrict__ colC, T *__restrict__ valC,
+                                            int64_t cap) {
   using A = typename Traits<T>::acc_t;
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = *nuniq;
   if (q >= n || q >= cap) return;
-  const int64_t r = row_u[q];
-  int64_t lo = 0, hi = q;  // first q' with row_u[q'] == r
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (row_u[mid] < r) lo = mid + 1; else hi = mid;
-  }
-  const int64_t j = q - lo;
-  const int64_t dst = prodptr[r] + j;
-  colT[dst] = col_u[q];
-  if (valT != nullptr) {
+  const int64_t dst = rowptrC[row_u[q]] + rank_in_row(row_u, q);
+  colC[dst] = col_u[q];
+  if (valC != nullptr) {
     A acc = A(0);
     for (int64_t t = seg_ptr[q]; t < seg_ptr[q + 1]; ++t) acc += Traits<T>::to_acc(eval[perm[t]]);
-    valT[dst] = Traits<T>::from_acc(acc);
+    valC[dst] = Traits<T>::from_acc(acc);
   }
-  if (q == n - 1 || row_u[q + 1] != r) nnzC[r] = j + 1;
-}
-
-template <typename T>
-__global__ void spspmm_compact_kernel(const int64_t *__restrict__ rowC, const int64_t *__restrict__ rowptrC,
-                                      const int64_t *__restrict__ prodptr, const int64_t *__restrict__ colT,
-                                      const T *__restrict__ valT, int64_t nnz, int64_t *__restrict__ colC,
-                                      T *__restrict__ valC) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nnz) return;
-  const int64_t r = rowC[q];
-  const int64_t src = prodptr[r] + (q - rowptrC[r]);
-  colC[q] = colT[src];
-  if (valC != nullptr) valC[q] = valT[src];
-}
-
-template <typename T>
-int run_rows(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
-             const int64_t *colB, const void *valB, const int64_t *prodptr, const int64_t *bins,
-             int64_t M, int64_t N, int64_t n_small, int64_t n_medium, int64_t *colT, void *valT,
-             int64_t *nnzC, hipStream_t stream) {
-  int bits = 1;
-  while (bits < 32 && ((int64_t)1 << bits) < N) ++bits;
-  const int passes = (bits + 7) / 8;  // 8-bit radix passes over the column ids
-  const T *va = reinterpret_cast<const T *>(valA);
-  const T *vb = reinterpret_cast<const T *>(valB);
-  T *vt = reinterpret_cast<T *>(valT);
-  if (n_small > 0) {
-    hipLaunchKernelGGL((spspmm_row_kernel<T, 64, kSmallCap>), dim3((unsigned int)n_small), dim3(64), 0,
-                       stream, rowptrA, colA, va, rowptrB, colB, vb, prodptr, bins, colT, vt, nnzC, passes);
-    TSAMD_LAUNCH_CHECK();
-  }
-  if (n_medium > 0) {
-    hipLaunchKernelGGL((spspmm_row_kernel<T, 256, kMediumCap>), dim3((unsigned int)n_medium), dim3(256),
-                       0, stream, rowptrA, colA, va, rowptrB, colB, vb, prodptr, bins + M, colT, vt,
-                       nnzC, passes);
-    TSAMD_LAUNCH_CHECK();
-  }
-  return TSAMD_OK;
 }
 
 struct LargeWs {
@@ -414,7 +690,8 @@ struct LargeWs {
   size_t sort_bytes, coal_bytes;
 };
 
-size_t carve_large(void *base, int64_t n_large, int64_t P_large, size_t esize, LargeWs *w) {
+// erow / ecol are only needed until the sort has run; eval (numeric stage) reuses their space.
+size_t carve_large(void *base, int64_t n_large, int64_t P_large, LargeWs *w) {
   char *p = reinterpret_cast<char *>(base);
   size_t off = 0;
   auto take = [&](size_t bytes) -> void * {
@@ -427,7 +704,7 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, size_t esize, L
   l.lp = (int64_t *)take(8 * (size_t)(n_large + 1));
   l.erow = (int64_t *)take(8 * P);
   l.ecol = (int64_t *)take(8 * P);
-  l.eval = take(esize * P);
+  l.eval = l.erow;  // fp32 / fp64 values of the numeric stage (<= 8 bytes each)
   l.row_s = (int64_t *)take(8 * P);
   l.col_s = (int64_t *)take(8 * P);
   l.perm = (int64_t *)take(8 * P);
@@ -444,22 +721,23 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, size_t esize, L
   return off;
 }
 
-template <typename T>
-int run_large(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
-              const int64_t *colB, const void *valB, const int64_t *prodptr, const int64_t *rows,
-              int64_t n_large, int64_t P_large, int64_t M, int64_t N, int64_t *colT, void *valT,
-              int64_t *nnzC, void *workspace, hipStream_t stream) {
+// symbolic stage of the large rows: the sorted unique (row, col) pattern and the permutation
+// that groups the expanded products stay in the workspace for the numeric stage
+int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
+                   const int64_t *colB, const int64_t *prod, const int64_t *rows, int64_t n_large,
+                   int64_t P_large, int64_t M, int64_t N, int64_t *nnzC, void *workspace,
+                   hipStream_t stream) {
   LargeWs w;
-  carve_large(workspace, n_large, P_large, sizeof(T), &w);
+  carve_large(workspace, n_large, P_large, &w);
   hipLaunchKernelGGL(gather_prod_kernel, dim3((unsigned int)ceil_div(n_large, 256)), dim3(256), 0,
-                     stream, rows, prodptr, n_large, w.lp);
+                     stream, rows, prod, n_large, w.lp);
   TSAMD_LAUNCH_CHECK();
   int st = exclusive_scan_i64(w.lp, w.lp, n_large, nullptr, w.scan_ws, stream);
   if (st != TSAMD_OK) return st;
-  T *ev = valT ? reinterpret_cast<T *>(w.eval) : nullptr;
-  hipLaunchKernelGGL((spspmm_expand_large_kernel<T>), dim3((unsigned int)n_large), dim3(256), 0,
-                     stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
-                     reinterpret_cast<const T *>(valB), rows, (const int64_t *)w.lp, w.erow, w.ecol, ev);
+  hipLaunchKernelGGL((spspmm_expand_large_kernel<float>), dim3((unsigned int)n_large), dim3(256), 0,
+                     stream, rowptrA, colA, (const float *)nullptr, rowptrB, colB,
+                     (const float *)nullptr, rows, (const int64_t *)w.lp, w.erow, w.ecol,
+                     (float *)nullptr);
   TSAMD_LAUNCH_CHECK();
   st = tsamd_sort_coo(w.erow, w.ecol, P_large, M, N, w.row_s, w.col_s, w.perm, w.sort_ws,
                       w.sort_bytes, stream);
@@ -467,12 +745,62 @@ int run_large(const int64_t *rowptrA, const int64_t *colA, const void *valA, con
   st = tsamd_coalesce_index(w.row_s, w.col_s, P_large, w.row_u, w.col_u, w.seg, w.nuniq, w.coal_ws,
                             w.coal_bytes, stream);
   if (st != TSAMD_OK) return st;
+  hipLaunchKernelGGL(spspmm_count_large_kernel, dim3((unsigned int)ceil_div(P_large, 256)), dim3(256),
+                     0, stream, (const int64_t *)w.row_u, (const int64_t *)w.nuniq, nnzC, P_large);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+template <typename T>
+int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
+                  const int64_t *colB, const void *valB, const int64_t *rows, int64_t n_large,
+                  int64_t P_large, const int64_t *rowptrC, int64_t *colC, void *valC, void *workspace,
+                  hipStream_t stream) {
+  LargeWs w;
+  carve_large(workspace, n_large, P_large, &w);
+  T *ev = valC ? reinterpret_cast<T *>(w.eval) : nullptr;
+  if (ev != nullptr) {
+    hipLaunchKernelGGL((spspmm_expand_large_kernel<T>), dim3((unsigned int)n_large), dim3(256), 0,
+                       stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
+                       reinterpret_cast<const T *>(valB), rows, (const int64_t *)w.lp,
+                       (int64_t *)nullptr, (int64_t *)nullptr, ev);
+    TSAMD_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL((spspmm_scatter_large_kernel<T>), dim3((unsigned int)ceil_div(P_large, 256)),
                      dim3(256), 0, stream, (const int64_t *)w.row_u, (const int64_t *)w.col_u,
                      (const int64_t *)w.seg, (const int64_t *)w.perm, (const T *)ev,
-                     (const int64_t *)w.nuniq, prodptr, colT, reinterpret_cast<T *>(valT), nnzC,
-                     P_large);
+                     (const int64_t *)w.nuniq, rowptrC, colC, reinterpret_cast<T *>(valC), P_large);
   TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+template <typename T>
+int numeric_rows(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
+                 const int64_t *colB, const void *valB, const int64_t *prod, const int64_t *bins,
+                 int64_t M, int64_t N, int64_t n_medium, const int64_t *rowptrC, int64_t *colC, void *valC,
+                 hipStream_t stream) {
+  int bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < N) ++bits;
+  const int passes = (bits + 7) / 8;  // 8-bit radix passes over the column ids
+  const T *va = reinterpret_cast<const T *>(valA);
+  const T *vb = reinterpret_cast<const T *>(valB);
+  T *vc = reinterpret_cast<T *>(valC);
+  {  // small rows: all M rows in natural order, the kernel skips the others
+    if (bits + kIdxBits <= 32)
+      hipLaunchKernelGGL((spspmm_numeric_small_kernel<T>), dim3((unsigned int)M), dim3(64), 0, stream,
+                         rowptrA, colA, va, rowptrB, colB, vb, prod, rowptrC, colC, vc);
+    else
+      hipLaunchKernelGGL((spspmm_numeric_pairs_kernel<T, 64, kSmallCap>), dim3((unsigned int)M), dim3(64),
+                         0, stream, rowptrA, colA, va, rowptrB, colB, vb, prod, bins, rowptrC, colC, vc,
+                         passes);
+    TSAMD_LAUNCH_CHECK();
+  }
+  if (n_medium > 0) {
+    hipLaunchKernelGGL((spspmm_numeric_pairs_kernel<T, 256, kMediumCap>), dim3((unsigned int)n_medium),
+                       dim3(256), 0, stream, rowptrA, colA, va, rowptrB, colB, vb, prod, bins, rowptrC,
+                       colC, vc, passes);
+    TSAMD_LAUNCH_CHECK();
+  }
   return TSAMD_OK;
 }
 
@@ -491,84 +819,82 @@ extern "C" int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t
   return exclusive_scan_i64(in, out, n, total, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" size_t tsamd_spspmm_plan_workspace_bytes(int64_t M) { return scan_workspace_bytes(M + 1); }
-
 extern "C" int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA,
-                                 const int64_t *rowptrB, int64_t M, int64_t *prodptr,
-                                 int64_t *bins, int64_t *stats, void *workspace,
-                                 size_t workspace_bytes, void *stream_) {
+                                 const int64_t *rowptrB, int64_t M, int64_t *prod, int64_t *bins,
+                                 int64_t *stats, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (M < 0 || !prodptr || !stats) return TSAMD_ERR_INVALID;
+  if (M < 0 || !stats) return TSAMD_ERR_INVALID;
+  if (M > 0 && (!rowptrA || !rowptrB || !bins || !prod)) return TSAMD_ERR_INVALID;
   TSAMD_HIP_TRY(hipMemsetAsync(stats, 0, 8 * sizeof(int64_t), stream));
-  TSAMD_HIP_TRY(hipMemsetAsync(prodptr, 0, sizeof(int64_t) * (size_t)(M + 1), stream));
   if (M == 0) return TSAMD_OK;
-  if (!rowptrA || !rowptrB || !bins) return TSAMD_ERR_INVALID;
-  if (!workspace || workspace_bytes < scan_workspace_bytes(M + 1)) return TSAMD_ERR_WORKSPACE;
-  hipLaunchKernelGGL(spspmm_count_kernel, dim3((unsigned int)ceil_div(M, 4)), dim3(256), 0, stream,
-                     rowptrA, colA, rowptrB, M, prodptr);
+  hipLaunchKernelGGL(spspmm_count_kernel, dim3((unsigned int)ceil_div(M * kCountLanes, 256)), dim3(256),
+                     0, stream, rowptrA, colA, rowptrB, M, prod);
   TSAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(spspmm_bin_kernel, dim3((unsigned int)ceil_div(M, 256)), dim3(256), 0, stream,
-                     (const int64_t *)prodptr, M, bins, reinterpret_cast<unsigned long long *>(stats));
+                     (const int64_t *)prod, M, bins, reinterpret_cast<unsigned long long *>(stats));
   TSAMD_LAUNCH_CHECK();
-  // prodptr[0..M) holds counts, prodptr[M] = 0: the scan over M + 1 entries leaves the total there
-  return exclusive_scan_i64(prodptr, prodptr, M + 1, stats + ST_P, workspace, stream);
+  return TSAMD_OK;
 }
 
-extern "C" size_t tsamd_spspmm_rows_workspace_bytes(int dtype, int64_t n_large, int64_t P_large) {
+extern "C" size_t tsamd_spspmm_workspace_bytes(int64_t n_large, int64_t P_large) {
   if (n_large <= 0) return 0;
-  return carve_large(nullptr, n_large, P_large, dtype_size(dtype), nullptr);
+  return carve_large(nullptr, n_large, P_large, nullptr);
 }
 
-extern "C" int tsamd_spspmm_rows(int dtype, const int64_t *rowptrA, const int64_t *colA,
-                                 const void *valA, const int64_t *rowptrB, const int64_t *colB,
-                                 const void *valB, int64_t M, int64_t N, const int64_t *prodptr,
-                                 const int64_t *bins, int64_t n_small, int64_t n_medium,
-                                 int64_t n_large, int64_t P_large, int64_t *colT, void *valT,
-                                 int64_t *nnzC, void *workspace, size_t workspace_bytes,
-                                 void *stream_) {
+extern "C" int tsamd_spspmm_symbolic(const int64_t *rowptrA, const int64_t *colA,
+                                     const int64_t *rowptrB, const int64_t *colB, int64_t M,
+                                     int64_t N, const int64_t *prod, const int64_t *bins,
+                                     int64_t n_medium, int64_t n_large, int64_t P_large,
+                                     int64_t *nnzC, void *workspace, size_t workspace_bytes,
+                                     void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || N < 0 || N >= ((int64_t)1 << 32) - 1 || M >= ((int64_t)1 << 31)) return TSAMD_ERR_UNSUPPORTED;
+  if (M == 0) return TSAMD_OK;
+  if (!nnzC || !rowptrA || !colA || !rowptrB || !colB || !prod || !bins) return TSAMD_ERR_INVALID;
+  if (n_medium < 0 || n_large < 0 || n_medium + n_large > M) return TSAMD_ERR_INVALID;
+  if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(n_large, P_large)))
+    return TSAMD_ERR_WORKSPACE;
+  TSAMD_HIP_TRY(hipMemsetAsync(nnzC, 0, sizeof(int64_t) * (size_t)M, stream));
+  hipLaunchKernelGGL((spspmm_symbolic_kernel<64, 10>), dim3((unsigned int)M), dim3(64), 0, stream, rowptrA,
+                     colA, rowptrB, colB, prod, bins, nnzC);
+  TSAMD_LAUNCH_CHECK();
+  if (n_medium > 0) {
+    hipLaunchKernelGGL((spspmm_symbolic_kernel<256, 13>), dim3((unsigned int)n_medium), dim3(256), 0,
+                       stream, rowptrA, colA, rowptrB, colB, prod, bins, nnzC);
+    TSAMD_LAUNCH_CHECK();
+  }
+  if (n_large > 0)
+    return symbolic_large(rowptrA, colA, rowptrB, colB, prod, bins + M, n_large, P_large, M, N, nnzC,
+                          workspace, stream);
+  return TSAMD_OK;
+}
+
+extern "C" int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int64_t *colA,
+                                    const void *valA, const int64_t *rowptrB, const int64_t *colB,
+                                    const void *valB, int64_t M, int64_t N, const int64_t *prod,
+                                    const int64_t *bins, int64_t n_medium, int64_t n_large,
+                                    int64_t P_large, const int64_t *rowptrC, int64_t *colC,
+                                    void *valC, void *workspace, size_t workspace_bytes,
+                                    void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (dtype != TSAMD_F32 && dtype != TSAMD_F64) return TSAMD_ERR_UNSUPPORTED;
-  if (M < 0 || N < 0 || N >= (int64_t)1 << 32) return TSAMD_ERR_UNSUPPORTED;
+  if (M < 0 || N < 0 || N >= ((int64_t)1 << 32) - 1 || M >= ((int64_t)1 << 31)) return TSAMD_ERR_UNSUPPORTED;
   if (M == 0) return TSAMD_OK;
-  if (!nnzC) return TSAMD_ERR_INVALID;
-  TSAMD_HIP_TRY(hipMemsetAsync(nnzC, 0, sizeof(int64_t) * (size_t)M, stream));
-  if (n_small + n_medium + n_large == 0) return TSAMD_OK;
-  if (!rowptrA || !colA || !rowptrB || !colB || !prodptr || !bins || !colT) return TSAMD_ERR_INVALID;
-  if (n_large > 0 &&
-      (!workspace || workspace_bytes < tsamd_spspmm_rows_workspace_bytes(dtype, n_large, P_large)))
+  if (!rowptrA || !colA || !rowptrB || !colB || !prod || !bins || !rowptrC) return TSAMD_ERR_INVALID;
+  if (n_medium < 0 || n_large < 0 || n_medium + n_large > M) return TSAMD_ERR_INVALID;
+  if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(n_large, P_large)))
     return TSAMD_ERR_WORKSPACE;
   int st;
   if (dtype == TSAMD_F32)
-    st = run_rows<float>(rowptrA, colA, valA, rowptrB, colB, valB, prodptr, bins, M, N, n_small, n_medium,
-                         colT, valT, nnzC, stream);
+    st = numeric_rows<float>(rowptrA, colA, valA, rowptrB, colB, valB, prod, bins, M, N, n_medium, rowptrC,
+                             colC, valC, stream);
   else
-    st = run_rows<double>(rowptrA, colA, valA, rowptrB, colB, valB, prodptr, bins, M, N, n_small,
-                          n_medium, colT, valT, nnzC, stream);
+    st = numeric_rows<double>(rowptrA, colA, valA, rowptrB, colB, valB, prod, bins, M, N, n_medium, rowptrC,
+                              colC, valC, stream);
   if (st != TSAMD_OK || n_large == 0) return st;
   if (dtype == TSAMD_F32)
-    return run_large<float>(rowptrA, colA, valA, rowptrB, colB, valB, prodptr, bins + 2 * M, n_large,
-                            P_large, M, N, colT, valT, nnzC, workspace, stream);
-  return run_large<double>(rowptrA, colA, valA, rowptrB, colB, valB, prodptr, bins + 2 * M, n_large,
-                           P_large, M, N, colT, valT, nnzC, workspace, stream);
-}
-
-extern "C" int tsamd_spspmm_compact(int dtype, const int64_t *rowC, const int64_t *rowptrC,
-                                    const int64_t *prodptr, const int64_t *colT, const void *valT,
-                                    int64_t nnz, int64_t *colC, void *valC, void *stream_) {
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (dtype != TSAMD_F32 && dtype != TSAMD_F64) return TSAMD_ERR_UNSUPPORTED;
-  if (nnz < 0) return TSAMD_ERR_INVALID;
-  if (nnz == 0) return TSAMD_OK;
-  if (!rowC || !rowptrC || !prodptr || !colT || !colC) return TSAMD_ERR_INVALID;
-  const unsigned int blocks = (unsigned int)ceil_div(nnz, 256);
-  if (dtype == TSAMD_F32)
-    hipLaunchKernelGGL((spspmm_compact_kernel<float>), dim3(blocks), dim3(256), 0, stream, rowC, rowptrC,
-                       prodptr, colT, reinterpret_cast<const float *>(valT), nnz, colC,
-                       reinterpret_cast<float *>(valC));
-  else
-    hipLaunchKernelGGL((spspmm_compact_kernel<double>), dim3(blocks), dim3(256), 0, stream, rowC,
-                       rowptrC, prodptr, colT, reinterpret_cast<const double *>(valT), nnz, colC,
-                       reinterpret_cast<double *>(valC));
-  TSAMD_LAUNCH_CHECK();
-  return TSAMD_OK;
+    return numeric_large<float>(rowptrA, colA, valA, rowptrB, colB, valB, bins + M, n_large, P_large,
+                                rowptrC, colC, valC, workspace, stream);
+  return numeric_large<double>(rowptrA, colA, valA, rowptrB, colB, valB, bins + M, n_large, P_large,
+                               rowptrC, colC, valC, workspace, stream);
 }

@@ -411,7 +411,8 @@ Tensor segment_reduce(Tensor value, OptTensor perm, Tensor seg_ptr, int64_t nseg
 }
 
 // C = A * B on CSR operands -> (rowptrC, colC, valueC); valueC is empty unless with_value.
-// Two host syncs (product count, nnz(C)) because the output size is data dependent.
+// Count first, write once (csrc/spspmm.hip); two host syncs (size classes, nnz(C)) because the
+// scratch of oversized rows and the output size are data dependent.
 std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor valA,
                                           Tensor rowptrB, Tensor colB, OptTensor valB, int64_t N,
                                           bool with_value) {
@@ -439,57 +440,50 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   auto vopt = iopt.dtype(vdtype);
   void *stream = current_stream(rowptrA);
 
-  Tensor prodptr = torch::empty({M + 1}, iopt), bins = torch::empty({3 * M + 1}, iopt);
+  Tensor prod = torch::empty({M + 1}, iopt), bins = torch::empty({2 * M + 1}, iopt);
   Tensor stats = torch::empty({8}, iopt);
-  Tensor ws0 = workspace(tsamd_spspmm_plan_workspace_bytes(M), rowptrA);
   check_status(tsamd_spspmm_plan(rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
-                                 rowptrB.data_ptr<int64_t>(), M, prodptr.data_ptr<int64_t>(),
-                                 bins.data_ptr<int64_t>(), stats.data_ptr<int64_t>(), ws0.data_ptr(),
-                                 (size_t)ws0.numel(), stream),
+                                 rowptrB.data_ptr<int64_t>(), M, prod.data_ptr<int64_t>(),
+                                 bins.data_ptr<int64_t>(), stats.data_ptr<int64_t>(), stream),
                "tsamd_spspmm_plan");
-  Tensor h = stats.cpu();  // sync 1
+  Tensor h = stats.cpu();  // sync 1: grid sizes, workspace of the rows beyond the LDS capacity
   const int64_t *hs = h.data_ptr<int64_t>();
-  const int64_t P = hs[0], n_small = hs[1], n_medium = hs[2], n_large = hs[3], P_large = hs[4];
+  const int64_t n_medium = hs[2], n_large = hs[3], P_large = hs[4];
 
-  {  // the expand-sort-compress intermediates are data dependent: refuse politely instead of OOM
+  const size_t ws_bytes = tsamd_spspmm_workspace_bytes(n_large, P_large);
+  if (n_large > 0) {  // data dependent scratch: refuse politely instead of an allocator OOM
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const double need = 12.0 * (double)P + (double)tsamd_spspmm_rows_workspace_bytes(dt, n_large, P_large);
-      TORCH_CHECK(need < 0.9 * (double)free_b, "spspmm: ", P, " intermediate products (", P_large,
-                  " of them in rows beyond the LDS capacity) need ~", (int64_t)(need / 1e9),
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      TORCH_CHECK((double)ws_bytes < 0.9 * (double)free_b, "spspmm: ", P_large, " intermediate products in ",
+                  n_large, " rows beyond the LDS capacity need ~", (int64_t)((double)ws_bytes / 1e9),
                   " GB of scratch, more than the free device memory");
-    }
   }
-  Tensor colT = torch::empty({P}, iopt);
-  Tensor valT = with_value ? torch::empty({P}, vopt) : Tensor();
+  Tensor ws1 = workspace(ws_bytes, rowptrA);
   Tensor rowptrC = torch::zeros({M + 1}, iopt);  // nnzC in [0, M), scanned in place below
-  Tensor ws1 = workspace(tsamd_spspmm_rows_workspace_bytes(dt, n_large, P_large), rowptrA);
-  check_status(
-      tsamd_spspmm_rows(dt, rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
-                        valA.has_value() ? va.data_ptr() : nullptr, rowptrB.data_ptr<int64_t>(),
-                        colB.data_ptr<int64_t>(), valB.has_value() ? vb.data_ptr() : nullptr, M, N,
-                        prodptr.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_small, n_medium,
-                        n_large, P_large, colT.data_ptr<int64_t>(),
-                        with_value ? valT.data_ptr() : nullptr, rowptrC.data_ptr<int64_t>(),
-                        ws1.data_ptr(), (size_t)ws1.numel(), stream),
-      "tsamd_spspmm_rows");
+  check_status(tsamd_spspmm_symbolic(rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
+                                     rowptrB.data_ptr<int64_t>(), colB.data_ptr<int64_t>(), M, N,
+                                     prod.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_medium,
+                                     n_large, P_large, rowptrC.data_ptr<int64_t>(),
+                                     ws1.data_ptr(), (size_t)ws1.numel(), stream),
+               "tsamd_spspmm_symbolic");
   Tensor total = torch::empty({1}, iopt);
   Tensor ws2 = workspace(tsamd_exclusive_scan_workspace_bytes(M + 1), rowptrA);
   check_status(tsamd_exclusive_scan_i64(rowptrC.data_ptr<int64_t>(), rowptrC.data_ptr<int64_t>(),
                                         M + 1, total.data_ptr<int64_t>(), ws2.data_ptr(),
                                         (size_t)ws2.numel(), stream),
                "tsamd_exclusive_scan_i64");
-  const int64_t nnz = total.item<int64_t>();  // sync 2
-  Tensor rowC = torch::empty({nnz}, iopt), colC = torch::empty({nnz}, iopt);
+  const int64_t nnz = total.item<int64_t>();  // sync 2: the output size
+  Tensor colC = torch::empty({nnz}, iopt);
   Tensor valC = with_value ? torch::empty({nnz}, vopt) : torch::empty({0}, vopt);
-  check_status(tsamd_ptr2ind(rowptrC.data_ptr<int64_t>(), M, nnz, rowC.data_ptr<int64_t>(), stream),
-               "tsamd_ptr2ind");
-  check_status(tsamd_spspmm_compact(dt, rowC.data_ptr<int64_t>(), rowptrC.data_ptr<int64_t>(),
-                                    prodptr.data_ptr<int64_t>(), colT.data_ptr<int64_t>(),
-                                    with_value ? valT.data_ptr() : nullptr, nnz,
-                                    colC.data_ptr<int64_t>(), with_value ? valC.data_ptr() : nullptr,
-                                    stream),
-               "tsamd_spspmm_compact");
+  check_status(
+      tsamd_spspmm_numeric(dt, rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
+                           valA.has_value() ? va.data_ptr() : nullptr, rowptrB.data_ptr<int64_t>(),
+                           colB.data_ptr<int64_t>(), valB.has_value() ? vb.data_ptr() : nullptr, M, N,
+                           prod.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_medium, n_large,
+                           P_large, rowptrC.data_ptr<int64_t>(), colC.data_ptr<int64_t>(),
+                           with_value ? valC.data_ptr() : nullptr, ws1.data_ptr(), (size_t)ws1.numel(),
+                           stream),
+      "tsamd_spspmm_numeric");
   return std::make_tuple(rowptrC, colC, valC);
 }
 

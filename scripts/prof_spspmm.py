@@ -1,14 +1,10 @@
-import sys, os
+"""C4 / R-MAT stress SpSpMM timing (whole op) -- run under rocprofv3 --kernel-trace --stats for the breakdown."""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import pytorch_sparse_amd as ts
-from pytorch_sparse_amd import synth
+from tests import baseline_configs as bc
 dev = torch.device('cuda:0')
-m = n = 500000; nnz = 7500000
-row, col = synth.uniform_edges(m, n, nnz, seed=0, device=dev)
-A = ts.SparseTensor(row=row, col=col, value=synth.values(nnz, device=dev), sparse_sizes=(m, n)).coalesce()
-At = A.t()
-for _ in range(3):
-    C = A @ At
-torch.cuda.synchronize()
-print(C.nnz())
+import pytorch_sparse_amd  # noqa
+for kind in sys.argv[1:] or ['c4']:
+    r = bc.run_spspmm(dev, kind, cpu='cpu' in os.environ.get('SPSPMM_CHECK', ''), iters=5)
+    print(json.dumps(r), flush=True)
