@@ -96,6 +96,31 @@ int tsamd_spmm_profiled(int dtype, int reduce, const int64_t *rowptr,
                         void *stream, float *kernel_ms_host);
 
 /* ------------------------------------------------------------------------ *
+ * Relabelled ("channel-camping free") layout, end to end.  tsamd_spmm fixes the camping of
+ * Kronecker-like graphs by copying `mat` to hashed row positions on EVERY call (15 % of a
+ * north-star step).  A caller that runs many products with the same matrix (every layer / epoch
+ * of a GNN) can instead keep its dense matrices in that layout for good:
+ *
+ *   position of row i of a [n, K] matrix = tsamd_relabel_ids(i, n)   (a bijection on [0, n))
+ *
+ *   tsamd_relabel_ids       out[j] = position(ids[j]) (ids == NULL: ids[j] = j, i.e. the whole map);
+ *                           ids outside [0, n) are passed through (the reference's "E = no winner").
+ *   tsamd_spmm_relabelled   same arithmetic as tsamd_spmm -- bit-identical values -- with
+ *                           col_h = position(col) (computed once per matrix), mat_h in relabelled
+ *                           row order (positions over N) and out_h / arg_out_h written in
+ *                           relabelled row order (positions over M): no probe, no copy, and the
+ *                           result feeds the next product as it is.  arg_out_h holds the ORIGINAL
+ *                           entry ids (E for "no winner").
+ * ------------------------------------------------------------------------ */
+int tsamd_relabel_ids(const int64_t *ids, int64_t count, int64_t n, int64_t *out, void *stream);
+size_t tsamd_spmm_relabelled_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M,
+                                             int64_t N, int64_t K, int64_t E);
+int tsamd_spmm_relabelled(int dtype, int reduce, const int64_t *rowptr, const int64_t *col_h,
+                          const void *value, const void *mat_h, void *out_h, int64_t *arg_out_h,
+                          int64_t B, int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ *
  * Gradient of SUM/MEAN SpMM w.r.t. the sparse values (an SDDMM over the
  * pattern).  Replaces spmm_value_bw_cuda / spmm_value_bw_cpu
  * (csrc/cuda/spmm_cuda.cu:196-237, csrc/cpu/spmm_cpu.cpp:103-152).

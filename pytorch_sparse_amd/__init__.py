@@ -52,6 +52,7 @@ from .transpose import t, transpose  # noqa: E402
 from .matmul import matmul, spmm_sum, spmm_mean, spmm_min, spmm_max, spspmm_sum  # noqa: E402
 from .coalesce import coalesce  # noqa: E402
 from .spmm import spmm  # noqa: E402
+from .relabelled import matmul_relabelled, to_relabelled, from_relabelled, relabel_index  # noqa: E402
 from .spspmm import spspmm  # noqa: E402
 from .reduce import sum, mean, min, max  # noqa: E402,A004
 from .mul import mul, mul_, mul_nnz, mul_nnz_, add, add_, add_nnz, add_nnz_  # noqa: E402
@@ -72,5 +73,6 @@ __all__ = [
     'add_nnz_', 'narrow', '__narrow_diag__', 'select', 'index_select', 'index_select_nnz',
     'masked_select', 'masked_select_nnz', 'permute', 'cat', 'remove_diag', 'set_diag', 'fill_diag',
     'get_diag', 'sample', 'sample_adj', 'random_walk', 'saint_subgraph', 'reverse_cuthill_mckee', 'partition', 'to_torch_sparse', 'from_torch_sparse', 'to_scipy', 'from_scipy', 'eye', 'spadd',
+    'matmul_relabelled', 'to_relabelled', 'from_relabelled', 'relabel_index',
     '__version__',
 ]

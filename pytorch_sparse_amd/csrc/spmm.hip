@@ -83,6 +83,10 @@ struct Workspace {
   int *relabel_flag;  // device int[4]: sample counters (see use_relabel)
   void *xperm;        // [B][N][K] copy of mat with rows at hashed positions
   uint32_t hash_bits, hash_mul, hash_shift;
+  // relabelled layout end to end (tsamd_spmm_relabelled): output row m is stored at position
+  // hash_row(m, M, ...), `col` already holds hashed ids and `mat` is already in hashed row order
+  int out_relabel;
+  uint32_t ohash_bits, ohash_shift;
 };
 
 // ---------------------------------------------------------------------------
@@ -103,6 +107,11 @@ __device__ __forceinline__ uint32_t hash_row(uint32_t c, uint32_t N, uint32_t bi
     c ^= c >> shift;
   } while (c >= N);
   return c;
+}
+
+__device__ __forceinline__ uint64_t out_position(const Workspace &ws, int64_t r, int64_t M) {
+  return ws.out_relabel ? (uint64_t)hash_row((uint32_t)r, (uint32_t)M, ws.ohash_bits, ws.hash_mul, ws.ohash_shift)
+                        : (uint64_t)r;
 }
 
 // counters: [1] #sampled ids with 3 low zero
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
         if (incoming && r == r0) {  // head of a cut row: the fix-up kernel finishes it
           write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg64);
         } else {
-          const uint64_t o = out_b + (uint64_t)r * K;
+          const uint64_t o = out_b + out_position(ws, r, M) * K;
           write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, rend - estart, mean, E);
         }
       }
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
       }
     }
     if constexpr (kWideFold) val[0] = (A)wide;
-    const uint64_t o = ((uint64_t)b * M + R) * K + k;
+    const uint64_t o = ((uint64_t)b * M + out_position(ws, R, M)) * K + k;
     write_row<T, 1, RED>(out + o, arg_out + o, val, arg, deg, mean, E);
   }
 }
@@ -596,7 +605,7 @@ bool relabel_possible(int dtype, int64_t N, int64_t K, int64_t E) {
 }
 
 size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,
-             int64_t E, Workspace *ws) {
+             int64_t E, Workspace *ws, bool relabelled = false) {
   int64_t P, items;
   plan_partition(M, E, K * (int64_t)dtype_size(dtype), &P, &items);
   const bool minmax = reduce == TSAMD_MIN || reduce == TSAMD_MAX;
@@ -619,11 +628,15 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.tail_arg = reinterpret_cast<int64_t *>(minmax ? take(sizeof(int64_t) * plane) : nullptr);
   w.relabel_mode = 0;
   w.relabel_flag = reinterpret_cast<int *>(take(256));
-  w.xperm = relabel_possible(dtype, N, K, E) ? take(dtype_size(dtype) * (size_t)B * N * K) : nullptr;
+  w.xperm = (!relabelled && relabel_possible(dtype, N, K, E)) ? take(dtype_size(dtype) * (size_t)B * N * K) : nullptr;
   w.hash_bits = 1;
   while (w.hash_bits < 32 && ((uint64_t)1 << w.hash_bits) < (uint64_t)(N > 1 ? N : 2)) ++w.hash_bits;
   w.hash_mul = 0x9E3779B1u;  // odd (golden-ratio) multiplier
   w.hash_shift = w.hash_bits > 1 ? w.hash_bits / 2 : 1;
+  w.out_relabel = 0;
+  w.ohash_bits = 1;
+  while (w.ohash_bits < 32 && ((uint64_t)1 << w.ohash_bits) < (uint64_t)(M > 1 ? M : 2)) ++w.ohash_bits;
+  w.ohash_shift = w.ohash_bits > 1 ? w.ohash_bits / 2 : 1;
   if (ws) *ws = w;
   return off;
 }
@@ -641,7 +654,7 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[0], stream));
   {
     int mode = 0;
-    if (ws.xperm != nullptr && VEC > 1) {
+    if (ws.xperm != nullptr && VEC > 1 && !ws.out_relabel) {
       const char *env = getenv("TSAMD_SPMM_RELABEL");
       mode = env ? (env[0] == '1' ? 1 : (env[0] == '0' ? 0 : 2)) : 2;
     }
@@ -738,7 +751,8 @@ extern "C" size_t tsamd_spmm_workspace_bytes(int dtype, int reduce, int64_t B, i
 static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
                       const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
                       int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
-                      size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev) {
+                      size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev,
+                      bool relabelled = false) {
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
@@ -748,11 +762,15 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   if (B * M * K == 0) return TSAMD_OK;  // nothing to write
   if (!rowptr || !out || (E > 0 && (!col || !mat)) || (minmax && !arg_out))
     return TSAMD_ERR_INVALID;
-  const size_t need = carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr);
+  const size_t need = carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr, relabelled);
   if (!workspace || workspace_bytes_given < need) return TSAMD_ERR_WORKSPACE;
   if ((uintptr_t)workspace % 256 != 0) return TSAMD_ERR_WORKSPACE;
   Workspace ws;
-  carve(workspace, dtype, reduce, B, M, N, K, E, &ws);
+  carve(workspace, dtype, reduce, B, M, N, K, E, &ws, relabelled);
+  if (relabelled) {
+    if (M >= (int64_t)1 << 32) return TSAMD_ERR_UNSUPPORTED;
+    ws.out_relabel = 1;
+  }
   const size_t es = dtype_size(dtype);
   int vec = es == 2 ? 4 : (int)(16 / es);  // widest packet for the type (see dispatch_spmm)
   while (vec > 1 && !((K % vec) == 0 && ((uintptr_t)mat % (vec * es)) == 0 &&
@@ -772,6 +790,58 @@ extern "C" int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const in
                           size_t workspace_bytes_given, void *stream_) {
   return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, workspace,
                     workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// relabelled ("camping-free") layout end to end: see include/tsamd.h
+// ---------------------------------------------------------------------------
+namespace tsamd {
+namespace {
+struct RelabelParams {
+  uint32_t bits, mul, shift;
+};
+RelabelParams relabel_params(int64_t n) {
+  RelabelParams p;
+  p.bits = 1;
+  while (p.bits < 32 && ((uint64_t)1 << p.bits) < (uint64_t)(n > 1 ? n : 2)) ++p.bits;
+  p.mul = 0x9E3779B1u;
+  p.shift = p.bits > 1 ? p.bits / 2 : 1;
+  return p;
+}
+__global__ void relabel_ids_kernel(const int64_t *__restrict__ ids, int64_t count, uint32_t n,
+                                   RelabelParams p, int64_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int64_t v = ids ? ids[i] : i;
+  out[i] = (v < 0 || v >= (int64_t)n) ? v : (int64_t)hash_row((uint32_t)v, n, p.bits, p.mul, p.shift);
+}
+}  // namespace
+}  // namespace tsamd
+
+extern "C" int tsamd_relabel_ids(const int64_t *ids, int64_t count, int64_t n, int64_t *out,
+                                 void *stream_) {
+  if (count < 0 || n < 0 || n >= (int64_t)1 << 32) return TSAMD_ERR_UNSUPPORTED;
+  if (count == 0) return TSAMD_OK;
+  if (!out) return TSAMD_ERR_INVALID;
+  hipLaunchKernelGGL(relabel_ids_kernel, dim3((unsigned int)ceil_div(count, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), ids, count, (uint32_t)n, relabel_params(n), out);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+extern "C" size_t tsamd_spmm_relabelled_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M,
+                                                        int64_t N, int64_t K, int64_t E) {
+  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
+  return carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr, true);
+}
+
+extern "C" int tsamd_spmm_relabelled(int dtype, int reduce, const int64_t *rowptr,
+                                     const int64_t *col_h, const void *value, const void *mat_h,
+                                     void *out_h, int64_t *arg_out_h, int64_t B, int64_t M, int64_t N,
+                                     int64_t K, int64_t E, void *workspace,
+                                     size_t workspace_bytes_given, void *stream_) {
+  return spmm_entry(dtype, reduce, rowptr, col_h, value, mat_h, out_h, arg_out_h, B, M, N, K, E, workspace,
+                    workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, true);
 }
 
 extern "C" int tsamd_spmm_profiled(int dtype, int reduce, const int64_t *rowptr,

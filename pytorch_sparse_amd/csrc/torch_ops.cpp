@@ -251,6 +251,140 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
   }
 };
 
+// ---- relabelled ("channel-camping free") layout, end to end (include/tsamd.h) -----------------
+// position of every id of `ids` in a relabelled [n, *] matrix; ids == None: the whole map [n]
+Tensor relabel_ids(OptTensor ids, int64_t n, Tensor like) {
+  check_gpu(like, "like");
+  c10::hip::HIPGuard guard(like.get_device());
+  Tensor src;
+  int64_t count = n;
+  if (ids.has_value()) {
+    check_index(ids.value(), "ids");
+    src = ids.value().contiguous();
+    count = src.numel();
+  }
+  Tensor out = torch::empty({count}, like.options().dtype(at::kLong).requires_grad(false));
+  check_status(tsamd_relabel_ids(ids.has_value() ? src.data_ptr<int64_t>() : nullptr, count, n,
+                                 out.data_ptr<int64_t>(), current_stream(like)),
+               "tsamd_relabel_ids");
+  return out;
+}
+
+std::tuple<Tensor, OptTensor> spmm_relabelled_fw(const Tensor &rowptr, const Tensor &col_h,
+                                                 const OptTensor &opt_value, Tensor mat_h,
+                                                 const std::string &reduce) {
+  check_index(rowptr, "rowptr");
+  check_index(col_h, "col_h");
+  check_gpu(mat_h, "mat");
+  TORCH_CHECK(mat_h.dim() >= 2, "Input mismatch");
+  if (opt_value.has_value()) {
+    check_gpu(opt_value.value(), "value");
+    TORCH_CHECK(opt_value.value().dim() == 1 && opt_value.value().size(0) == col_h.size(0), "Input mismatch");
+    TORCH_CHECK(opt_value.value().scalar_type() == mat_h.scalar_type(), "expected scalar type ",
+                mat_h.scalar_type(), " but found ", opt_value.value().scalar_type());
+  }
+  c10::hip::HIPGuard guard(rowptr.get_device());
+  mat_h = mat_h.contiguous();
+  Tensor rp = rowptr.contiguous(), c = col_h.contiguous();
+  OptTensor value = opt_value.has_value() ? OptTensor(opt_value.value().contiguous()) : std::nullopt;
+  auto sizes = mat_h.sizes().vec();
+  const int64_t M = rp.numel() - 1, E = c.numel();
+  const int64_t N = mat_h.size(-2), K = mat_h.size(-1);
+  const int64_t B = (N * K) > 0 ? mat_h.numel() / (N * K) : 1;
+  sizes[mat_h.dim() - 2] = M;
+  Tensor out = torch::empty(sizes, mat_h.options().requires_grad(false));
+  const int red = reduce_code(reduce);
+  OptTensor arg_out = std::nullopt;
+  int64_t *arg_ptr = nullptr;
+  if (red == TSAMD_MIN || red == TSAMD_MAX) {
+    arg_out = torch::empty(sizes, rp.options());
+    arg_ptr = arg_out.value().data_ptr<int64_t>();
+  }
+  const int dt = dtype_code(mat_h);
+  Tensor ws = workspace(tsamd_spmm_relabelled_workspace_bytes(dt, red, B, M, N, K, E), mat_h);
+  check_status(tsamd_spmm_relabelled(dt, red, rp.data_ptr<int64_t>(), c.data_ptr<int64_t>(),
+                                     ptr_or_null(value), mat_h.data_ptr(), out.data_ptr(), arg_ptr, B, M,
+                                     N, K, E, ws.data_ptr(), (size_t)ws.numel(), current_stream(mat_h)),
+               "tsamd_spmm_relabelled");
+  return std::make_tuple(out, arg_out);
+}
+
+// sum / mean in the relabelled layout with both gradients; the backward works in the same layout
+// (grad_out arrives relabelled over M, grad_mat leaves relabelled over N).
+// Saved: row, rowptr, col_h, value, rowcount, colptr, csr2csc, mat_h.
+class SpmmRelabelledFunction : public torch::autograd::Function<SpmmRelabelledFunction> {
+ public:
+  static variable_list forward(AutogradContext *ctx, OptTensor opt_row, Tensor rowptr, Tensor col_h,
+                               Tensor value, OptTensor opt_rowcount, OptTensor opt_colptr,
+                               OptTensor opt_csr2csc, Tensor mat_h, bool has_value, bool mean) {
+    if ((has_value && needs_grad(value)) || needs_grad(mat_h)) {
+      TORCH_CHECK(opt_row.has_value(), "Argument `row` is missing");
+      if (mean) TORCH_CHECK(opt_rowcount.has_value(), "Argument `rowcount` is missing");
+    }
+    if (needs_grad(mat_h)) {
+      TORCH_CHECK(opt_colptr.has_value(), "Argument `colptr` is missing");
+      TORCH_CHECK(opt_csr2csc.has_value(), "Argument `csr2csc` is missing");
+    }
+    OptTensor v = has_value ? OptTensor(value) : std::nullopt;
+    Tensor out = std::get<0>(spmm_relabelled_fw(rowptr, col_h, v, mat_h, mean ? "mean" : "sum"));
+    ctx->saved_data["has_value"] = has_value;
+    ctx->saved_data["mean"] = mean;
+    ctx->save_for_backward({opt_row.value_or(col_h), rowptr, col_h, value, opt_rowcount.value_or(col_h),
+                            opt_colptr.value_or(col_h), opt_csr2csc.value_or(col_h), mat_h});
+    return {out};
+  }
+
+  static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+    const bool has_value = ctx->saved_data["has_value"].toBool();
+    const bool mean = ctx->saved_data["mean"].toBool();
+    Tensor grad_h = grad_outs[0].contiguous();
+    auto s = ctx->get_saved_variables();
+    Tensor row = s[0], rowptr = s[1], col_h = s[2], value = s[3], rowcount = s[4], colptr = s[5],
+           csr2csc = s[6], mat_h = s[7];
+    const int64_t M = rowptr.numel() - 1;
+    Tensor grad_value, grad_mat;
+    if (has_value && needs_grad(value)) {
+      // SDDMM over the pattern with both operands gathered at relabelled positions
+      Tensor row_h = relabel_ids(row, M, row);
+      grad_value = spmm_value_bw(row_h, rowptr, col_h, mat_h, grad_h, "sum");
+      if (mean) grad_value = grad_value / rowcount.index_select(0, row).to(grad_value.scalar_type()).clamp_min_(1);
+    }
+    if (needs_grad(mat_h)) {
+      Tensor row_t = row.index_select(0, csr2csc);
+      OptTensor w = std::nullopt;
+      if (mean) {
+        Tensor cnt = rowcount.index_select(0, row_t).to(mat_h.scalar_type()).clamp_min_(1);
+        w = has_value ? value.detach().index_select(0, csr2csc).div_(cnt) : cnt.reciprocal_();
+      } else if (has_value) {
+        w = value.detach().index_select(0, csr2csc);
+      }
+      grad_mat = std::get<0>(spmm_relabelled_fw(colptr, relabel_ids(row_t, M, row_t), w, grad_h, "sum"));
+    }
+    return {Tensor(), Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_mat,
+            Tensor(), Tensor()};
+  }
+};
+
+// (out_h, arg_out_h or an empty tensor).  min / max are forward only in this layout.
+std::tuple<Tensor, Tensor> spmm_relabelled(OptTensor opt_row, Tensor rowptr, Tensor col_h,
+                                           OptTensor opt_value, OptTensor opt_rowcount,
+                                           OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat_h,
+                                           std::string reduce) {
+  const int red = reduce_code(reduce);
+  if (red == TSAMD_MIN || red == TSAMD_MAX) {
+    TORCH_CHECK(!needs_grad(mat_h) && !(opt_value.has_value() && needs_grad(opt_value.value())),
+                "spmm_relabelled: min / max have no backward in the relabelled layout; use "
+                "torch.ops.torch_sparse.spmm_", reduce, " on the plain layout for training");
+    auto r = spmm_relabelled_fw(rowptr, col_h, opt_value, mat_h, reduce);
+    return std::make_tuple(std::get<0>(r), std::get<1>(r).value());
+  }
+  Tensor value = opt_value.value_or(col_h);
+  Tensor out = SpmmRelabelledFunction::apply(opt_row, rowptr, col_h, value, opt_rowcount, opt_colptr,
+                                             opt_csr2csc, mat_h, opt_value.has_value(),
+                                             red == TSAMD_MEAN)[0];
+  return std::make_tuple(out, torch::empty({0}, rowptr.options()));
+}
+
 // ---- registered entry points (reference signatures) -----------------------------------------
 Tensor spmm_sum(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_value,
                 OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat) {
@@ -1003,6 +1137,8 @@ static auto registry = torch::RegisterOperators()
                            .op("tsamd::coalesce_index", &coalesce_index)
                            .op("tsamd::segment_reduce", &segment_reduce)
                            .op("tsamd::spspmm", &spspmm)
+                           .op("tsamd::relabel_ids", &relabel_ids)
+                           .op("tsamd::spmm_relabelled", &spmm_relabelled)
                            .op("tsamd::select_segments", &select_segments)
                            .op("tsamd::filter_coo", &filter_coo)
                            .op("tsamd::scatter_rows", &scatter_rows)
