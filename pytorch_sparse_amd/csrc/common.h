@@ -48,21 +48,43 @@ __host__ __device__ inline float bf16_to_f32(bf16_t h) {
   return c.f;
 }
 
-// round-to-nearest-even, NaN -> quiet NaN (same rule as c10::BFloat16)
+// round-to-nearest-even, NaN -> quiet NaN (same rule as c10::BFloat16).  On the device the rounding
+// is gfx950's v_cvt_pk_bf16_f32 (one instruction instead of five); NaNs are canonicalised to 0x7FC0
+// by hand because c10 does (the hardware keeps sign / payload).
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {
+  bf16_t r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __bf16 h = (__bf16)f;
+  uint16_t b;
+  __builtin_memcpy(&b, &h, 2);
+  r.bits = f != f ? (uint16_t)0x7FC0 : b;
+#else
   union {
     uint32_t u;
     float f;
   } c;
   c.f = f;
-  bf16_t r;
   if (f != f) {
     r.bits = 0x7FC0;
   } else {
     uint32_t bias = 0x7FFFu + ((c.u >> 16) & 1u);
     r.bits = (uint16_t)((c.u + bias) >> 16);
   }
+#endif
   return r;
+}
+
+// fp32 -> bf16 -> fp32 for values that are only compared afterwards (NaN payloads do not matter)
+__device__ inline float round_through_bf16(float f) {
+  const __bf16 h = (__bf16)f;
+  uint16_t b;
+  __builtin_memcpy(&b, &h, 2);
+  union {
+    uint32_t u;
+    float f;
+  } c;
+  c.u = ((uint32_t)b) << 16;
+  return c.f;
 }
 
 // Traits<T>: accumulator type, conversions, and the reducer's init values
@@ -114,7 +136,7 @@ struct Traits<bf16_t> {
   static constexpr bool kNarrow = true;
   __device__ static inline acc_t to_acc(bf16_t x) { return bf16_to_f32(x); }
   __device__ static inline bf16_t from_acc(acc_t a) { return f32_to_bf16(a); }
-  __device__ static inline acc_t round_acc(acc_t a) { return bf16_to_f32(f32_to_bf16(a)); }
+  __device__ static inline acc_t round_acc(acc_t a) { return round_through_bf16(a); }
   // 0x7F7F = largest finite bf16
   __device__ static inline acc_t max_init() { return 3.38953139e+38f; }
   __device__ static inline acc_t lowest_init() { return -3.38953139e+38f; }
@@ -203,6 +225,44 @@ template <typename A>
 __device__ inline A lane_xor(A v, int mask) {
   int lane = (int)(threadIdx.x & 63);
   return lane_read(v, lane ^ mask);
+}
+
+// Value held by lane + OFF (OFF = 1, 2, 4, 8, 16, 32), for reductions towards the low lanes: pure
+// VALU data movement (DPP row_shl inside a row of 16 lanes, gfx950's v_permlane16_swap /
+// v_permlane32_swap across rows), no LDS-pipe round trip like ds_bpermute.  Lanes whose source
+// would lie outside the wave (or, for OFF < 16, outside their row of 16) get an unspecified value.
+template <int OFF>
+__device__ __forceinline__ uint32_t lane_down_u32(uint32_t v) {
+  if constexpr (OFF == 32) {
+    return (uint32_t)__builtin_amdgcn_permlane32_swap(v, v, false, false)[1];
+  } else if constexpr (OFF == 16) {
+    return (uint32_t)__builtin_amdgcn_permlane16_swap(v, v, false, false)[1];
+  } else {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8, "lane_down: power-of-two offsets only");
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x100 | OFF, 0xF, 0xF, false);  // row_shl:OFF
+  }
+}
+template <int OFF>
+__device__ __forceinline__ float lane_down(float v) {
+  return __uint_as_float(lane_down_u32<OFF>(__float_as_uint(v)));
+}
+template <int OFF>
+__device__ __forceinline__ int32_t lane_down(int32_t v) {
+  return (int32_t)lane_down_u32<OFF>((uint32_t)v);
+}
+template <int OFF>
+__device__ __forceinline__ uint32_t lane_down(uint32_t v) {
+  return lane_down_u32<OFF>(v);
+}
+template <int OFF>
+__device__ __forceinline__ int64_t lane_down(int64_t v) {
+  const uint32_t lo = lane_down_u32<OFF>((uint32_t)(uint64_t)v);
+  const uint32_t hi = lane_down_u32<OFF>((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <int OFF>
+__device__ __forceinline__ double lane_down(double v) {
+  return __longlong_as_double(lane_down<OFF>((int64_t)__double_as_longlong(v)));
 }
 
 // A 16-byte (or narrower) packet of VEC elements; alignment lets the compiler

@@ -60,7 +60,11 @@ constexpr int RED_MAX = 2;
 #ifndef TSAMD_TARGET_WAVES
 #define TSAMD_TARGET_WAVES 32768
 #endif
+#ifndef TSAMD_MINMAX_UNROLL
+#define TSAMD_MINMAX_UNROLL 2
+#endif
 constexpr int kUnroll = TSAMD_UNROLL;      // gathers in flight per group
+constexpr int kMinMaxUnroll = TSAMD_MINMAX_UNROLL;  // min / max carry (value, arg) per element: fewer
 constexpr int kWavesPerBlock = TSAMD_WPB;  // 256-thread workgroups
 constexpr int64_t kNoArg = 0x7fffffffffffffffLL;
 
@@ -199,7 +203,7 @@ __device__ __forceinline__ void init_acc(typename Traits<T>::acc_t (&val)[VEC], 
 // Accumulate window entries [lo, hi) (window-relative, 0..64) of one row.  `wrel` is the window's
 // offset from the partition's first edge (min/max args are kept as 32-bit offsets).
 // c_l / w_l hold the window's column ids / weights, one per lane.  All lanes
-// stay active; slots past `hi` re-read the last valid entry and are masked.
+// stay active; slots past `hi` re-read the last valid entry (masked for sums, harmless for min / max).
 template <typename T, int VEC, int RED>
 __device__ __forceinline__ void accumulate_window(
     int lo, int hi, uint32_t wrel, uint32_t c_l, typename Traits<T>::acc_t w_l, bool has_value,
@@ -208,7 +212,7 @@ __device__ __forceinline__ void accumulate_window(
   using A = typename Traits<T>::acc_t;
   using P = Pack<T, VEC>;
   // min/max carry (value, arg) per element: fewer gathers in flight keep the VGPR count down
-  constexpr int kU = RED == RED_ADD ? kUnroll : (kUnroll > 2 ? 2 : kUnroll);
+  constexpr int kU = RED == RED_ADD ? kUnroll : kMinMaxUnroll;
   const int n = hi - lo;
   const int nsteps = (n + (1 << lgG) - 1) >> lgG;
   for (int s = 0; s < nsteps; s += kU) {
@@ -219,6 +223,7 @@ __device__ __forceinline__ void accumulate_window(
     for (int u = 0; u < kU; ++u) {
       idx[u] = lo + ((s + u) << lgG) + g;
       const int src = idx[u] < hi ? idx[u] : hi - 1;
+      if constexpr (RED != RED_ADD) idx[u] = src;  // see below: min / max need no mask
       const uint32_t c = lane_read(c_l, src);
       w[u] = lane_read(w_l, src);
       x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
@@ -233,37 +238,68 @@ __device__ __forceinline__ void accumulate_window(
           const A p = w[u] * xv;
           val[j] += ok ? p : A(0);
         } else {
+          // Slots past `hi` re-read the row's last entry: min / max are idempotent, the duplicate
+          // carries the same (value, edge id) as the original, so nothing has to be masked
+          // (strict compares: an equal candidate with a larger or equal id never replaces).
           // without values the candidate is the stored element itself (no product to round)
           const A p = has_value ? Traits<T>::round_acc(w[u] * xv) : xv;
           const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
-          if (ok && better) {
-            val[j] = p;
-            arg[j] = wrel + (uint32_t)idx[u];
-          }
+          val[j] = better ? p : val[j];
+          arg[j] = better ? wrel + (uint32_t)idx[u] : arg[j];
         }
       }
     }
   }
 }
 
-// Butterfly over the G groups; afterwards every lane holds the combined result.
-template <typename A, int VEC, int RED, typename ARG>
-__device__ __forceinline__ void reduce_groups(int lgG, A (&val)[VEC], ARG (&arg)[VEC]) {
-  for (int off = 32; off >= (64 >> lgG); off >>= 1) {
+// Reduce over the G lane groups towards group 0 (the only one that writes): log2(G) levels, each
+// combining a lane with lane + off.  The exchanges are VALU-only (lane_down: DPP / permlane swaps),
+// so a row end costs no LDS-pipe round trips; the pairs combined at every level are the ones a
+// butterfly would combine, i.e. group 0 ends up with bit-identical results.
+template <int OFF, typename A, int VEC, int RED, typename ARG>
+__device__ __forceinline__ void reduce_level(A (&val)[VEC], ARG (&arg)[VEC]) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const A o = lane_xor(val[j], off);
-      if constexpr (RED == RED_ADD) {
-        val[j] += o;
-      } else {
-        const ARG oa = lane_xor(arg[j], off);
-        const bool better = RED == RED_MIN ? (o < val[j]) : (o > val[j]);
-        if (better || (o == val[j] && oa < arg[j])) {
-          val[j] = o;
-          arg[j] = oa;
-        }
+  for (int j = 0; j < VEC; ++j) {
+    const A o = lane_down<OFF>(val[j]);
+    if constexpr (RED == RED_ADD) {
+      val[j] += o;
+    } else {
+      const ARG oa = lane_down<OFF>(arg[j]);
+      const bool better = RED == RED_MIN ? (o < val[j]) : (o > val[j]);
+      if (better || (o == val[j] && oa < arg[j])) {
+        val[j] = o;
+        arg[j] = oa;
       }
     }
+  }
+}
+
+template <typename A, int VEC, int RED, typename ARG>
+__device__ __forceinline__ void reduce_groups(int lgG, A (&val)[VEC], ARG (&arg)[VEC]) {
+  if (lgG >= 1) reduce_level<32, A, VEC, RED, ARG>(val, arg);
+  if (lgG >= 2) reduce_level<16, A, VEC, RED, ARG>(val, arg);
+  if (lgG >= 3) reduce_level<8, A, VEC, RED, ARG>(val, arg);
+  if (lgG >= 4) reduce_level<4, A, VEC, RED, ARG>(val, arg);
+  if (lgG >= 5) reduce_level<2, A, VEC, RED, ARG>(val, arg);
+  if (lgG >= 6) reduce_level<1, A, VEC, RED, ARG>(val, arg);
+}
+
+// Non-temporal store of a packet (any size that is a multiple of 4 bytes goes out as dwords).
+template <typename U, int VEC>
+__device__ __forceinline__ void nt_store(U *dst, const Pack<U, VEC> &v) {
+  constexpr int kBytes = (int)sizeof(Pack<U, VEC>);
+  if constexpr (kBytes % 16 == 0) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < kBytes / 16; ++i)
+      __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(&v)[i], reinterpret_cast<u32x4 *>(dst) + i);
+  } else if constexpr (kBytes == 8) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(*reinterpret_cast<const u32x2 *>(&v), reinterpret_cast<u32x2 *>(dst));
+  } else if constexpr (kBytes == 4) {
+    __builtin_nontemporal_store(*reinterpret_cast<const unsigned int *>(&v), reinterpret_cast<unsigned int *>(dst));
+  } else {
+    *reinterpret_cast<Pack<U, VEC> *>(dst) = v;
   }
 }
 
@@ -312,8 +348,10 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
         a.v[j] = E;
       }
     }
-    *reinterpret_cast<Pack<T, VEC> *>(outk) = o;
-    *reinterpret_cast<Pack<int64_t, VEC> *>(argk) = a;
+    // written once, never re-read here: keep them out of L2 (1.3 GB of arg ids at config-3 size
+    // would otherwise evict the gathered rows of `mat`)
+    nt_store(outk, o);
+    nt_store(argk, a);
   }
 }
 
@@ -532,22 +570,41 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
     // error of a long row at that of one piece (costs nothing: a few records per cut row).
     constexpr bool kWideFold = RED == RED_ADD && std::is_same<A, float>::value;
     double wide = kWideFold ? (double)val[0] : 0.0;
-#pragma unroll 4
-    for (int64_t i = 0; i < run; ++i) {
-      const uint64_t o = (plane + (q - 1 - i)) * K + k;
-      const A v = tail_val[o];
+    // the records of a hub row (hundreds of pieces) are fetched kFold at a time: the loads of a
+    // batch are independent, only the fold itself is sequential
+    constexpr int kFold = 8;
+    auto fold = [&](A v, int64_t a) {
       if constexpr (kWideFold) {
         wide += (double)v;
       } else if constexpr (RED == RED_ADD) {
         val[0] += v;
       } else {
-        const int64_t a = ws.tail_arg[o];
         const bool better = RED == RED_MIN ? (v < val[0]) : (v > val[0]);
         if (better || (v == val[0] && a < arg[0])) {
           val[0] = v;
           arg[0] = a;
         }
       }
+    };
+    int64_t i = 0;
+    for (; i + kFold <= run; i += kFold) {  // full batches: only long (hub) rows get here
+      A v[kFold];
+      int64_t a[kFold];
+#pragma unroll
+      for (int u = 0; u < kFold; ++u) {
+        const uint64_t o = (plane + (q - 1 - i - u)) * K + k;
+        v[u] = tail_val[o];
+        a[u] = kNoArg;
+        if constexpr (RED != RED_ADD) a[u] = ws.tail_arg[o];
+      }
+#pragma unroll
+      for (int u = 0; u < kFold; ++u) fold(v[u], a[u]);
+    }
+    for (; i < run; ++i) {
+      const uint64_t o = (plane + (q - 1 - i)) * K + k;
+      int64_t a = kNoArg;
+      if constexpr (RED != RED_ADD) a = ws.tail_arg[o];
+      fold(tail_val[o], a);
     }
     if constexpr (kWideFold) val[0] = (A)wide;
     const uint64_t o = ((uint64_t)b * M + out_position(ws, R, M)) * K + k;
