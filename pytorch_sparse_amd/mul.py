@@ -7,7 +7,7 @@ shared with the input; only the value tensor is new.  Sparse (x) sparse goes thr
 radix sort: ``add`` = concatenate + sort + ``coalesce('sum')`` (add.py:41-59), ``mul`` = concatenate +
 stable sort + keep the adjacent equal pairs (mul.py:43-80).
 """
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -21,11 +21,11 @@ def _broadcast(src: SparseTensor, other: Tensor) -> Tensor:
         return other.squeeze(1).index_select(0, src.storage.row())
     if other.dim() >= 2 and other.size(0) == 1 and other.size(1) == src.size(1):
         return other.squeeze(0).index_select(0, src.storage.col())
-    raise ValueError('Size mismatch: Expected size (%d, 1, ...) or (1, %d, ...), but got size %s.'
-                     % (src.size(0), src.size(1), tuple(other.size())))
+    raise ValueError('Size mismatch: Expected size (%d, 1, ...) or (1, %d, ...), but got size (%d, %d, ...).'
+                     % (src.size(0), src.size(1), other.size(0), other.size(1) if other.dim() > 1 else 1))
 
 
-def _concat(src: SparseTensor, other: SparseTensor):
+def _concat(src: SparseTensor, other: SparseTensor) -> Tuple[Tensor, Tensor, Optional[Tensor], Tuple[int, int]]:
     rowA, colA, valueA = src.coo()
     rowB, colB, valueB = other.coo()
     row = torch.cat([rowA, rowB], dim=0)
@@ -37,12 +37,25 @@ def _concat(src: SparseTensor, other: SparseTensor):
     return row, col, value, sizes
 
 
-def mul(src: SparseTensor, other) -> SparseTensor:
+@torch.jit._overload  # noqa: F811
+def mul(src, other):  # noqa: F811
+    # type: (SparseTensor, Tensor) -> SparseTensor
+    pass
+
+
+@torch.jit._overload  # noqa: F811
+def mul(src, other):  # noqa: F811
+    # type: (SparseTensor, SparseTensor) -> SparseTensor
+    pass
+
+
+def mul(src, other):  # noqa: F811
     if isinstance(other, Tensor):
-        other = _broadcast(src, other)
+        bc = _broadcast(src, other)
         value = src.storage.value()
-        value = other if value is None else other.to(value.dtype) * value
-        return src.set_value(value, layout='coo')
+        if value is not None:
+            bc = bc.to(value.dtype) * value
+        return src.set_value(bc, layout='coo')
 
     assert isinstance(other, SparseTensor)
     if not src.is_coalesced():
@@ -60,7 +73,8 @@ def mul(src: SparseTensor, other) -> SparseTensor:
     row, col, pos, _ = torch.ops.tsamd.filter_coo('mask', row, col, second, 0, 0, False, 0, 0, True, True)
     value = value.index_select(0, perm.index_select(0, pos - 1)) * \
         value.index_select(0, perm.index_select(0, pos))
-    return SparseTensor(row=row, col=col, value=value, sparse_sizes=sizes, is_sorted=True)
+    return SparseTensor(row=row, rowptr=None, col=col, value=value, sparse_sizes=sizes, is_sorted=True,
+                        trust_data=False)
 
 
 def mul_(src: SparseTensor, other: Tensor) -> SparseTensor:
@@ -82,15 +96,31 @@ def mul_nnz_(src: SparseTensor, other: Tensor, layout: Optional[str] = None) -> 
     return src.set_value_(value, layout=layout)
 
 
-def add(src: SparseTensor, other) -> SparseTensor:
+@torch.jit._overload  # noqa: F811
+def add(src, other):  # noqa: F811
+    # type: (SparseTensor, Tensor) -> SparseTensor
+    pass
+
+
+@torch.jit._overload  # noqa: F811
+def add(src, other):  # noqa: F811
+    # type: (SparseTensor, SparseTensor) -> SparseTensor
+    pass
+
+
+def add(src, other):  # noqa: F811
     if isinstance(other, Tensor):
-        other = _broadcast(src, other)
+        bc = _broadcast(src, other)
         value = src.storage.value()
-        value = other + 1 if value is None else other.to(value.dtype) + value
-        return src.set_value(value, layout='coo')
-    if isinstance(other, SparseTensor):
+        if value is None:
+            bc = bc + 1
+        else:
+            bc = bc.to(value.dtype) + value
+        return src.set_value(bc, layout='coo')
+    elif isinstance(other, SparseTensor):
         row, col, value, sizes = _concat(src, other)
-        out = SparseTensor(row=row, col=col, value=value, sparse_sizes=sizes)
+        out = SparseTensor(row=row, rowptr=None, col=col, value=value, sparse_sizes=sizes, is_sorted=False,
+                           trust_data=False)
         return out.coalesce(reduce='sum')
     raise NotImplementedError
 

@@ -11,7 +11,9 @@ fused HIP ops instead of Python/ATen/torch_scatter compositions:
     stable input order);
   * ``rowptr`` / ``row`` / ``colptr``                  -> ``torch_sparse::ind2ptr`` / ``ptr2ind``.
 
-The class is a plain Python object (not a TorchScript class).
+Like the reference's (storage.py:21) this is a TorchScript class: scripted functions and modules can
+take, build and return it.  Everything in the class body compiles; the few Python-only conveniences
+(pinning, shared memory) are attached below it, as the reference attaches its own.
 """
 import warnings
 from typing import List, Optional, Tuple
@@ -19,8 +21,11 @@ from typing import List, Optional, Tuple
 import torch
 from torch import Tensor
 
-layouts = ['coo', 'csr', 'csc']
-_CACHE_KEYS = ('rowcount', 'colptr', 'colcount', 'csr2csc', 'csc2csr')
+layouts: List[str] = ['coo', 'csr', 'csc']
+_CACHE_KEYS: List[str] = ['rowcount', 'colptr', 'colcount', 'csr2csc', 'csc2csr']
+
+# what _remade() does to every tensor of a storage
+_OP_SAME, _OP_CLONE, _OP_DEVICE = 0, 1, 2
 
 
 def get_layout(layout: Optional[str] = None) -> str:
@@ -28,22 +33,53 @@ def get_layout(layout: Optional[str] = None) -> str:
         layout = 'coo'
         warnings.warn('`layout` argument unset, using default layout "coo". This may lead to '
                       'unexpected behaviour.')
-    assert layout in layouts
+    assert layout == 'coo' or layout == 'csr' or layout == 'csc'
     return layout
 
 
-def _check_index(t: Optional[Tensor], name: str, like: Tensor, numel: Optional[int] = None):
+def _checked(t: Optional[Tensor], like: Tensor, numel: int) -> Optional[Tensor]:
+    """An optional int64 index array of `numel` (< 0: any) entries on `like`'s device, contiguous."""
     if t is None:
         return None
-    assert t.dtype == torch.long, '%s must be int64' % name
-    assert t.device == like.device, '%s is on a different device' % name
-    assert t.dim() == 1, '%s must be 1-D' % name
-    if numel is not None:
-        assert t.numel() == numel, '%s has %d entries, expected %d' % (name, t.numel(), numel)
+    assert t.dtype == torch.long, 'index tensors must be int64'
+    assert t.device == like.device, 'index tensor on a different device'
+    assert t.dim() == 1, 'index tensors must be 1-D'
+    if numel >= 0:
+        assert t.numel() == numel, 'index tensor of unexpected length'
     return t.contiguous()
 
 
+def _xf(t: Optional[Tensor], op: int, device: torch.device, non_blocking: bool) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if op == 1:
+        return t.clone()
+    if op == 2:
+        return t.to(device, non_blocking=non_blocking)
+    return t
+
+
+@torch.jit.ignore
+def _reduce_duplicates(value: Tensor, seg_ptr: Tensor, n: int, reduce: str, balanced: bool) -> Tensor:
+    # differentiable w.r.t. value (a Python autograd.Function): runs outside the compiled graph
+    from .segment import segment_reduce
+    return segment_reduce(value, None, seg_ptr, n, reduce, balanced=balanced)
+
+
+@torch.jit.script
 class SparseStorage(object):
+    _row: Optional[Tensor]
+    _rowptr: Optional[Tensor]
+    _col: Tensor
+    _value: Optional[Tensor]
+    _sparse_sizes: Tuple[int, int]
+    _rowcount: Optional[Tensor]
+    _colptr: Optional[Tensor]
+    _colcount: Optional[Tensor]
+    _csr2csc: Optional[Tensor]
+    _csc2csr: Optional[Tensor]
+    _pending_sort: bool
+
     def __init__(self, row: Optional[Tensor] = None, rowptr: Optional[Tensor] = None,
                  col: Optional[Tensor] = None, value: Optional[Tensor] = None,
                  sparse_sizes: Optional[Tuple[Optional[int], Optional[int]]] = None,
@@ -53,74 +89,98 @@ class SparseStorage(object):
                  trust_data: bool = False):
         assert row is not None or rowptr is not None
         assert col is not None
-        col = _check_index(col, 'col', col)
+        assert col.dtype == torch.long, 'col must be int64'
+        assert col.dim() == 1, 'col must be 1-D'
+        col = col.contiguous()
         nnz = col.numel()
 
         # sizes: given, or inferred (inference reads a maximum back from the device)
-        M = N = None
+        M: int = 0
+        given_m: Optional[int] = None
+        given_n: Optional[int] = None
         if sparse_sizes is not None:
-            M, N = sparse_sizes
-        if M is None:
+            given_m, given_n = sparse_sizes
+        if given_m is not None:
+            M = given_m
             if rowptr is not None:
-                M = rowptr.numel() - 1
-            else:
-                M = int(row.max()) + 1 if row.numel() > 0 else 0
+                assert rowptr.numel() - 1 == M
+            elif row is not None and row.numel() > 0 and not trust_data:
+                assert int(row.max()) < M
         elif rowptr is not None:
-            assert rowptr.numel() - 1 == M
-        elif not trust_data and row.numel() > 0:
-            assert int(row.max()) < M
-        if N is None:
-            N = int(col.max()) + 1 if nnz > 0 else 0
-        elif not trust_data and nnz > 0:
-            assert int(col.max()) < N
-        self._sparse_sizes = (int(M), int(N))
+            M = rowptr.numel() - 1
+        elif row is not None and row.numel() > 0:
+            M = int(row.max()) + 1
+        N: int = 0
+        if given_n is not None:
+            N = given_n
+            if nnz > 0 and not trust_data:
+                assert int(col.max()) < N
+        elif nnz > 0:
+            N = int(col.max()) + 1
+        self._sparse_sizes = (M, N)
 
-        self._row = _check_index(row, 'row', col, nnz)
-        self._rowptr = _check_index(rowptr, 'rowptr', col, M + 1)
+        self._row = _checked(row, col, nnz)
+        self._rowptr = _checked(rowptr, col, M + 1)
         self._col = col
         if value is not None:
             assert value.device == col.device
             assert value.size(0) == nnz
             value = value.contiguous()
         self._value = value
-        self._cache = {
-            'rowcount': _check_index(rowcount, 'rowcount', col, M),
-            'colptr': _check_index(colptr, 'colptr', col, N + 1),
-            'colcount': _check_index(colcount, 'colcount', col, N),
-            'csr2csc': _check_index(csr2csc, 'csr2csc', col, nnz),
-            'csc2csr': _check_index(csc2csr, 'csc2csr', col, nnz),
-        }
+        self._rowcount = _checked(rowcount, col, M)
+        self._colptr = _checked(colptr, col, N + 1)
+        self._colcount = _checked(colcount, col, N)
+        self._csr2csc = _checked(csr2csc, col, nnz)
+        self._csc2csr = _checked(csc2csr, col, nnz)
 
         # Unsorted COO handed over on the CPU: there is no CPU sort in this package, so the sort is
         # deferred until the storage is moved to the GPU (`.cuda()` / `.to(device)`); until then every
         # accessor refuses to hand out the (still unsorted) arrays.
-        self._pending_sort = bool(not is_sorted and nnz > 1 and not col.is_cuda)
-        if not is_sorted and nnz > 1 and col.is_cuda:
+        self._pending_sort = (not is_sorted) and nnz > 1 and not col.is_cuda
+        if (not is_sorted) and nnz > 1 and col.is_cuda:
             r = self.row()
             descents = int(torch.ops.tsamd.coo_order(r, col, N)[0])  # the one host sync
             if descents > 0:
                 rs, cs, perm = torch.ops.tsamd.sort_coo(r, col, M, N, True)
-                self._row, self._col = rs, cs
+                self._row = rs
+                self._col = cs
                 self._rowptr = None
                 if value is not None:
                     self._value = value[perm]
-                self._cache['csr2csc'] = None
-                self._cache['csc2csr'] = None
+                self._csr2csc = None
+                self._csc2csr = None
 
     # ---- construction helpers --------------------------------------------------------------
     @classmethod
-    def empty(cls):
+    def empty(self):
         z = torch.tensor([], dtype=torch.long)
-        return cls(row=z, col=z, sparse_sizes=(0, 0), is_sorted=True, trust_data=True)
+        return SparseStorage(row=z, rowptr=None, col=z, value=None, sparse_sizes=(0, 0), rowcount=None,
+                             colptr=None, colcount=None, csr2csc=None, csc2csr=None, is_sorted=True,
+                             trust_data=True)
 
-    def _derive(self, **overrides):
-        """A new storage sharing this one's tensors, with some fields replaced."""
-        self._ready()
-        kw = dict(row=self._row, rowptr=self._rowptr, col=self._col, value=self._value,
-                  sparse_sizes=self._sparse_sizes, is_sorted=True, trust_data=True)
-        kw.update(self._cache)
-        kw.update(overrides)
-        return SparseStorage(**kw)
+    def _remade(self, op: int, device: torch.device, non_blocking: bool, value: Optional[Tensor],
+                keep_value: bool):
+        """A new storage from this one's tensors, each one kept / cloned / moved (`op`); the values are
+        this storage's (keep_value) or `value` (not transformed)."""
+        self._ready_or_moving(op)
+        v = value
+        if keep_value:
+            v = _xf(self._value, op, device, non_blocking)
+        return SparseStorage(row=_xf(self._row, op, device, non_blocking),
+                             rowptr=_xf(self._rowptr, op, device, non_blocking),
+                             col=self._col if op == 0 else (self._col.clone() if op == 1 else
+                                                            self._col.to(device, non_blocking=non_blocking)),
+                             value=v, sparse_sizes=self._sparse_sizes,
+                             rowcount=_xf(self._rowcount, op, device, non_blocking),
+                             colptr=_xf(self._colptr, op, device, non_blocking),
+                             colcount=_xf(self._colcount, op, device, non_blocking),
+                             csr2csc=_xf(self._csr2csc, op, device, non_blocking),
+                             csc2csr=_xf(self._csc2csr, op, device, non_blocking),
+                             is_sorted=not self._pending_sort, trust_data=True)
+
+    def _ready_or_moving(self, op: int):
+        if op != 2:  # a pending CPU storage may only be moved (the move sorts it on the GPU)
+            self._ready()
 
     # ---- COO / CSR views -------------------------------------------------------------------
     def _ready(self):
@@ -134,22 +194,30 @@ class SparseStorage(object):
 
     def row(self) -> Tensor:
         self._ready()
-        if self._row is None:
-            if self._rowptr is None:
-                raise ValueError
-            self._row = torch.ops.torch_sparse.ptr2ind(self._rowptr, self._col.numel())
-        return self._row
+        row = self._row
+        if row is not None:
+            return row
+        rowptr = self._rowptr
+        if rowptr is None:
+            raise ValueError
+        row = torch.ops.torch_sparse.ptr2ind(rowptr, self._col.numel())
+        self._row = row
+        return row
 
     def has_rowptr(self) -> bool:
         return self._rowptr is not None
 
     def rowptr(self) -> Tensor:
         self._ready()
-        if self._rowptr is None:
-            if self._row is None:
-                raise ValueError
-            self._rowptr = torch.ops.torch_sparse.ind2ptr(self._row, self._sparse_sizes[0])
-        return self._rowptr
+        rowptr = self._rowptr
+        if rowptr is not None:
+            return rowptr
+        row = self._row
+        if row is None:
+            raise ValueError
+        rowptr = torch.ops.torch_sparse.ind2ptr(row, self._sparse_sizes[0])
+        self._rowptr = rowptr
+        return rowptr
 
     def col(self) -> Tensor:
         self._ready()
@@ -176,7 +244,7 @@ class SparseStorage(object):
         return self
 
     def set_value(self, value: Optional[Tensor], layout: Optional[str] = None):
-        return self._derive(value=self._layout_value(value, layout))
+        return self._remade(0, self._col.device, False, self._layout_value(value, layout), False)
 
     # ---- sizes -----------------------------------------------------------------------------
     def sparse_sizes(self) -> Tuple[int, int]:
@@ -186,23 +254,36 @@ class SparseStorage(object):
         return self._sparse_sizes[dim]
 
     def sparse_resize(self, sparse_sizes: Tuple[int, int]):
-        assert len(sparse_sizes) == 2
+        self._ready()
         nnz = self._col.numel()
-        out = {}
-        for dim, (ptr_key, cnt_key) in enumerate((('rowptr', 'rowcount'), ('colptr', 'colcount'))):
-            diff = sparse_sizes[dim] - self._sparse_sizes[dim]
-            ptr = self._rowptr if dim == 0 else self._cache['colptr']
-            cnt = self._cache[cnt_key]
-            if diff > 0:
-                if ptr is not None:
-                    ptr = torch.cat([ptr, ptr.new_full((diff, ), nnz)])
-                if cnt is not None:
-                    cnt = torch.cat([cnt, cnt.new_zeros(diff)])
-            elif diff < 0:
-                ptr = ptr[:diff] if ptr is not None else None
-                cnt = cnt[:diff] if cnt is not None else None
-            out[ptr_key], out[cnt_key] = ptr, cnt
-        return self._derive(sparse_sizes=tuple(sparse_sizes), **out)
+        rowptr, rowcount = self._rowptr, self._rowcount
+        colptr, colcount = self._colptr, self._colcount
+        grow_m = sparse_sizes[0] - self._sparse_sizes[0]
+        if grow_m > 0:
+            if rowptr is not None:
+                rowptr = torch.cat([rowptr, rowptr.new_full((grow_m, ), nnz)])
+            if rowcount is not None:
+                rowcount = torch.cat([rowcount, rowcount.new_zeros(grow_m)])
+        elif grow_m < 0:
+            if rowptr is not None:
+                rowptr = rowptr[:grow_m]
+            if rowcount is not None:
+                rowcount = rowcount[:grow_m]
+        grow_n = sparse_sizes[1] - self._sparse_sizes[1]
+        if grow_n > 0:
+            if colptr is not None:
+                colptr = torch.cat([colptr, colptr.new_full((grow_n, ), nnz)])
+            if colcount is not None:
+                colcount = torch.cat([colcount, colcount.new_zeros(grow_n)])
+        elif grow_n < 0:
+            if colptr is not None:
+                colptr = colptr[:grow_n]
+            if colcount is not None:
+                colcount = colcount[:grow_n]
+        return SparseStorage(row=self._row, rowptr=rowptr, col=self._col, value=self._value,
+                             sparse_sizes=(sparse_sizes[0], sparse_sizes[1]), rowcount=rowcount,
+                             colptr=colptr, colcount=colcount, csr2csc=self._csr2csc,
+                             csc2csr=self._csc2csr, is_sorted=True, trust_data=True)
 
     def sparse_reshape(self, num_rows: int, num_cols: int):
         assert num_rows > 0 or num_rows == -1
@@ -217,71 +298,86 @@ class SparseStorage(object):
         idx = self._sparse_sizes[1] * self.row() + self._col
         row = torch.div(idx, num_cols, rounding_mode='floor')
         col = idx - row * num_cols
-        return SparseStorage(row=row, col=col, value=self._value, sparse_sizes=(num_rows, num_cols),
-                             is_sorted=True, trust_data=True)
+        return SparseStorage(row=row, rowptr=None, col=col, value=self._value,
+                             sparse_sizes=(num_rows, num_cols), rowcount=None, colptr=None,
+                             colcount=None, csr2csc=None, csc2csr=None, is_sorted=True, trust_data=True)
 
     # ---- cached CSC-side views -------------------------------------------------------------
     def has_rowcount(self) -> bool:
-        return self._cache['rowcount'] is not None
+        return self._rowcount is not None
 
     def rowcount(self) -> Tensor:
-        if self._cache['rowcount'] is None:
-            rowptr = self.rowptr()
-            self._cache['rowcount'] = rowptr[1:] - rowptr[:-1]
-        return self._cache['rowcount']
+        rowcount = self._rowcount
+        if rowcount is not None:
+            return rowcount
+        rowptr = self.rowptr()
+        rowcount = rowptr[1:] - rowptr[:-1]
+        self._rowcount = rowcount
+        return rowcount
 
     def has_csr2csc(self) -> bool:
-        return self._cache['csr2csc'] is not None
+        return self._csr2csc is not None
 
     def csr2csc(self) -> Tensor:
         """Permutation that orders the entries column-major (stable radix sort of col*M+row)."""
-        if self._cache['csr2csc'] is None:
-            M, N = self._sparse_sizes
-            _, _, perm = torch.ops.tsamd.sort_coo(self._col, self.row(), N, M, False)
-            self._cache['csr2csc'] = perm
-        return self._cache['csr2csc']
+        perm = self._csr2csc
+        if perm is not None:
+            return perm
+        out = torch.ops.tsamd.sort_coo(self._col, self.row(), self._sparse_sizes[1], self._sparse_sizes[0],
+                                       False)
+        perm = out[2]
+        self._csr2csc = perm
+        return perm
 
     def has_csc2csr(self) -> bool:
-        return self._cache['csc2csr'] is not None
+        return self._csc2csr is not None
 
     def csc2csr(self) -> Tensor:
-        if self._cache['csc2csr'] is None:
-            perm = self.csr2csc()
-            inv = torch.empty_like(perm)
-            inv[perm] = torch.arange(perm.numel(), device=perm.device)
-            self._cache['csc2csr'] = inv
-        return self._cache['csc2csr']
+        inv = self._csc2csr
+        if inv is not None:
+            return inv
+        perm = self.csr2csc()
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        self._csc2csr = inv
+        return inv
 
     def has_colptr(self) -> bool:
-        return self._cache['colptr'] is not None
+        return self._colptr is not None
 
     def colptr(self) -> Tensor:
-        if self._cache['colptr'] is None:
-            N = self._sparse_sizes[1]
-            if self._cache['colcount'] is not None:
-                ptr = self._col.new_zeros(N + 1)
-                torch.cumsum(self._cache['colcount'], dim=0, out=ptr[1:])
-            else:
-                ptr = torch.ops.torch_sparse.ind2ptr(self._col[self.csr2csc()], N)
-            self._cache['colptr'] = ptr
-        return self._cache['colptr']
+        ptr = self._colptr
+        if ptr is not None:
+            return ptr
+        N = self._sparse_sizes[1]
+        colcount = self._colcount
+        if colcount is not None:
+            ptr = self._col.new_zeros(N + 1)
+            torch.cumsum(colcount, dim=0, out=ptr[1:])
+        else:
+            ptr = torch.ops.torch_sparse.ind2ptr(self._col[self.csr2csc()], N)
+        self._colptr = ptr
+        return ptr
 
     def has_colcount(self) -> bool:
-        return self._cache['colcount'] is not None
+        return self._colcount is not None
 
     def colcount(self) -> Tensor:
-        if self._cache['colcount'] is None:
-            ptr = self.colptr()
-            self._cache['colcount'] = ptr[1:] - ptr[:-1]
-        return self._cache['colcount']
+        colcount = self._colcount
+        if colcount is not None:
+            return colcount
+        ptr = self.colptr()
+        colcount = ptr[1:] - ptr[:-1]
+        self._colcount = colcount
+        return colcount
 
     # ---- coalescing ------------------------------------------------------------------------
     def is_coalesced(self) -> bool:
         self._ready()
         if self._col.numel() <= 1:
             return True
-        counts = torch.ops.tsamd.coo_order(self.row(), self._col, self._sparse_sizes[1]).tolist()
-        return counts[0] == 0 and counts[1] == 0
+        counts = torch.ops.tsamd.coo_order(self.row(), self._col, self._sparse_sizes[1])
+        return int(counts[0]) == 0 and int(counts[1]) == 0
 
     def coalesce(self, reduce: str = 'add'):
         """Merge duplicate (row, col) entries; values of duplicates are reduced in storage order."""
@@ -297,48 +393,60 @@ class SparseStorage(object):
         n = nnz - dup
         value = self._value
         if value is not None:
-            from .segment import segment_reduce
             # heavy duplication (few distinct pairs, long runs): take the entry-balanced path
-            value = segment_reduce(value, None, seg_ptr, n, reduce, balanced=nnz > 8 * max(n, 1))
-        return SparseStorage(row=row_u[:n].clone(), col=col_u[:n].clone(), value=value,
-                             sparse_sizes=self._sparse_sizes, is_sorted=True, trust_data=True)
+            value = _reduce_duplicates(value, seg_ptr, n, reduce, nnz > 8 * max(n, 1))
+        return SparseStorage(row=row_u[:n].clone(), rowptr=None, col=col_u[:n].clone(), value=value,
+                             sparse_sizes=self._sparse_sizes, rowcount=None, colptr=None, colcount=None,
+                             csr2csc=None, csc2csr=None, is_sorted=True, trust_data=True)
 
     # ---- cache management ------------------------------------------------------------------
     def fill_cache_(self):
-        self.row(), self.rowptr(), self.rowcount()
-        self.csr2csc(), self.csc2csr(), self.colptr(), self.colcount()
+        self.row()
+        self.rowptr()
+        self.rowcount()
+        self.csr2csc()
+        self.csc2csr()
+        self.colptr()
+        self.colcount()
         return self
 
     def clear_cache_(self):
-        for k in _CACHE_KEYS:
-            self._cache[k] = None
+        self._rowcount = None
+        self._colptr = None
+        self._colcount = None
+        self._csr2csc = None
+        self._csc2csr = None
         return self
 
     def cached_keys(self) -> List[str]:
-        return [k for k in _CACHE_KEYS if self._cache[k] is not None]
+        keys: List[str] = []
+        if self.has_rowcount():
+            keys.append('rowcount')
+        if self.has_colptr():
+            keys.append('colptr')
+        if self.has_colcount():
+            keys.append('colcount')
+        if self.has_csr2csc():
+            keys.append('csr2csc')
+        if self.has_csc2csr():
+            keys.append('csc2csr')
+        return keys
 
     def num_cached_keys(self) -> int:
         return len(self.cached_keys())
 
     # ---- copies / device / dtype -----------------------------------------------------------
-    def _map(self, fn, value_fn=None):
-        def ap(t, f):
-            return None if t is None else f(t)
-        return SparseStorage(row=ap(self._row, fn), rowptr=ap(self._rowptr, fn), col=fn(self._col),
-                             value=ap(self._value, value_fn or fn), sparse_sizes=self._sparse_sizes,
-                             is_sorted=not self._pending_sort, trust_data=True,
-                             **{k: ap(v, fn) for k, v in self._cache.items()})
-
     def copy(self):
-        return self._derive()
+        return self._remade(0, self._col.device, False, None, True)
 
     def clone(self):
-        return self._map(lambda t: t.clone())
+        return self._remade(1, self._col.device, False, None, True)
 
     def type(self, dtype: torch.dtype, non_blocking: bool = False):
-        if self._value is None or dtype == self._value.dtype:
+        value = self._value
+        if value is None or dtype == value.dtype:
             return self
-        return self.set_value(self._value.to(dtype=dtype, non_blocking=non_blocking), layout='coo')
+        return self.set_value(value.to(dtype=dtype, non_blocking=non_blocking), layout='coo')
 
     def type_as(self, tensor: Tensor, non_blocking: bool = False):
         return self.type(tensor.dtype, non_blocking)
@@ -346,54 +454,49 @@ class SparseStorage(object):
     def to_device(self, device: torch.device, non_blocking: bool = False):
         if device == self._col.device:
             return self
-        return self._map(lambda t: t.to(device, non_blocking=non_blocking))
+        return self._remade(2, device, non_blocking, None, True)
 
     def device_as(self, tensor: Tensor, non_blocking: bool = False):
         return self.to_device(tensor.device, non_blocking)
 
     def cuda(self):
-        return self if self._col.is_cuda else self._map(lambda t: t.cuda())
+        if self._col.is_cuda:
+            return self
+        return self._remade(2, torch.device('cuda'), False, None, True)
 
     def cpu(self):
-        return self._map(lambda t: t.cpu()) if self._col.is_cuda else self
+        if not self._col.is_cuda:
+            return self
+        return self._remade(2, torch.device('cpu'), False, None, True)
 
     def is_cuda(self) -> bool:
         return self._col.is_cuda
 
-    def pin_memory(self):
-        return self._map(lambda t: t.pin_memory())
 
-    def is_pinned(self) -> bool:
-        ts = [self._row, self._rowptr, self._col, self._value] + list(self._cache.values())
-        return all(t.is_pinned() for t in ts if t is not None)
+# ---- Python-only conveniences (not visible to TorchScript, like the reference's) -----------------
+def _tensors(self) -> List[Tensor]:
+    ts = [self._row, self._rowptr, self._col, self._value, self._rowcount, self._colptr, self._colcount,
+          self._csr2csc, self._csc2csr]
+    return [t for t in ts if t is not None]
 
-    def share_memory_(self):
-        for t in [self._row, self._rowptr, self._col, self._value] + list(self._cache.values()):
-            if t is not None:
-                t.share_memory_()
-        return self
 
-    def is_shared(self) -> bool:
-        ts = [self._row, self._rowptr, self._col, self._value] + list(self._cache.values())
-        return all(t.is_shared() for t in ts if t is not None)
+def _pin_memory(self):
+    def pin(t):
+        return None if t is None else t.pin_memory()
+    return SparseStorage(row=pin(self._row), rowptr=pin(self._rowptr), col=pin(self._col),
+                         value=pin(self._value), sparse_sizes=self._sparse_sizes,
+                         rowcount=pin(self._rowcount), colptr=pin(self._colptr),
+                         colcount=pin(self._colcount), csr2csc=pin(self._csr2csc),
+                         csc2csr=pin(self._csc2csr), is_sorted=not self._pending_sort, trust_data=True)
 
-    # private attribute names the reference exposes and its front-ends read directly
-    @property
-    def _rowcount(self):
-        return self._cache['rowcount']
 
-    @property
-    def _colptr(self):
-        return self._cache['colptr']
+def _share_memory_(self):
+    for t in _tensors(self):
+        t.share_memory_()
+    return self
 
-    @property
-    def _colcount(self):
-        return self._cache['colcount']
 
-    @property
-    def _csr2csc(self):
-        return self._cache['csr2csc']
-
-    @property
-    def _csc2csr(self):
-        return self._cache['csc2csr']
+SparseStorage.pin_memory = _pin_memory
+SparseStorage.is_pinned = lambda self: all(t.is_pinned() for t in _tensors(self))
+SparseStorage.share_memory_ = _share_memory_
+SparseStorage.is_shared = lambda self: all(t.is_shared() for t in _tensors(self))

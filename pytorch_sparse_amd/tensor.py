@@ -6,6 +6,11 @@ torch.sparse conversions, and -- attached by the sibling modules, as the referen
 edits, ``narrow/select/index_select/masked_select/permute/[]``, ``sample/sample_adj``,
 ``random_walk``, ``saint_subgraph`` and ``reverse_cuthill_mckee``.  Not provided: the heterogeneous /
 temporal samplers and the METIS partitioner.
+
+Like the reference's (tensor.py:12) the class is a TorchScript class: ``torch.jit.script`` functions and
+modules can take, build and return it (``matmul(adj, x, reduce)`` inside a scripted ``nn.Module``,
+``torch.jit.script(spspmm)`` -- reference test/test_matmul.py:79).  The class body compiles; what cannot
+(``to(*args)``, scipy conversions, ``__repr__``, pinning) is attached below it.
 """
 from typing import List, Optional, Tuple, Union
 
@@ -15,6 +20,36 @@ from torch import Tensor
 from .storage import SparseStorage, get_layout
 
 
+def storage_spmm(st: SparseStorage, other: Tensor, reduce: str) -> Tuple[Tensor, Optional[Tensor]]:
+    """``A @ other`` on a storage -> (out, arg_out for min / max).  Collects the cached arrays the
+    reference front-end hands to its ops (torch_sparse/matmul.py:12-28, 38-56, 60-77): the CSC-side
+    caches are only filled when a gradient w.r.t. `other` will be asked for."""
+    rowptr, col, value = st.rowptr(), st.col(), st.value()
+    if value is not None:
+        value = value.to(other.dtype)
+    if reduce == 'min':
+        out, arg = torch.ops.torch_sparse.spmm_min(rowptr, col, value, other)
+        return out, arg
+    if reduce == 'max':
+        out, arg = torch.ops.torch_sparse.spmm_max(rowptr, col, value, other)
+        return out, arg
+    row, csr2csc, colptr, rowcount = st._row, st._csr2csc, st._colptr, st._rowcount
+    if value is not None and value.requires_grad:
+        row = st.row()
+    if other.requires_grad:
+        row, csr2csc, colptr = st.row(), st.csr2csc(), st.colptr()
+        if reduce == 'mean':
+            rowcount = st.rowcount()
+    none: Optional[Tensor] = None
+    if reduce == 'sum' or reduce == 'add':
+        return torch.ops.torch_sparse.spmm_sum(row, rowptr, col, value, colptr, csr2csc, other), none
+    if reduce == 'mean':
+        return torch.ops.torch_sparse.spmm_mean(row, rowptr, col, value, rowcount, colptr, csr2csc,
+                                                other), none
+    raise ValueError
+
+
+@torch.jit.script
 class SparseTensor(object):
     storage: SparseStorage
 
@@ -23,62 +58,76 @@ class SparseTensor(object):
                  sparse_sizes: Optional[Tuple[Optional[int], Optional[int]]] = None,
                  is_sorted: bool = False, trust_data: bool = False):
         self.storage = SparseStorage(row=row, rowptr=rowptr, col=col, value=value,
-                                     sparse_sizes=sparse_sizes, is_sorted=is_sorted,
+                                     sparse_sizes=sparse_sizes, rowcount=None, colptr=None,
+                                     colcount=None, csr2csc=None, csc2csr=None, is_sorted=is_sorted,
                                      trust_data=trust_data)
 
     # ---- constructors ------------------------------------------------------------------------
     @classmethod
-    def from_storage(cls, storage: SparseStorage):
-        out = cls.__new__(cls)
+    def from_storage(self, storage: SparseStorage):
+        # TorchScript classes have no __new__: build a (cheap, already sorted) instance, then swap
+        # the storage in so that its caches and its pending-sort state come along
+        out = SparseTensor(row=None, rowptr=torch.zeros(1, dtype=torch.long, device=storage._col.device),
+                           col=torch.zeros(0, dtype=torch.long, device=storage._col.device), value=None,
+                           sparse_sizes=(0, 0), is_sorted=True, trust_data=True)
         out.storage = storage
         return out
 
     @classmethod
-    def from_edge_index(cls, edge_index: Tensor, edge_attr: Optional[Tensor] = None,
+    def from_edge_index(self, edge_index: Tensor, edge_attr: Optional[Tensor] = None,
                         sparse_sizes: Optional[Tuple[Optional[int], Optional[int]]] = None,
                         is_sorted: bool = False, trust_data: bool = False):
-        return cls(row=edge_index[0], col=edge_index[1], value=edge_attr, sparse_sizes=sparse_sizes,
-                   is_sorted=is_sorted, trust_data=trust_data)
+        return SparseTensor(row=edge_index[0], rowptr=None, col=edge_index[1], value=edge_attr,
+                            sparse_sizes=sparse_sizes, is_sorted=is_sorted, trust_data=trust_data)
 
     @classmethod
-    def from_dense(cls, mat: Tensor, has_value: bool = True):
+    def from_dense(self, mat: Tensor, has_value: bool = True):
         if mat.dim() > 2:
             index = mat.abs().sum([i for i in range(2, mat.dim())]).nonzero()
         else:
             index = mat.nonzero()
         index = index.t()
         row, col = index[0], index[1]
-        value = mat[row, col] if has_value else None
-        return cls(row=row, col=col, value=value, sparse_sizes=(mat.size(0), mat.size(1)),
-                   is_sorted=True, trust_data=True)
+        value: Optional[Tensor] = None
+        if has_value:
+            value = mat[row, col]
+        return SparseTensor(row=row, rowptr=None, col=col, value=value,
+                            sparse_sizes=(mat.size(0), mat.size(1)), is_sorted=True, trust_data=True)
 
     @classmethod
-    def from_torch_sparse_coo_tensor(cls, mat: Tensor, has_value: bool = True):
+    def from_torch_sparse_coo_tensor(self, mat: Tensor, has_value: bool = True):
         mat = mat.coalesce()
         index = mat._indices()
-        value = mat._values() if has_value else None
-        return cls(row=index[0], col=index[1], value=value,
-                   sparse_sizes=(mat.size(0), mat.size(1)), is_sorted=True, trust_data=True)
+        value: Optional[Tensor] = None
+        if has_value:
+            value = mat.values()
+        return SparseTensor(row=index[0], rowptr=None, col=index[1], value=value,
+                            sparse_sizes=(mat.size(0), mat.size(1)), is_sorted=True, trust_data=True)
 
     @classmethod
-    def from_torch_sparse_csr_tensor(cls, mat: Tensor, has_value: bool = True):
-        value = mat.values() if has_value else None
-        return cls(rowptr=mat.crow_indices(), col=mat.col_indices(), value=value,
-                   sparse_sizes=(mat.size(0), mat.size(1)), is_sorted=True, trust_data=True)
+    def from_torch_sparse_csr_tensor(self, mat: Tensor, has_value: bool = True):
+        value: Optional[Tensor] = None
+        if has_value:
+            value = mat.values()
+        return SparseTensor(row=None, rowptr=mat.crow_indices(), col=mat.col_indices(), value=value,
+                            sparse_sizes=(mat.size(0), mat.size(1)), is_sorted=True, trust_data=True)
 
     @classmethod
-    def eye(cls, M: int, N: Optional[int] = None, has_value: bool = True,
-            dtype: Optional[torch.dtype] = None, device: Optional[torch.device] = None,
+    def eye(self, M: int, N: Optional[int] = None, has_value: bool = True,
+            dtype: Optional[int] = None, device: Optional[torch.device] = None,
             fill_cache: bool = False):
-        N = M if N is None else N
-        k = min(M, N)
+        n: int = M
+        if N is not None:
+            n = N
+        k = min(M, n)
         idx = torch.arange(k, device=device)
         rowptr = torch.cat([torch.arange(k + 1, device=device),
                             torch.full((M - k, ), k, dtype=torch.long, device=device)])
-        value = torch.ones(k, dtype=dtype, device=device) if has_value else None
-        storage = SparseStorage(row=idx, rowptr=rowptr, col=idx, value=value, sparse_sizes=(M, N),
-                                is_sorted=True, trust_data=True)
-        out = cls.from_storage(storage)
+        value: Optional[Tensor] = None
+        if has_value:
+            value = torch.ones(k, dtype=dtype, device=device)
+        out = SparseTensor(row=idx, rowptr=rowptr, col=idx, value=value, sparse_sizes=(M, n),
+                           is_sorted=True, trust_data=True)
         if fill_cache:
             out.storage.fill_cache_()
         return out
@@ -120,6 +169,14 @@ class SparseTensor(object):
     def fill_value(self, fill_value: float, dtype: Optional[torch.dtype] = None):
         value = torch.full((self.nnz(), ), fill_value, dtype=dtype, device=self.device())
         return self.set_value(value, layout='coo')
+
+    # ---- products (dense operand; the Python-level ``matmul`` / ``@`` attached by matmul.py also take a
+    #      SparseTensor) -- real methods, so that scripted code can call ``adj.matmul(x, reduce)`` ------
+    def spmm(self, other: Tensor, reduce: str = 'sum') -> Tensor:
+        return storage_spmm(self.storage, other, reduce)[0]
+
+    def matmul(self, other: Tensor, reduce: str = 'sum') -> Tensor:
+        return storage_spmm(self.storage, other, reduce)[0]
 
     # ---- sizes -------------------------------------------------------------------------------
     def sparse_sizes(self) -> Tuple[int, int]:
@@ -218,7 +275,9 @@ class SparseTensor(object):
         return self
 
     def __eq__(self, other) -> bool:
-        if not isinstance(other, self.__class__) or self.sizes() != other.sizes():
+        if not isinstance(other, self.__class__):
+            return False
+        if self.sizes() != other.sizes():
             return False
         rowptr1, col1, value1 = self.csr()
         rowptr2, col2, value2 = other.csr()
@@ -229,8 +288,6 @@ class SparseTensor(object):
         if not (torch.equal(rowptr1, rowptr2) and torch.equal(col1, col2)):
             return False
         return value1 is None or torch.equal(value1, value2)
-
-    __hash__ = None
 
     # ---- autograd / device / dtype -------------------------------------------------------------
     def detach_(self):
@@ -254,19 +311,6 @@ class SparseTensor(object):
         if value is not None:
             value.requires_grad_(requires_grad)
         return self
-
-    def pin_memory(self):
-        return self.from_storage(self.storage.pin_memory())
-
-    def is_pinned(self) -> bool:
-        return self.storage.is_pinned()
-
-    def share_memory_(self):
-        self.storage.share_memory_()
-        return self
-
-    def is_shared(self) -> bool:
-        return self.storage.is_shared()
 
     def device(self):
         return self.storage._col.device
@@ -299,50 +343,35 @@ class SparseTensor(object):
     def device_as(self, tensor: Tensor, non_blocking: bool = False):
         return self.to_device(tensor.device, non_blocking)
 
-    def to(self, *args, **kwargs):
-        device, dtype, non_blocking = torch._C._nn._parse_to(*args, **kwargs)[:3]
-        out = self
-        if dtype is not None:
-            out = out.type(dtype, non_blocking)
-        if device is not None:
-            out = out.to_device(device, non_blocking)
-        return out
-
-    def cpu(self):
-        return self.to_device(torch.device('cpu'))
-
-    def cuda(self, device: Optional[Union[int, str]] = None, non_blocking: bool = False):
-        return self.to_device(torch.device('cuda' if device is None else device), non_blocking)
-
     def bfloat16(self):
-        return self.type(torch.bfloat16)
+        return self.type(torch.bfloat16, False)
 
     def half(self):
-        return self.type(torch.half)
+        return self.type(torch.half, False)
 
     def float(self):
-        return self.type(torch.float)
+        return self.type(torch.float, False)
 
     def double(self):
-        return self.type(torch.double)
+        return self.type(torch.double, False)
 
     def int(self):
-        return self.type(torch.int)
+        return self.type(torch.int, False)
 
     def long(self):
-        return self.type(torch.long)
+        return self.type(torch.long, False)
 
     def bool(self):
-        return self.type(torch.bool)
+        return self.type(torch.bool, False)
 
     def byte(self):
-        return self.type(torch.uint8)
+        return self.type(torch.uint8, False)
 
     def char(self):
-        return self.type(torch.int8)
+        return self.type(torch.int8, False)
 
     def short(self):
-        return self.type(torch.short)
+        return self.type(torch.short, False)
 
     # ---- conversions ---------------------------------------------------------------------------
     def to_dense(self, dtype: Optional[torch.dtype] = None) -> Tensor:
@@ -373,47 +402,80 @@ class SparseTensor(object):
             value = torch.ones(self.nnz(), dtype=dtype, device=self.device())
         return torch.sparse_csc_tensor(colptr, row, value, self.sizes())
 
-    @classmethod
-    def from_scipy(cls, mat, has_value: bool = True):
-        colptr = None
-        if mat.format == 'csc':
-            colptr = torch.from_numpy(mat.indptr).to(torch.long)
-        mat = mat.tocsr()
-        rowptr = torch.from_numpy(mat.indptr).to(torch.long)
-        mat = mat.tocoo()
-        row = torch.from_numpy(mat.row).to(torch.long)
-        col = torch.from_numpy(mat.col).to(torch.long)
-        value = torch.from_numpy(mat.data) if has_value else None
-        storage = SparseStorage(row=row, rowptr=rowptr, col=col, value=value,
-                                sparse_sizes=tuple(mat.shape), colptr=colptr, is_sorted=True,
-                                trust_data=True)
-        return cls.from_storage(storage)
 
-    def to_scipy(self, layout: Optional[str] = None, dtype: Optional[torch.dtype] = None):
-        import scipy.sparse
-        assert self.dim() == 2
-        layout = get_layout(layout)
-        ones = lambda: torch.ones(self.nnz(), dtype=dtype)  # noqa: E731
-        if layout == 'coo':
-            row, col, value = self.coo()
-            value = ones() if value is None else value.detach().cpu()
-            return scipy.sparse.coo_matrix((value, (row.cpu(), col.cpu())), self.sizes())
-        if layout == 'csr':
-            rowptr, col, value = self.csr()
-            value = ones() if value is None else value.detach().cpu()
-            return scipy.sparse.csr_matrix((value, col.cpu(), rowptr.cpu()), self.sizes())
-        colptr, row, value = self.csc()
-        value = ones() if value is None else value.detach().cpu()
-        return scipy.sparse.csc_matrix((value, row.cpu(), colptr.cpu()), self.sizes())
+# ---- Python-only methods (not visible to TorchScript; the reference attaches its own the same way) --
+def _to(self, *args, **kwargs):
+    device, dtype, non_blocking = torch._C._nn._parse_to(*args, **kwargs)[:3]
+    out = self
+    if dtype is not None:
+        out = out.type(dtype, non_blocking)
+    if device is not None:
+        out = out.to_device(device, non_blocking)
+    return out
 
-    # __getitem__, narrow, index_select, ... are attached by select.py / cat.py / diag.py / mul.py /
-    # reduce.py / sample.py, like the reference attaches its method modules
 
-    def __repr__(self) -> str:
+def _cuda(self, device: Optional[Union[int, str]] = None, non_blocking: bool = False):
+    return self.to_device(torch.device('cuda' if device is None else device), non_blocking)
+
+
+def _share_memory_(self):
+    self.storage.share_memory_()
+    return self
+
+
+def _from_scipy(mat, has_value: bool = True):
+    colptr = None
+    if mat.format == 'csc':
+        colptr = torch.from_numpy(mat.indptr).to(torch.long)
+    mat = mat.tocsr()
+    rowptr = torch.from_numpy(mat.indptr).to(torch.long)
+    mat = mat.tocoo()
+    row = torch.from_numpy(mat.row).to(torch.long)
+    col = torch.from_numpy(mat.col).to(torch.long)
+    value = torch.from_numpy(mat.data) if has_value else None
+    storage = SparseStorage(row=row, rowptr=rowptr, col=col, value=value,
+                            sparse_sizes=tuple(mat.shape), colptr=colptr, is_sorted=True,
+                            trust_data=True)
+    return SparseTensor.from_storage(storage)
+
+
+def _to_scipy(self, layout: Optional[str] = None, dtype: Optional[torch.dtype] = None):
+    import scipy.sparse
+    assert self.dim() == 2
+    layout = get_layout(layout)
+    ones = lambda: torch.ones(self.nnz(), dtype=dtype)  # noqa: E731
+    if layout == 'coo':
         row, col, value = self.coo()
-        lines = ['row=%s' % row, 'col=%s' % col]
-        if value is not None:
-            lines.append('val=%s' % value)
-        lines.append('size=%s, nnz=%d, density=%.2f%%' % (tuple(self.sizes()), self.nnz(),
-                                                          100 * self.density()))
-        return '%s(%s)' % (self.__class__.__name__, ',\n             '.join(lines))
+        value = ones() if value is None else value.detach().cpu()
+        return scipy.sparse.coo_matrix((value, (row.cpu(), col.cpu())), self.sizes())
+    if layout == 'csr':
+        rowptr, col, value = self.csr()
+        value = ones() if value is None else value.detach().cpu()
+        return scipy.sparse.csr_matrix((value, col.cpu(), rowptr.cpu()), self.sizes())
+    colptr, row, value = self.csc()
+    value = ones() if value is None else value.detach().cpu()
+    return scipy.sparse.csc_matrix((value, row.cpu(), colptr.cpu()), self.sizes())
+
+
+def _repr(self) -> str:
+    row, col, value = self.coo()
+    lines = ['row=%s' % row, 'col=%s' % col]
+    if value is not None:
+        lines.append('val=%s' % value)
+    lines.append('size=%s, nnz=%d, density=%.2f%%' % (tuple(self.sizes()), self.nnz(),
+                                                      100 * self.density()))
+    return '%s(%s)' % (self.__class__.__name__, ',\n             '.join(lines))
+
+
+SparseTensor.to = _to
+SparseTensor.cpu = lambda self: self.to_device(torch.device('cpu'))
+SparseTensor.cuda = _cuda
+SparseTensor.pin_memory = lambda self: SparseTensor.from_storage(self.storage.pin_memory())
+SparseTensor.is_pinned = lambda self: self.storage.is_pinned()
+SparseTensor.share_memory_ = _share_memory_
+SparseTensor.is_shared = lambda self: self.storage.is_shared()
+SparseTensor.from_scipy = staticmethod(_from_scipy)
+SparseTensor.to_scipy = _to_scipy
+SparseTensor.__repr__ = _repr
+# __getitem__, narrow, index_select, ... are attached by select.py / cat.py / diag.py / mul.py /
+# reduce.py / sample.py, like the reference attaches its method modules
