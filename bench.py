@@ -59,6 +59,20 @@ def b_min(E, M, N, K, esize, has_value, minmax):
         (M * K * 8 if minmax else 0)
 
 
+def strong_block(scale, edge_factor, world, rank, device):
+    """Strong scaling: ONE 2**scale square R-MAT matrix (the single-GPU workload, same seed on every
+    rank), cut into `world` row blocks of equal nnz; X is sharded by the same row ranges.
+    -> (rowptr, col, rows of this rank, columns, rows owned by every rank)."""
+    from pytorch_sparse_amd import synth
+    from pytorch_sparse_amd.parallel import narrow_rows, partition_rows
+    n = 1 << scale
+    rowptr, col = synth.rmat_csr(scale, edge_factor, seed=0, device=device)
+    ranges = partition_rows(rowptr, world, 'nnz')
+    s, e = ranges[rank]
+    rp, c, _ = narrow_rows(rowptr, col, None, s, e)
+    return rp.contiguous(), c.contiguous(), e - s, n, [b - a for a, b in ranges]
+
+
 def local_block(scale, edge_factor, world, rank, device):
     """Rank-local row block: 2**scale rows, columns over all world * 2**scale vertices (R-MAT)."""
     from pytorch_sparse_amd import synth
@@ -179,6 +193,9 @@ def main():
                     help='N > 1: all_gather of X | halo = all_to_all of the referenced rows only | '
                          'pipelined = halo exchange in row pieces, overlapped with the SpMM of the previous piece')
     ap.add_argument('--chunks', type=int, default=8, help='row pieces of the pipelined exchange')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak (default): every rank owns 2**scale rows; strong: the single-GPU matrix is cut '
+                         'into N row blocks of equal nnz')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -199,7 +216,11 @@ def main():
 
     wl = WORKLOADS[args.workload]
     scale, ef, F = wl['scale'], wl['edge_factor'], wl['F']
-    rowptr, col, m_local, n_global = local_block(scale, ef, world, rank, dev)
+    if args.scaling == 'strong' and world > 1:
+        rowptr, col, m_local, n_global, x_sizes = strong_block(scale, ef, world, rank, dev)
+    else:
+        rowptr, col, m_local, n_global = local_block(scale, ef, world, rank, dev)
+        x_sizes = [m_local] * world
     E = col.numel()
     value = synth.values(E, seed=1 + rank, device=dev)
     x_local = synth.features(m_local, F, seed=2 + rank, device=dev)
@@ -216,8 +237,6 @@ def main():
         if reduce == 'min':
             return torch.ops.torch_sparse.spmm_min(rp, c, v, x)[0]
         return torch.ops.torch_sparse.spmm_max(rp, c, v, x)[0]
-
-    x_sizes = [m_local] * world
 
     # The requested exchange first; if its planning or a trial step raises on ANY rank, the ranks fall
     # back together (pipelined -> halo -> allgather) and the JSON line says so.
@@ -263,6 +282,40 @@ def main():
             sharded, None if isinstance(sharded, (RowShardedSpMM, HaloShardedSpMM)) else ref_plan, x_local,
             lambda: op_spmm(rowptr, col_k, value, x_full, args.reduce), n_global, F * 4,
             reps=max(3, min(args.steps, 10)), sync=torch.cuda.synchronize)
+
+    # N > 1: the same step with each of the three exchanges (the north star names the all-gather; the
+    # halo variants move only the referenced rows), a few steps each, max over ranks
+    variants = None
+    if world > 1:
+        variants = {}
+        from pytorch_sparse_amd.parallel import EXCHANGES, PipelinedHaloSpMM
+        for mode in ('allgather', 'halo', 'pipelined'):
+            try:
+                if mode == args.exchange:
+                    op_v = sharded
+                else:
+                    kw = dict(chunks=args.chunks) if EXCHANGES[mode] is PipelinedHaloSpMM else {}
+                    op_v = EXCHANGES[mode](rowptr, col, value, x_sizes, None, op_spmm, **kw)
+                reps = max(3, min(args.steps, 10))
+                with torch.no_grad():
+                    op_v(x_local, args.reduce)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t1 = time.perf_counter()
+                    for _ in range(reps):
+                        op_v(x_local, args.reduce)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    ms_v = (time.perf_counter() - t1) / reps * 1e3
+                failed = 0
+            except Exception:  # noqa: BLE001
+                ms_v, failed = 0.0, 1
+            tv = torch.tensor([ms_v, float(failed)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+            variants[mode] = None if float(tv[1]) > 0 else round(float(tv[0]), 4)
+            if mode != args.exchange:
+                del op_v
+                torch.cuda.empty_cache()
 
     stats = torch.tensor([elapsed, float(E)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -319,7 +372,7 @@ def main():
                              'whole_op_frac counts all of them')
         line = dict(metric='SpMM GEdges/s', value=round(gedges, 3), unit='GEdges/s', n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
-                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32',
+                    higher_is_better=True, scaling=(args.scaling if world > 1 else 'weak'), vs_baseline=None, dtype='f32',
                     data='synthetic',
                     config=dict(workload=wl['desc'], reduce=args.reduce, rows_per_gpu=m_local,
                                 cols=n_global, edges_per_gpu=E, features=F,
@@ -328,6 +381,10 @@ def main():
                     roofline=roofline)
         if exchange_info is not None:
             line['exchange'] = exchange_info
+        if variants is not None:
+            line['exchange_variants_ms_per_step'] = variants
+            line['exchange_variants_gedges_per_s'] = {k: (None if v is None else round(total_edges / v / 1e6, 3))
+                                                      for k, v in variants.items()}
         if fallback_reason is not None:
             line['config']['exchange_fallback'] = 'requested %s; %s' % (requested, fallback_reason)
         if world == 1 and not args.no_cpu_baseline:

@@ -121,6 +121,15 @@ int tsamd_spmm_relabelled(int dtype, int reduce, const int64_t *rowptr, const in
                           size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------ *
+ * Row gather of a dense row-major matrix: dst[i, :] = src[idx[i], :], rows of `row_bytes` bytes
+ * (any element type).  The pack step in front of the row exchange of the sharded SpMM
+ * (pytorch_sparse_amd/parallel.py; no reference counterpart: the reference has no distributed code).
+ * idx in [-n_src, n_src); negative ids wrap like torch indexing.
+ * ------------------------------------------------------------------------ */
+int tsamd_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t n, int64_t n_src,
+                      int64_t row_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ *
  * Gradient of SUM/MEAN SpMM w.r.t. the sparse values (an SDDMM over the
  * pattern).  Replaces spmm_value_bw_cuda / spmm_value_bw_cpu
  * (csrc/cuda/spmm_cuda.cu:196-237, csrc/cpu/spmm_cpu.cpp:103-152).

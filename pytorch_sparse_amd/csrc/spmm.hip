@@ -875,6 +875,64 @@ __global__ void relabel_ids_kernel(const int64_t *__restrict__ ids, int64_t coun
 }  // namespace
 }  // namespace tsamd
 
+// ---------------------------------------------------------------------------
+// dst[i, :] = src[idx[i], :] for row-major matrices of `row_bytes`-byte rows: the pack step in front
+// of a row exchange (pytorch_sparse_amd/parallel.py).  One packet (16 / 8 / 4 / 2 / 1 bytes, the
+// widest the pitch and the pointers allow) per lane, 2^lgL lanes per row.
+// ---------------------------------------------------------------------------
+namespace tsamd {
+namespace {
+template <typename P>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const P *__restrict__ src,
+                                                          const int64_t *__restrict__ idx,
+                                                          P *__restrict__ dst, int64_t n, int64_t n_src,
+                                                          uint32_t slots, int lgL) {
+  const uint32_t lanes = 1u << lgL;
+  const uint32_t sl0 = threadIdx.x & (lanes - 1);
+  const int64_t rows_per_block = 256 >> lgL;
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> lgL); r < n;
+       r += (int64_t)gridDim.x * rows_per_block) {
+    int64_t j = idx[r];
+    if (j < 0) j += n_src;  // torch indexing convention; the caller guarantees the range
+    const P *s = src + (uint64_t)j * slots;
+    P *d = dst + (uint64_t)r * slots;
+    for (uint32_t sl = sl0; sl < slots; sl += lanes) d[sl] = s[sl];
+  }
+}
+
+template <typename P>
+int launch_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t n, int64_t n_src,
+                       int64_t row_bytes, hipStream_t stream) {
+  const uint32_t slots = (uint32_t)(row_bytes / (int64_t)sizeof(P));
+  int lgL = 0;
+  while (lgL < 8 && (1u << lgL) < slots) ++lgL;
+  const int64_t rows_per_block = 256 >> lgL;
+  int64_t blocks = ceil_div(n, rows_per_block);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL((gather_rows_kernel<P>), dim3((unsigned int)blocks), dim3(256), 0, stream,
+                     reinterpret_cast<const P *>(src), idx, reinterpret_cast<P *>(dst), n, n_src, slots, lgL);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+}  // namespace
+}  // namespace tsamd
+
+extern "C" int tsamd_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t n,
+                                 int64_t n_src, int64_t row_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || n_src < 0 || row_bytes < 0 || row_bytes >= (int64_t)1 << 32) return TSAMD_ERR_INVALID;
+  if (n == 0 || row_bytes == 0) return TSAMD_OK;
+  if (!src || !idx || !dst) return TSAMD_ERR_INVALID;
+  const uintptr_t a = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)row_bytes;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  if (a % 16 == 0) return launch_gather_rows<u32x4>(src, idx, dst, n, n_src, row_bytes, stream);
+  if (a % 8 == 0) return launch_gather_rows<u32x2>(src, idx, dst, n, n_src, row_bytes, stream);
+  if (a % 4 == 0) return launch_gather_rows<uint32_t>(src, idx, dst, n, n_src, row_bytes, stream);
+  if (a % 2 == 0) return launch_gather_rows<uint16_t>(src, idx, dst, n, n_src, row_bytes, stream);
+  return launch_gather_rows<uint8_t>(src, idx, dst, n, n_src, row_bytes, stream);
+}
+
 extern "C" int tsamd_relabel_ids(const int64_t *ids, int64_t count, int64_t n, int64_t *out,
                                  void *stream_) {
   if (count < 0 || n < 0 || n >= (int64_t)1 << 32) return TSAMD_ERR_UNSUPPORTED;

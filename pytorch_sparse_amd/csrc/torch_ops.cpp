@@ -385,6 +385,22 @@ std::tuple<Tensor, Tensor> spmm_relabelled(OptTensor opt_row, Tensor rowptr, Ten
   return std::make_tuple(out, torch::empty({0}, rowptr.options()));
 }
 
+// dst = src[idx] for a 2-D row-major matrix (send buffer of the sharded SpMM's row exchange)
+Tensor gather_rows(Tensor src, Tensor idx) {
+  check_gpu(src, "src");
+  check_index(idx, "idx");
+  TORCH_CHECK(src.dim() == 2, "gather_rows: src must be 2-D");
+  c10::hip::HIPGuard guard(src.get_device());
+  src = src.contiguous();
+  idx = idx.contiguous();
+  Tensor out = torch::empty({idx.numel(), src.size(1)}, src.options().requires_grad(false));
+  check_status(tsamd_gather_rows(src.data_ptr(), idx.data_ptr<int64_t>(), out.data_ptr(), idx.numel(),
+                                 src.size(0), src.size(1) * (int64_t)src.element_size(),
+                                 current_stream(src)),
+               "tsamd_gather_rows");
+  return out;
+}
+
 // ---- registered entry points (reference signatures) -----------------------------------------
 Tensor spmm_sum(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_value,
                 OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat) {
@@ -1138,6 +1154,7 @@ static auto registry = torch::RegisterOperators()
                            .op("tsamd::segment_reduce", &segment_reduce)
                            .op("tsamd::spspmm", &spspmm)
                            .op("tsamd::relabel_ids", &relabel_ids)
+                           .op("tsamd::gather_rows", &gather_rows)
                            .op("tsamd::spmm_relabelled", &spmm_relabelled)
                            .op("tsamd::select_segments", &select_segments)
                            .op("tsamd::filter_coo", &filter_coo)

@@ -50,6 +50,23 @@ def narrow_rows(rowptr: Tensor, col: Tensor, value: Optional[Tensor], start: int
     return rowptr[start:end + 1] - e0, col[e0:e1], None if value is None else value[e0:e1]
 
 
+def pack_rows(x: Tensor, idx: Tensor) -> Tensor:
+    """x[idx] for a send buffer: the hand-written gather (tsamd::gather_rows, one 16-byte packet per
+    lane) on the GPU -- outside autograd, the exchange Functions own the gradient -- else ATen."""
+    if x.is_cuda and x.dim() == 2 and not x.requires_grad:
+        return torch.ops.tsamd.gather_rows(x, idx)
+    return x.index_select(0, idx)
+
+
+def _default_spmm_into(rowptr, col, value, x, reduce, out):
+    """The local product written straight into `out` (a row slice of the rank's result): the C-ABI takes
+    caller-allocated outputs, so the pieces of a pipelined step need no concatenation afterwards."""
+    from . import _native as nat
+    if value is not None and value.dtype != x.dtype:
+        value = value.to(x.dtype)
+    nat.spmm(rowptr, col, value, x, reduce, out=out)
+
+
 def _default_spmm(rowptr, col, value, x, reduce):
     from .matmul import matmul
     from .tensor import SparseTensor
@@ -127,7 +144,7 @@ class _ExchangeRows(torch.autograd.Function):
         ctx.group, ctx.send_counts, ctx.recv_counts = group, list(send_counts), list(recv_counts)
         ctx.save_for_backward(serve_idx)
         ctx.n_local = x_local.size(0)
-        send = x_local.index_select(0, serve_idx)  # rows packed by requesting rank
+        send = pack_rows(x_local.detach(), serve_idx)  # rows packed by requesting rank
         recv = x_local.new_empty((sum(recv_counts), ) + tuple(x_local.shape[1:]))
         dist.all_to_all_single(recv, send, output_split_sizes=ctx.recv_counts,
                                input_split_sizes=ctx.send_counts, group=group)
@@ -215,8 +232,9 @@ class HaloShardedSpMM(object):
 
 
 class PipelinedHaloSpMM(object):
-    """HaloShardedSpMM with the exchange hidden behind the compute (forward only, SUM / MEAN / MIN /
-    MAX all work because rows are never split).
+    """HaloShardedSpMM with the exchange hidden behind the compute (SUM / MEAN / MIN / MAX all work
+    because rows are never split; differentiable w.r.t. X and the values -- the training path queues
+    the same exchanges through ``_PipelinedFetch``).
 
     The local row block is cut into `chunks` pieces of equal nnz.  Piece i needs the column set
     S_i; what has to arrive before it can run is only D_i = S_i minus (S_0 u ... u S_{i-1}) -- hub columns are
@@ -229,8 +247,14 @@ class PipelinedHaloSpMM(object):
     """
 
     def __init__(self, rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
-                 group=None, spmm_fn: Optional[Callable] = None, chunks: int = 4):
+                 group=None, spmm_fn: Optional[Callable] = None, chunks: int = 4,
+                 spmm_into_fn: Optional[Callable] = None):
         self.group = group
+        # with the product kernels the pieces write into one preallocated result (no torch.cat); an
+        # injected spmm_fn (CPU tests) gets the concatenating path unless it brings its own writer
+        self.spmm_into_fn = spmm_into_fn if spmm_into_fn is not None else (
+            _default_spmm_into if spmm_fn is None else None)
+        self._works, self._keep = [], []
         self.spmm_fn = spmm_fn or _default_spmm
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -280,7 +304,7 @@ class PipelinedHaloSpMM(object):
         self.rows = M
 
     def _start_exchange(self, piece, x_local: Tensor, buf: Tensor):
-        send = x_local.index_select(0, piece['serve_idx'])
+        send = pack_rows(x_local.detach(), piece['serve_idx'])
         a, b = piece['seg']
         return dist.all_to_all_single(buf[a:b], send, output_split_sizes=piece['recv_counts'],
                                       input_split_sizes=piece['send_counts'], group=self.group,
@@ -290,7 +314,15 @@ class PipelinedHaloSpMM(object):
         if self.world == 1:
             p = self.pieces[0]
             return self.spmm_fn(p['rowptr'], p['col'], p['value'], x_local, reduce)
+        needs_grad = torch.is_grad_enabled() and (
+            x_local.requires_grad or any(p['value'] is not None and p['value'].requires_grad for p in self.pieces))
+        if needs_grad:
+            return self._differentiable(x_local, reduce)
         buf = x_local.new_empty((self.n_needed, ) + tuple(x_local.shape[1:]))
+        # one result buffer for the whole row block: every piece writes its rows in place
+        out = None
+        if self.spmm_into_fn is not None:
+            out = x_local.new_empty((self.rows, ) + tuple(x_local.shape[1:]))
         outs = []
         work, keep = self._start_exchange(self.pieces[0], x_local, buf)
         for i, p in enumerate(self.pieces):
@@ -298,10 +330,57 @@ class PipelinedHaloSpMM(object):
             if i + 1 < len(self.pieces):  # enqueue the next exchange BEFORE this piece's SpMM
                 nxt = self._start_exchange(self.pieces[i + 1], x_local, buf)
             work.wait()  # this piece's rows have landed (the compute stream waits, the host does not)
-            outs.append(self.spmm_fn(p['rowptr'], p['col'], p['value'], buf[:p['n_prefix']], reduce))
+            if out is not None:
+                s, e = p['rows']
+                self.spmm_into_fn(p['rowptr'], p['col'], p['value'], buf[:p['n_prefix']], reduce, out[s:e])
+            else:
+                outs.append(self.spmm_fn(p['rowptr'], p['col'], p['value'], buf[:p['n_prefix']], reduce))
             if nxt is not None:
                 work, keep = nxt
+        return out if out is not None else torch.cat(outs, dim=-2)
+
+    def _differentiable(self, x_local: Tensor, reduce: str) -> Tensor:
+        """Training step: the same exchanges, recorded for autograd.  All pieces' exchanges are queued up
+        front (RCCL runs them in order while the pieces multiply); the gradient of the fetched rows is
+        summed over the pieces by autograd and routed back to the owners piece by piece."""
+        buf = _PipelinedFetch.apply(x_local, self)
+        outs = []
+        for i, p in enumerate(self.pieces):
+            self._works[i].wait()
+            outs.append(self.spmm_fn(p['rowptr'], p['col'], p['value'], buf[:p['n_prefix']], reduce))
+        self._works = []
         return torch.cat(outs, dim=-2)
+
+
+class _PipelinedFetch(torch.autograd.Function):
+    """X_need = [D_0 | D_1 | ...] of a PipelinedHaloSpMM with every piece's all_to_all enqueued
+    asynchronously; backward sends each segment's gradient back to the owners and adds it up there."""
+
+    @staticmethod
+    def forward(ctx, x_local: Tensor, plan):
+        ctx.plan = plan
+        ctx.n_local = x_local.size(0)
+        buf = x_local.new_empty((plan.n_needed, ) + tuple(x_local.shape[1:]))
+        plan._works, plan._keep = [], []
+        for p in plan.pieces:
+            work, send = plan._start_exchange(p, x_local, buf)
+            plan._works.append(work)
+            plan._keep.append(send)  # the send buffers must outlive the collectives
+        return buf
+
+    @staticmethod
+    def backward(ctx, grad_buf: Tensor):
+        plan = ctx.plan
+        grad_buf = grad_buf.contiguous()
+        grad_local = grad_buf.new_zeros((ctx.n_local, ) + tuple(grad_buf.shape[1:]))
+        for p in plan.pieces:
+            a, b = p['seg']
+            back = grad_buf.new_empty((sum(p['send_counts']), ) + tuple(grad_buf.shape[1:]))
+            dist.all_to_all_single(back, grad_buf[a:b].contiguous(), output_split_sizes=p['send_counts'],
+                                   input_split_sizes=p['recv_counts'], group=plan.group)
+            grad_local.index_add_(0, p['serve_idx'], back)
+        plan._keep = []
+        return grad_local, None
 
 
 def shard_matrix(rowptr: Tensor, col: Tensor, value: Optional[Tensor], n_cols: int, group=None,

@@ -30,9 +30,16 @@ def oracle_spmm(rowptr, col, value, x, reduce):
 
 
 def torch_spmm_sum(rowptr, col, value, x, reduce):
-    assert reduce == 'sum'
-    row = torch.repeat_interleave(torch.arange(rowptr.numel() - 1), rowptr[1:] - rowptr[:-1])
-    return torch.zeros(rowptr.numel() - 1, x.size(1), dtype=x.dtype).index_add_(0, row, value[:, None] * x[col])
+    """Differentiable torch formulation of the local product (sum, and min / max through
+    scatter_reduce, whose backward routes the gradient to the winning entry like csrc/spmm.cpp:204-242)."""
+    M = rowptr.numel() - 1
+    row = torch.repeat_interleave(torch.arange(M), rowptr[1:] - rowptr[:-1])
+    prod = value[:, None] * x[col]
+    if reduce == 'sum':
+        return torch.zeros(M, x.size(1), dtype=x.dtype).index_add_(0, row, prod)
+    assert reduce in ('min', 'max')
+    return torch.zeros(M, x.size(1), dtype=x.dtype).scatter_reduce(
+        0, row[:, None].expand_as(prod), prod, reduce='a' + reduce, include_self=False)
 
 
 def _worker(rank, world, port, balance, q, exchange='allgather'):
@@ -54,19 +61,31 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
             out_local = op(x_local, reduce)
             full, _ = oc.spmm(oc.F32, reduce, rp.numpy(), c.numpy(), v.numpy(), x.numpy())
             res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]))
-        if exchange == 'pipelined':  # forward-only class
-            res['grad'] = True
-            res['range'] = (s, e)
-            q.put((rank, res))
-            return
-        # backward: grad of x must be reduce-scattered to the owning rank
+        # backward: the gradient of x is a partial sum on every rank and has to reach the owning rank
+        # (reduce-scatter / reverse all_to_all), for sum and -- across ranks -- for min / max; the value
+        # gradient is local
         opd, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=torch_spmm_sum, exchange=exchange)
-        xl = x_local.clone().requires_grad_()
-        gout = synth.features(n, 12, seed=5)[s:e]
-        opd(xl, 'sum').backward(gout)
-        xg = x.clone().requires_grad_()
-        torch_spmm_sum(rp, c, v, xg, 'sum').backward(synth.features(n, 12, seed=5))
-        res['grad'] = bool(torch.allclose(xl.grad, xg.grad[xs:xs + sizes[rank]], rtol=1e-5, atol=1e-5))
+        e0, e1 = int(rp[s]), int(rp[e])
+        ok = True
+        for reduce in ('sum', 'max', 'min'):
+            xl = x_local.clone().requires_grad_()
+            vl = v[e0:e1].clone().requires_grad_()
+            if hasattr(opd, 'pieces'):  # pipelined: the pieces hold views of the value array
+                off = 0
+                for pc in opd.pieces:
+                    k = pc['col'].numel()
+                    pc['value'] = vl[off:off + k]
+                    off += k
+            else:
+                opd.value = vl
+            gout = synth.features(n, 12, seed=5)[s:e]
+            opd(xl, reduce).backward(gout)
+            xg = x.clone().requires_grad_()
+            vg = v.clone().requires_grad_()
+            torch_spmm_sum(rp, c, vg, xg, reduce).backward(synth.features(n, 12, seed=5))
+            ok = ok and bool(torch.allclose(xl.grad, xg.grad[xs:xs + sizes[rank]], rtol=1e-5, atol=1e-5))
+            ok = ok and bool(torch.allclose(vl.grad, vg.grad[e0:e1], rtol=1e-5, atol=1e-5))
+        res['grad'] = ok
         res['range'] = (s, e)
         q.put((rank, res))
     finally:
@@ -153,6 +172,15 @@ def test_bench_local_block_shapes():
                 share = torch.bincount(c // m, minlength=world).float() / c.numel()
                 assert (share > 0.5 / world).all()
     assert bench.b_alg(10, 4, 8, 4, True, False) == 10 * (8 + 4 + 32) + 5 * 8 + 4 * 8 * 4
+    # strong scaling: the blocks of all ranks tile ONE matrix, balanced by nnz
+    full_rp, full_c = synth.rmat_csr(10, 8, seed=0)
+    for world in (2, 4):
+        blocks = [bench.strong_block(10, 8, world, r, 'cpu') for r in range(world)]
+        assert all(b[3] == 1 << 10 and b[4] == blocks[0][4] for b in blocks)
+        assert sum(blocks[0][4]) == 1 << 10 and [b[2] for b in blocks] == blocks[0][4]
+        assert torch.equal(torch.cat([b[1] for b in blocks]), full_c)
+        nnz = [b[1].numel() for b in blocks]
+        assert max(nnz) - min(nnz) <= int((full_rp[1:] - full_rp[:-1]).max())  # equal shares up to one row
 
 
 def _orchestration_worker(rank, world, port, q):
