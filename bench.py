@@ -204,11 +204,18 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists)'
+    # TSAMD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+    # (ranks share devices, collectives go through gloo) -- a functional check, never a measurement
+    backend = os.environ.get('TSAMD_BENCH_BACKEND', 'nccl')
+    local_rank = local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pytorch_sparse_amd import _native as nat
     from pytorch_sparse_amd import synth
@@ -373,7 +380,7 @@ def main():
         line = dict(metric='SpMM GEdges/s', value=round(gedges, 3), unit='GEdges/s', n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                     higher_is_better=True, scaling=(args.scaling if world > 1 else 'weak'), vs_baseline=None, dtype='f32',
-                    data='synthetic',
+                    data='synthetic' if backend == 'nccl' else 'synthetic (REHEARSAL over %s, ranks share GPUs: not a measurement)' % backend,
                     config=dict(workload=wl['desc'], reduce=args.reduce, rows_per_gpu=m_local,
                                 cols=n_global, edges_per_gpu=E, features=F,
                                 graph='R-MAT(0.57,0.19,0.19,0.05) scale %d edge factor %d, coalesced' % (scale, ef),

@@ -44,7 +44,12 @@ typedef enum {
   TSAMD_F16 = 2,
   TSAMD_BF16 = 3,
   TSAMD_I32 = 4,
-  TSAMD_I64 = 5
+  TSAMD_I64 = 5,
+  /* SpMM forward only (the reference dispatches AT_DISPATCH_ALL_TYPES_AND2, csrc/cpu/spmm_cpu.cpp:47):
+   * sums wrap like the C++ type, mean divides the wrapped sum by the count cast to the type */
+  TSAMD_U8 = 6,
+  TSAMD_I8 = 7,
+  TSAMD_I16 = 8
 } tsamd_dtype;
 
 /* Reductions reachable from the registered ops (csrc/spmm.cpp:82,145,195,255;

@@ -9,11 +9,11 @@ import numpy as np
 
 from . import build
 
-F32, F64, F16, BF16, I32, I64 = range(6)
+F32, F64, F16, BF16, I32, I64, U8, I8, I16 = range(9)
 SUM, MEAN, MIN, MAX = range(4)
 REDUCE = {'sum': SUM, 'add': SUM, 'mean': MEAN, 'min': MIN, 'max': MAX}
 NP_DTYPE = {F32: np.float32, F64: np.float64, F16: np.float16, BF16: np.uint16, I32: np.int32,
-            I64: np.int64}
+            I64: np.int64, U8: np.uint8, I8: np.int8, I16: np.int16}
 
 _lib = None
 

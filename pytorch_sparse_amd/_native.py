@@ -36,7 +36,7 @@ SYMBOLS = [
 
 DTYPES = {
     torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3,
-    torch.int32: 4, torch.int64: 5,
+    torch.int32: 4, torch.int64: 5, torch.uint8: 6, torch.int8: 7, torch.int16: 8,
 }
 REDUCES = {'sum': 0, 'add': 0, 'mean': 1, 'min': 2, 'max': 3}
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <limits>
+#include <type_traits>
 
 #include "tsamd.h"
 
@@ -164,6 +165,41 @@ struct Traits<int64_t> {
   __device__ static inline acc_t lowest_init() { return (-9223372036854775807LL - 1); }
 };
 
+// 8- / 16-bit integers (SpMM forward only): carried in int32, wrapped to the element type where the
+// reference's scalar_t arithmetic wraps (every product handed to the reducer, the final sum).
+template <typename T>
+struct SmallIntTraits {
+  using acc_t = int32_t;
+  static constexpr bool kNarrow = false;
+  __device__ static inline acc_t to_acc(T x) { return (acc_t)x; }
+  __device__ static inline T from_acc(acc_t a) { return (T)a; }
+  __device__ static inline acc_t round_acc(acc_t a) { return (acc_t)(T)a; }
+  __device__ static inline acc_t max_init() { return (acc_t)std::numeric_limits<T>::max(); }
+  __device__ static inline acc_t lowest_init() { return (acc_t)std::numeric_limits<T>::lowest(); }
+};
+template <>
+struct Traits<uint8_t> : SmallIntTraits<uint8_t> {};
+template <>
+struct Traits<int8_t> : SmallIntTraits<int8_t> {};
+template <>
+struct Traits<int16_t> : SmallIntTraits<int16_t> {};
+
+// mean = sum / (scalar_t)count (reducer.h:74).  Floating types and 32 / 64-bit integers divide the
+// accumulator; the small integers divide the WRAPPED sum by the WRAPPED count like the reference
+// (a divisor that wraps to zero -- 256 entries in a uint8 row -- traps in the reference, gives 0 here).
+template <typename T>
+__device__ inline typename Traits<T>::acc_t mean_of(typename Traits<T>::acc_t sum, int64_t deg) {
+  using A = typename Traits<T>::acc_t;
+  const int64_t cnt = deg > 0 ? deg : 1;
+  if constexpr (std::is_same<T, uint8_t>::value || std::is_same<T, int8_t>::value ||
+                std::is_same<T, int16_t>::value) {
+    const int32_t s = (int32_t)(T)sum, d = (int32_t)(T)cnt;
+    return d == 0 ? 0 : s / d;
+  } else {
+    return sum / (A)cnt;
+  }
+}
+
 static inline size_t dtype_size(int dtype) {
   switch (dtype) {
     case TSAMD_F32: return 4;
@@ -172,12 +208,15 @@ static inline size_t dtype_size(int dtype) {
     case TSAMD_BF16: return 2;
     case TSAMD_I32: return 4;
     case TSAMD_I64: return 8;
+    case TSAMD_U8: case TSAMD_I8: return 1;
+    case TSAMD_I16: return 2;
     default: return 0;
   }
 }
 static inline size_t acc_size(int dtype) {
   switch (dtype) {
     case TSAMD_F32: case TSAMD_F16: case TSAMD_BF16: case TSAMD_I32: return 4;
+    case TSAMD_U8: case TSAMD_I8: case TSAMD_I16: return 4;
     case TSAMD_F64: case TSAMD_I64: return 8;
     default: return 0;
   }
@@ -195,6 +234,17 @@ static inline size_t acc_size(int dtype) {
       case TSAMD_I64: { using scalar_t = int64_t; return __VA_ARGS__(); }  \
       default: return (int)TSAMD_ERR_UNSUPPORTED;                          \
     }                                                                      \
+  }()
+
+// The same plus the 8- / 16-bit integers (SpMM forward).
+#define TSAMD_DISPATCH_DTYPE_ALL(dtype, ...)                                  \
+  [&]() -> int {                                                              \
+    switch (dtype) {                                                          \
+      case TSAMD_U8: { using scalar_t = uint8_t; return __VA_ARGS__(); }      \
+      case TSAMD_I8: { using scalar_t = int8_t; return __VA_ARGS__(); }       \
+      case TSAMD_I16: { using scalar_t = int16_t; return __VA_ARGS__(); }     \
+      default: return TSAMD_DISPATCH_DTYPE(dtype, __VA_ARGS__);               \
+    }                                                                         \
   }()
 
 // --------------------------------------------------------------------------

@@ -313,9 +313,8 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
   Pack<T, VEC> o;
   if constexpr (RED == RED_ADD) {
     if (mean) {
-      const A d = (A)(deg > 0 ? deg : 1);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) val[j] = val[j] / d;
+      for (int j = 0; j < VEC; ++j) val[j] = mean_of<T>(val[j], deg);
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -767,7 +766,7 @@ int dispatch_reduce(int reduce, const int64_t *rowptr, const int64_t *col, const
 // `vec` = elements per lane packet, chosen by the caller: the largest power of two <= kMaxVec<T>
 // that divides K and matches the pointers' alignment.
 template <typename T>
-constexpr int kMaxVec = sizeof(T) == 2 ? 4 : 16 / (int)sizeof(T);
+constexpr int kMaxVec = sizeof(T) <= 2 ? 4 : 16 / (int)sizeof(T);
 
 template <typename T>
 int dispatch_spmm(int reduce, int vec, const int64_t *rowptr, const int64_t *col,
@@ -829,13 +828,13 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
     ws.out_relabel = 1;
   }
   const size_t es = dtype_size(dtype);
-  int vec = es == 2 ? 4 : (int)(16 / es);  // widest packet for the type (see dispatch_spmm)
+  int vec = es <= 2 ? 4 : (int)(16 / es);  // widest packet for the type (see dispatch_spmm)
   while (vec > 1 && !((K % vec) == 0 && ((uintptr_t)mat % (vec * es)) == 0 &&
                       ((uintptr_t)out % (vec * es)) == 0 &&
                       (!minmax || ((uintptr_t)arg_out % (vec * 8)) == 0)))
     vec >>= 1;
 
-  return TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
+  return TSAMD_DISPATCH_DTYPE_ALL(dtype, [&]() -> int {
     return dispatch_spmm<scalar_t>(reduce, vec, rowptr, col, value, mat, out, arg_out, B, M, N,
                                    K, E, ws, stream, ev);
   });

@@ -40,9 +40,13 @@ int dtype_code(const Tensor &t) {
     case at::kBFloat16: return TSAMD_BF16;
     case at::kInt: return TSAMD_I32;
     case at::kLong: return TSAMD_I64;
+    case at::kByte: return TSAMD_U8;
+    case at::kChar: return TSAMD_I8;
+    case at::kShort: return TSAMD_I16;
     default:
       TORCH_CHECK(false, "pytorch_sparse_amd: unsupported dtype ", t.scalar_type(),
-                  " (supported: float32, float64, float16, bfloat16, int32, int64)");
+                  " (supported: float32, float64, float16, bfloat16, int32, int64; uint8, int8, int16 in "
+                  "the SpMM forward)");
   }
 }
 

@@ -24,8 +24,9 @@ def make_inputs(rp, c, n, K, dtype, has_value, batch=(), seed=0):
         x = synth.features(n, K, seed=seed + 2, dtype=dtype, batch=batch)
     else:
         g = torch.Generator().manual_seed(seed)
-        v = torch.randint(-4, 5, (E, ), dtype=dtype, generator=g) if has_value else None
-        x = torch.randint(-9, 9, (*batch, n, K), dtype=dtype, generator=g)
+        lo = 0 if dtype == torch.uint8 else 1  # unsigned: no negative draws (sums still wrap)
+        v = torch.randint(-4 * lo, 5, (E, ), dtype=dtype, generator=g) if has_value else None
+        x = torch.randint(-9 * lo, 9 + 100 * (1 - lo), (*batch, n, K), dtype=dtype, generator=g)
     return v, x
 
 

@@ -5,7 +5,8 @@ import torch
 from oracle import c_oracle as oc
 
 CODE = {torch.float32: oc.F32, torch.float64: oc.F64, torch.float16: oc.F16,
-        torch.bfloat16: oc.BF16, torch.int32: oc.I32, torch.int64: oc.I64}
+        torch.bfloat16: oc.BF16, torch.int32: oc.I32, torch.int64: oc.I64, torch.uint8: oc.U8,
+        torch.int8: oc.I8, torch.int16: oc.I16}
 ALL_DTYPES = list(CODE)
 FLOAT_DTYPES = [torch.float32, torch.float64, torch.float16, torch.bfloat16]
 # |gpu - exact| <= TOL * sum_e |value_e * x_e|   (fp32: the 1e-5 rel bar of BASELINE.json;
