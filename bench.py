@@ -189,6 +189,9 @@ def main():
     ap.add_argument('--reduce', default='sum', choices=['sum', 'mean', 'min', 'max'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the C2 / C3 / C4 entries (N = 1 only)')
+    ap.add_argument('--headline-only', action='store_true',
+                    help='only the timed north-star steps + the roofline launches (for rocprofv3: every launch of the '
+                         'dominant kernel in the trace is then the headline workload)')
     ap.add_argument('--exchange', default='pipelined', choices=['pipelined', 'halo', 'allgather'],
                     help='N > 1: all_gather of X | halo = all_to_all of the referenced rows only | '
                          'pipelined = halo exchange in row pieces, overlapped with the SpMM of the previous piece')
@@ -394,12 +397,12 @@ def main():
                                                       for k, v in variants.items()}
         if fallback_reason is not None:
             line['config']['exchange_fallback'] = 'requested %s; %s' % (requested, fallback_reason)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             line['cpu_baseline'] = cpu_baseline(rowptr, col_k, value, x_full, args.reduce, out)
-        if world == 1:
+        if world == 1 and not args.headline_only:
             line['relabelled_layout'] = relabelled_leg(rowptr, col_k, value, x_full, out, args.reduce,
                                                        max(10, min(args.steps, 50)), dev)
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and not args.headline_only:
             del x_full, out, sharded
             torch.cuda.empty_cache()
             line['control'] = control_graph(m_local, ef, F, dev, nat)

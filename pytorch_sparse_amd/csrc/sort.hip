@@ -49,6 +49,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const int64_t *__restrict__ keys_in, const int64_t *__restrict__ vals_in,
     int64_t *__restrict__ keys_out, int64_t *__restrict__ vals_out, int64_t n, int shift,
     const int64_t *__restrict__ hist_scanned, int64_t nb) {
+  // gfx950 only: the tile lives in LDS (160 KB per CU there, 64 KB on older parts)
+  static_assert(sizeof(int64_t) * 2 * kSortTile + sizeof(uint32_t) * 5 * kRadix + sizeof(int64_t) * (kRadix + 8) <=
+                    160 * 1024,
+                "radix_scatter_kernel: the tile (TSAMD_SORT_ITEMS) no longer fits the 160 KB LDS of gfx950");
   __shared__ int64_t skey[kSortTile];
   __shared__ int64_t sval[kSortTile];
   __shared__ uint32_t cnt[4][kRadix];

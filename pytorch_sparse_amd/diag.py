@@ -74,7 +74,9 @@ def get_diag(src: SparseTensor) -> Tensor:
     # off-diagonal entries are parked in one extra slot that is dropped afterwards (no host sync)
     out = value.new_zeros([sizes[0] + 1] + sizes[1:])
     slot = torch.where(row == col, row, torch.full_like(row, sizes[0]))
-    out.index_copy_(0, slot, value.detach())
+    # differentiable w.r.t. the stored values, like the reference's `out[row[mask]] = value[mask]`
+    # (torch_sparse/diag.py:98-110): index_copy into fresh zeros carries the gradient of its source
+    out = out.index_copy(0, slot, value)
     return out[:sizes[0]]
 
 

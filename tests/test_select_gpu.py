@@ -333,3 +333,22 @@ def test_index_select_cols_sorted_subset_fast_path(ts):
     assert out2.storage.has_csc2csr()
     with pytest.raises(IndexError):
         A.index_select(1, torch.tensor([5, 30_000], device=DEV))
+
+
+def test_get_diag_is_differentiable():
+    """The reference's get_diag (`out[row[mask]] = value[mask]`, torch_sparse/diag.py:98-110) carries the
+    gradient of the stored values: d(sum(w * diag))/dvalue = w[row] on the diagonal, 0 elsewhere."""
+    import pytorch_sparse_amd as ts
+    g = torch.Generator().manual_seed(4)
+    n = 300
+    key = torch.randperm(n * n, generator=g)[:4000]
+    row, col = torch.cat([key // n, torch.arange(0, n, 2)]), torch.cat([key % n, torch.arange(0, n, 2)])
+    value = torch.rand(row.numel(), 3, generator=g, dtype=torch.float64)
+    A0 = ts.SparseTensor(row=row.to(DEV), col=col.to(DEV), value=value.to(DEV), sparse_sizes=(n, n)).coalesce()
+    r, c, v0 = A0.coo()
+    v = v0.clone().requires_grad_()
+    A = A0.set_value(v, layout='coo')
+    w = torch.rand(n, 3, generator=g, dtype=torch.float64).to(DEV)
+    (A.get_diag() * w).sum().backward()
+    expect = torch.where((r == c)[:, None], w[r], torch.zeros_like(v0))
+    assert torch.equal(v.grad, expect)
