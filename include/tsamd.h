@@ -266,19 +266,22 @@ int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t
  *        [3]=#large  [4]=products in large rows.
  *        --> host reads stats (sync 1: grid sizes and the workspace of the large rows).
  *   2. tsamd_spspmm_symbolic  nnzC[i] = exact number of entries of row i of C (LDS hash sets for
- *        small / medium rows; global sort + coalesce for large rows, whose sorted pattern stays in
- *        `workspace` for stage 4).  nnzC has M entries, all written.
+ *        small / medium rows; large rows: products binned by column range into `workspace`
+ *        -- 4 + sizeof(value) bytes per product, which stage 4 reuses -- and counted with LDS
+ *        bitmaps).  nnzC has M entries, all written.  `dtype` is the value type of stage 4 (it
+ *        fixes the width of a column range).
  *   3. host: rowptrC = exclusive scan of nnzC over M + 1 entries (tsamd_exclusive_scan_i64, entry
  *        M = 0), reads nnz(C) (sync 2), allocates colC / valC at their FINAL size.
  *   4. tsamd_spspmm_numeric   every row is expanded, sorted by column (registers / LDS), its equal
- *        columns summed in product order, and stored at rowptrC[i].  valA / valB may be NULL (all
- *        ones); valC may be NULL (structure only).  `workspace` is the one stage 2 filled.
+ *        columns summed in product order (large rows: in atomic order, not bit-reproducible), and
+ *        stored at rowptrC[i].  valA / valB may be NULL (all ones); valC may be NULL (structure
+ *        only).  `workspace` is the one stage 2 filled.
  * M < 2^31, N < 2^32 - 1.
  * ------------------------------------------------------------------------ */
 int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
                       int64_t M, int64_t *prod, int64_t *bins, int64_t *stats, void *stream);
-size_t tsamd_spspmm_workspace_bytes(int64_t n_large, int64_t P_large);
-int tsamd_spspmm_symbolic(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
+size_t tsamd_spspmm_workspace_bytes(int dtype, int64_t n_large, int64_t P_large, int64_t N);
+int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
                           const int64_t *colB, int64_t M, int64_t N, const int64_t *prod,
                           const int64_t *bins, int64_t n_medium, int64_t n_large, int64_t P_large,
                           int64_t *nnzC, void *workspace, size_t workspace_bytes, void *stream);

@@ -10,9 +10,9 @@
 //             products, medium <= 4096, large) with one atomic per wave and bin.
 //   symbolic  exact nnz of every row of C.  small / medium rows: one wave / one 256-thread
 //             workgroup expands the row's product COLUMNS straight into an LDS hash set (1 Ki / 8 Ki
-//             slots) and counts the successful inserts.  Large rows: expanded to HBM, global radix
-//             sort + coalesce (sort.hip / coalesce.hip); the sorted unique pattern stays in the
-//             workspace for the numeric stage.
+//             slots) and counts the successful inserts.  Large rows: their products are binned by
+//             column range into HBM scratch (4 + sizeof(T) bytes per product) and counted bin by bin
+//             with an LDS occupancy bitmap; the bins stay in the workspace for the numeric stage.
 //   (host)    exclusive scan of the counts = the FINAL rowptr of C; one sync for nnz(C); colC / valC
 //             are allocated at their final size -- no per-row slot buffer of `products` entries,
 //             no compaction copy.
@@ -24,19 +24,12 @@
 //             (deterministic) and the compressed row stored at its final position.  When
 //             ceil(log2 N) > 23 the keys do not fit 32 bits: LDS radix sort of (column, value)
 //             pairs instead.  Medium rows: 256-thread bitonic sort of pairs in LDS.  Large rows:
-//             values expanded to HBM and summed through the permutation of the symbolic stage.
+//             one column range at a time in dense LDS accumulators (see "large rows" below).
 #include "common.h"
 #include "scan.h"
 
 #include <type_traits>
 #include <utility>
-
-extern "C" int tsamd_sort_coo(const int64_t *, const int64_t *, int64_t, int64_t, int64_t,
-                              int64_t *, int64_t *, int64_t *, void *, size_t, void *);
-extern "C" size_t tsamd_sort_coo_workspace_bytes(int64_t);
-extern "C" int tsamd_coalesce_index(const int64_t *, const int64_t *, int64_t, int64_t *,
-                                    int64_t *, int64_t *, int64_t *, void *, size_t, void *);
-extern "C" size_t tsamd_coalesce_workspace_bytes(int64_t);
 
 namespace tsamd {
 namespace {
@@ -607,91 +600,245 @@ __global__ __launch_bounds__(BLOCK) void spspmm_numeric_pairs_kernel(
       [&](int idx) { return sval[idx]; });
 }
 
-// Large rows: expand (row, col, val) triples to HBM at lp[r] (exclusive scan of their products).
+// ---------------------------------------------------------------------------
+// large rows (more than kMediumCap products): binned dense accumulation.
+//
+// Power-law operands put most of their products into such rows (A * A^T of an R-MAT graph: a hub row
+// has 10^5 .. 10^8 products, many of them on the same few hub columns), where neither a sort nor a
+// per-row hash table in LDS fits and where sorting the expansion in HBM costs ~100 bytes of scratch per
+// product.  Here the column space is cut into ranges of kRangeCols columns -- one range of fp32 / fp64
+// accumulators plus an occupancy bitmap is what LDS holds -- and a row is processed range by range:
+//   hist      workgroup per large row: products per (row, range), counted in LDS while expanding
+//   (scan)    -> bin offsets: the products of (row, range) get a contiguous segment of a scratch array
+//   bin       workgroup per large row: expand again, every product (column inside the range [, value])
+//             goes to its segment (LDS cursors); 4 + sizeof(T) bytes of scratch per product
+//   count     (symbolic) persistent workgroups over the non-empty bins: set the occupancy bits, popcount
+//   accum     (numeric)  persistent workgroups over the non-empty bins: atomicAdd into the LDS accumulators,
+//             then walk the bitmap in column order, store (column, sum) at the bin's final position and
+//             put the touched accumulators back to zero
+// Duplicates cost nothing extra, the output comes out sorted by construction, explicit zeros are kept
+// (an entry exists when its bit is set).  The sums of such a row are formed in atomic order: unlike the
+// small / medium rows they are not bit-reproducible from run to run (fp32 rounding order).
+// ---------------------------------------------------------------------------
+constexpr int kRangeBytes = 128 * 1024;  // LDS accumulators of one range
+constexpr int kLargeThreads = 256;   // hist / bin kernels: one workgroup per large row
+constexpr int kAccumThreads = 1024;  // count / accum kernels: ONE workgroup per CU (LDS), so make it a big one
+constexpr int kBinBatch = 4;         // bin entries fetched per thread before they are consumed
+constexpr int kMaxRanges = 8192;         // LDS counters / cursors of the hist and bin kernels
+
 template <typename T>
-__global__ __launch_bounds__(256) void spspmm_expand_large_kernel(
+constexpr int kLgRange = sizeof(typename Traits<T>::acc_t) == 4 ? 15 : 14;  // 32 Ki fp32 / 16 Ki fp64 columns
+
+__global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
-    const T *__restrict__ valA, const int64_t *__restrict__ rowptrB,
-    const int64_t *__restrict__ colB, const T *__restrict__ valB,
-    const int64_t *__restrict__ rows, const int64_t *__restrict__ lp, int64_t *__restrict__ erow,
-    int64_t *__restrict__ ecol, T *__restrict__ eval) {
-  using A = typename Traits<T>::acc_t;
+    const int64_t *__restrict__ rowptrB, const int64_t *__restrict__ colB,
+    const int64_t *__restrict__ rows, int lg_range, int nr, int64_t *__restrict__ hist) {
+  __shared__ int cnt[kMaxRanges];
+  __shared__ ExpandScratch<float> sc;
   const int tid = (int)threadIdx.x;
   const int64_t i = rows[blockIdx.x];
-  int64_t out = lp[blockIdx.x];
-  for (int64_t e = rowptrA[i]; e < rowptrA[i + 1]; ++e) {
-    const int64_t c = colA[e];
-    const int64_t bs = rowptrB[c], d = rowptrB[c + 1] - bs;
-    const A av = (eval != nullptr && valA != nullptr) ? Traits<T>::to_acc(valA[e]) : A(1);
-    for (int64_t j = tid; j < d; j += 256) {
-      if (erow != nullptr) {
-        erow[out + j] = i;
-        ecol[out + j] = colB[bs + j];
-      }
-      if (eval != nullptr)
-        eval[out + j] = Traits<T>::from_acc(valB != nullptr ? av * Traits<T>::to_acc(valB[bs + j]) : av);
-    }
-    out += d;
-  }
+  for (int q = tid; q < nr; q += kLargeThreads) cnt[q] = 0;
+  __syncthreads();
+  expand_row<float, kLargeThreads, false>(colA, nullptr, rowptrB, colB, nullptr, rowptrA[i], rowptrA[i + 1], sc,
+                                          [&](int, uint32_t c, float) { atomicAdd(&cnt[c >> lg_range], 1); });
+  __syncthreads();
+  for (int q = tid; q < nr; q += kLargeThreads) hist[(int64_t)blockIdx.x * nr + q] = cnt[q];
 }
 
-__global__ void gather_prod_kernel(const int64_t *__restrict__ rows, const int64_t *__restrict__ prod,
-                                   int64_t n, int64_t *__restrict__ out) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) out[r] = prod[rows[r]];
-}
-
-// unique (row, col) of the large rows: entry q is the j-th entry of its row
-__device__ __forceinline__ int64_t rank_in_row(const int64_t *__restrict__ row_u, int64_t q) {
-  const int64_t r = row_u[q];
-  int64_t lo = 0, hi = q;  // first q' with row_u[q'] == r
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (row_u[mid] < r) lo = mid + 1; else hi = mid;
-  }
-  return q - lo;
-}
-
-__global__ void spspmm_count_large_kernel(const int64_t *__restrict__ row_u,
-                                          const int64_t *__restrict__ nuniq,
-                                          int64_t *__restrict__ nnzC, int64_t cap) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = *nuniq;
-  if (q >= n || q >= cap) return;
-  if (q == n - 1 || row_u[q + 1] != row_u[q]) nnzC[row_u[q]] = rank_in_row(row_u, q) + 1;
-}
-
-template <typename T>
-__global__ void spspmm_scatter_large_kernel(const int64_t *__restrict__ row_u,
-                                            const int64_t *__restrict__ col_u,
-                                            const int64_t *__restrict__ seg_ptr,
-                                            const int64_t *__restrict__ perm,
-                                            const T *__restrict__ eval,
-                                            const int64_t *__restrict__ nuniq,
-                                            const int64_t *__restrict__ rowptrC,
-                                            int64_t *__restrict__ colC, T *__restrict__ valC,
-                                            int64_t cap) {
+template <typename T, bool WITH_VAL>
+__global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
+    const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA, const T *__restrict__ valA,
+    const int64_t *__restrict__ rowptrB, const int64_t *__restrict__ colB, const T *__restrict__ valB,
+    const int64_t *__restrict__ rows, int lg_range, int nr, const int64_t *__restrict__ bin_off,
+    uint32_t *__restrict__ bcol, T *__restrict__ bval) {
   using A = typename Traits<T>::acc_t;
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = *nuniq;
-  if (q >= n || q >= cap) return;
-  const int64_t dst = rowptrC[row_u[q]] + rank_in_row(row_u, q);
-  colC[dst] = col_u[q];
-  if (valC != nullptr) {
-    A acc = A(0);
-    for (int64_t t = seg_ptr[q]; t < seg_ptr[q + 1]; ++t) acc += Traits<T>::to_acc(eval[perm[t]]);
-    valC[dst] = Traits<T>::from_acc(acc);
+  __shared__ int cursor[kMaxRanges];
+  __shared__ ExpandScratch<A> sc;
+  const int tid = (int)threadIdx.x;
+  const int64_t i = rows[blockIdx.x];
+  for (int q = tid; q < nr; q += kLargeThreads) cursor[q] = 0;
+  __syncthreads();
+  const int64_t *off = bin_off + (int64_t)blockIdx.x * nr;
+  const uint32_t mask = (1u << lg_range) - 1u;
+  expand_row<T, kLargeThreads, WITH_VAL>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+                                         [&](int, uint32_t c, A v) {
+    const int q = (int)(c >> lg_range);
+    const int64_t pos = off[q] + atomicAdd(&cursor[q], 1);
+    bcol[pos] = c & mask;
+    if (WITH_VAL) bval[pos] = Traits<T>::from_acc(v);
+  });
+}
+
+// The persistent count / accum workgroups draw their bins from a global ticket counter (bins differ by
+// five orders of magnitude in size, and a fixed stride hands every hub-range bin to the same few
+// workgroups: measured 46 -> 111 ms).  The ticket for the NEXT bin is drawn while the current one is
+// being processed, so its round trip is not exposed.
+struct Tickets {
+  unsigned long long *queue;
+  int64_t *slot;  // LDS
+  __device__ __forceinline__ int64_t first() {
+    if (threadIdx.x == 0) slot[0] = (int64_t)atomicAdd(queue, 1ull);
+    __syncthreads();
+    return slot[0];
+  }
+  // call once per bin, before the work on `current` starts
+  __device__ __forceinline__ void prefetch() {
+    if (threadIdx.x == 0) slot[1] = (int64_t)atomicAdd(queue, 1ull);
+  }
+  // call after the work (all threads): hands out the prefetched ticket
+  __device__ __forceinline__ int64_t next() {
+    __syncthreads();
+    if (threadIdx.x == 0) slot[0] = slot[1];
+    __syncthreads();
+    return slot[0];
+  }
+};
+
+// symbolic: distinct columns per bin, added up per row
+__global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
+    const int64_t *__restrict__ rows, int nr, int64_t ntask, const int64_t *__restrict__ bin_off,
+    const uint32_t *__restrict__ bcol, int range_words, int64_t *__restrict__ bin_cnt,
+    unsigned long long *__restrict__ nnzC, unsigned long long *queue) {
+  __shared__ uint32_t bits[(1 << 15) / 32];
+  __shared__ int s_part[kAccumThreads / 64];
+  const int tid = (int)threadIdx.x;
+  __shared__ int64_t s_ticket[2];
+  for (int w = tid; w < range_words; w += kAccumThreads) bits[w] = 0;
+  Tickets tk{queue, s_ticket};
+  for (int64_t task = tk.first(); task < ntask; task = tk.next()) {
+    tk.prefetch();
+    const int64_t b0 = bin_off[task], b1 = bin_off[task + 1];
+    if (b0 == b1) {
+      if (tid == 0) bin_cnt[task] = 0;
+      continue;
+    }
+    for (int64_t p0 = b0 + tid; p0 < b1; p0 += (int64_t)kAccumThreads * kBinBatch) {
+      uint32_t c[kBinBatch];
+#pragma unroll
+      for (int u = 0; u < kBinBatch; ++u) {
+        const int64_t p = p0 + (int64_t)u * kAccumThreads;
+        c[u] = bcol[p < b1 ? p : b1 - 1];  // a repeated entry sets the same bit again
+      }
+#pragma unroll
+      for (int u = 0; u < kBinBatch; ++u) atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
+    }
+    __syncthreads();
+    int n = 0;
+    for (int w = tid; w < range_words; w += kAccumThreads) {
+      n += __popc(bits[w]);
+      bits[w] = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) n += lane_xor(n, off);
+    if ((tid & 63) == 0) s_part[tid >> 6] = n;
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < kAccumThreads / 64; ++w) tot += s_part[w];
+      bin_cnt[task] = tot;
+      atomicAdd(&nnzC[rows[task / nr]], (unsigned long long)tot);
+    }
+  }
+}
+
+// numeric: accumulate a bin in LDS, emit it in column order at its final position
+template <typename T>
+__global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
+    const int64_t *__restrict__ rows, int nr, int64_t ntask, const int64_t *__restrict__ bin_off,
+    const uint32_t *__restrict__ bcol, const T *__restrict__ bval, const int64_t *__restrict__ bin_pref,
+    const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC, T *__restrict__ valC,
+    unsigned long long *queue) {
+  using A = typename Traits<T>::acc_t;
+  constexpr int kCols = 1 << kLgRange<T>;
+  constexpr int kWords = kCols / 32;  // 1024 (fp32) or 512 (fp64): at most one word per thread
+  static_assert(kWords <= kAccumThreads, "one bitmap word per thread");
+  __shared__ A acc[kCols];
+  __shared__ uint32_t bits[kWords];
+  __shared__ int sscan[kAccumThreads / 64];
+  __shared__ int wpre[kWords];
+  const int tid = (int)threadIdx.x;
+  for (int c = tid; c < kCols; c += kAccumThreads) acc[c] = A(0);
+  __shared__ int64_t s_ticket[2];
+  for (int w = tid; w < kWords; w += kAccumThreads) bits[w] = 0;
+  Tickets tk{queue, s_ticket};
+  for (int64_t task = tk.first(); task < ntask; task = tk.next()) {
+    tk.prefetch();
+    const int64_t b0 = bin_off[task], b1 = bin_off[task + 1];
+    if (b0 == b1) continue;
+    for (int64_t p0 = b0 + tid; p0 < b1; p0 += (int64_t)kAccumThreads * kBinBatch) {
+      uint32_t c[kBinBatch];
+      A v[kBinBatch];
+#pragma unroll
+      for (int u = 0; u < kBinBatch; ++u) {
+        const int64_t p = p0 + (int64_t)u * kAccumThreads;
+        const bool ok = p < b1;
+        c[u] = bcol[ok ? p : b1 - 1];
+        v[u] = (ok && valC != nullptr) ? Traits<T>::to_acc(bval[p]) : A(0);  // a repeat adds zero
+      }
+#pragma unroll
+      for (int u = 0; u < kBinBatch; ++u) {
+        atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
+        if (valC != nullptr) atomicAdd(&acc[c[u]], v[u]);
+      }
+    }
+    __syncthreads();
+    const int64_t r = task / nr, q = task - r * nr;
+    // bitmap word t -> exclusive prefix of the set bits (thread t owns word t)
+    const uint32_t wd = tid < kWords ? bits[tid] : 0u;
+    int tot;
+    const int pre = block_exclusive_scan_small<kAccumThreads / 64>(__popc(wd), sscan, &tot);
+    if (tid < kWords) wpre[tid] = pre;
+    __syncthreads();
+    // lane = OUTPUT position, so that the stores are coalesced (a thread that walks its own word writes
+    // 64 different cache lines per store instruction: measured 2x slower for the whole kernel): find the
+    // word that holds the o-th set bit (binary search over the prefixes), then the bit inside the word
+    const int64_t out0 = rowptrC[rows[r]] + (bin_pref[task] - bin_pref[r * nr]);
+    const int64_t col0 = q << kLgRange<T>;
+    for (int o = tid; o < tot; o += kAccumThreads) {
+      int lo = 0, hi = kWords;  // last word whose prefix is <= o
+#pragma unroll
+      for (int step = 0; step < 10; ++step) {
+        const int mid = (lo + hi) >> 1;
+        if (mid < kWords && wpre[mid] <= o) lo = mid; else hi = mid;
+      }
+      // (the LAST word with prefix <= o is the one that holds position o: empty words with the same
+      // prefix lie before it, every later word has a larger prefix)
+      const uint32_t word = bits[lo];
+      int k = o - wpre[lo];
+      int bit = 0;
+#pragma unroll
+      for (int sft = 16; sft >= 1; sft >>= 1) {
+        const int c = __popc((word >> bit) & ((1u << sft) - 1u));
+        if (k >= c) {
+          k -= c;
+          bit += sft;
+        }
+      }
+      const int idx = lo * 32 + bit;
+      colC[out0 + o] = col0 + idx;
+      if (valC != nullptr) {
+        valC[out0 + o] = Traits<T>::from_acc(acc[idx]);
+        acc[idx] = A(0);
+      }
+    }
+    __syncthreads();
+    if (wd) bits[tid] = 0;
   }
 }
 
 struct LargeWs {
-  int64_t *lp, *erow, *ecol, *row_s, *col_s, *perm, *row_u, *col_u, *seg, *nuniq;
-  void *eval, *sort_ws, *coal_ws, *scan_ws;
-  size_t sort_bytes, coal_bytes;
+  int64_t *hist;      // [n_large * nr + 1] products per bin, scanned in place -> bin offsets
+  int64_t *bin_cnt;   // [n_large * nr + 1] distinct columns per bin, scanned at numeric time
+  uint32_t *bcol;     // [P_large] column inside its range
+  void *bval;         // [P_large] value (numeric stage)
+  unsigned long long *queue;  // ticket counters of the persistent kernels
+  void *scan_ws;
+  int nr, lg_range;
+  int64_t ntask;
 };
 
-// erow / ecol are only needed until the sort has run; eval (numeric stage) reuses their space.
-size_t carve_large(void *base, int64_t n_large, int64_t P_large, LargeWs *w) {
+// One layout for both value types of a call sequence: the range is the one of the value type.
+size_t carve_large(void *base, int64_t n_large, int64_t P_large, int64_t N, size_t esize, LargeWs *w) {
   char *p = reinterpret_cast<char *>(base);
   size_t off = 0;
   auto take = [&](size_t bytes) -> void * {
@@ -700,53 +847,53 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, LargeWs *w) {
     return r;
   };
   LargeWs l;
-  const size_t P = (size_t)P_large;
-  l.lp = (int64_t *)take(8 * (size_t)(n_large + 1));
-  l.erow = (int64_t *)take(8 * P);
-  l.ecol = (int64_t *)take(8 * P);
-  l.eval = l.erow;  // fp32 / fp64 values of the numeric stage (<= 8 bytes each)
-  l.row_s = (int64_t *)take(8 * P);
-  l.col_s = (int64_t *)take(8 * P);
-  l.perm = (int64_t *)take(8 * P);
-  l.row_u = (int64_t *)take(8 * P);
-  l.col_u = (int64_t *)take(8 * P);
-  l.seg = (int64_t *)take(8 * (P + 1));
-  l.nuniq = (int64_t *)take(8);
-  l.sort_bytes = tsamd_sort_coo_workspace_bytes(P_large);
-  l.sort_ws = take(l.sort_bytes);
-  l.coal_bytes = tsamd_coalesce_workspace_bytes(P_large);
-  l.coal_ws = take(l.coal_bytes);
-  l.scan_ws = take(scan_workspace_bytes(n_large));
+  l.lg_range = esize == 8 ? 14 : 15;
+  l.nr = (int)((N + ((int64_t)1 << l.lg_range) - 1) >> l.lg_range);
+  if (l.nr < 1) l.nr = 1;
+  l.ntask = n_large * (int64_t)l.nr;
+  l.hist = (int64_t *)take(8 * (size_t)(l.ntask + 1));
+  l.bin_cnt = (int64_t *)take(8 * (size_t)(l.ntask + 1));
+  l.bcol = (uint32_t *)take(4 * (size_t)P_large);
+  l.bval = take(esize * (size_t)P_large);
+  l.queue = (unsigned long long *)take(64);
+  l.scan_ws = take(scan_workspace_bytes(l.ntask + 1));
   if (w) *w = l;
   return off;
 }
 
-// symbolic stage of the large rows: the sorted unique (row, col) pattern and the permutation
-// that groups the expanded products stay in the workspace for the numeric stage
+unsigned int persistent_blocks() {
+  static int cus = 0;  // the LDS footprint allows one workgroup per CU
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  return (unsigned int)cus;
+}
+
 int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
-                   const int64_t *colB, const int64_t *prod, const int64_t *rows, int64_t n_large,
-                   int64_t P_large, int64_t M, int64_t N, int64_t *nnzC, void *workspace,
-                   hipStream_t stream) {
+                   const int64_t *colB, const int64_t *rows, int64_t n_large, int64_t P_large, int64_t N,
+                   size_t esize, int64_t *nnzC, void *workspace, hipStream_t stream) {
   LargeWs w;
-  carve_large(workspace, n_large, P_large, &w);
-  hipLaunchKernelGGL(gather_prod_kernel, dim3((unsigned int)ceil_div(n_large, 256)), dim3(256), 0,
-                     stream, rows, prod, n_large, w.lp);
+  carve_large(workspace, n_large, P_large, N, esize, &w);
+  if (w.nr > kMaxRanges) return TSAMD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(spspmm_large_hist_kernel, dim3((unsigned int)n_large), dim3(kLargeThreads), 0, stream,
+                     rowptrA, colA, rowptrB, colB, rows, w.lg_range, w.nr, w.hist);
   TSAMD_LAUNCH_CHECK();
-  int st = exclusive_scan_i64(w.lp, w.lp, n_large, nullptr, w.scan_ws, stream);
+  TSAMD_HIP_TRY(hipMemsetAsync(w.hist + w.ntask, 0, 8, stream));
+  int st = exclusive_scan_i64(w.hist, w.hist, w.ntask + 1, nullptr, w.scan_ws, stream);
   if (st != TSAMD_OK) return st;
-  hipLaunchKernelGGL((spspmm_expand_large_kernel<float>), dim3((unsigned int)n_large), dim3(256), 0,
-                     stream, rowptrA, colA, (const float *)nullptr, rowptrB, colB,
-                     (const float *)nullptr, rows, (const int64_t *)w.lp, w.erow, w.ecol,
-                     (float *)nullptr);
+  hipLaunchKernelGGL((spspmm_large_bin_kernel<float, false>), dim3((unsigned int)n_large), dim3(kLargeThreads),
+                     0, stream, rowptrA, colA, (const float *)nullptr, rowptrB, colB, (const float *)nullptr,
+                     rows, w.lg_range, w.nr, (const int64_t *)w.hist, w.bcol, (float *)nullptr);
   TSAMD_LAUNCH_CHECK();
-  st = tsamd_sort_coo(w.erow, w.ecol, P_large, M, N, w.row_s, w.col_s, w.perm, w.sort_ws,
-                      w.sort_bytes, stream);
-  if (st != TSAMD_OK) return st;
-  st = tsamd_coalesce_index(w.row_s, w.col_s, P_large, w.row_u, w.col_u, w.seg, w.nuniq, w.coal_ws,
-                            w.coal_bytes, stream);
-  if (st != TSAMD_OK) return st;
-  hipLaunchKernelGGL(spspmm_count_large_kernel, dim3((unsigned int)ceil_div(P_large, 256)), dim3(256),
-                     0, stream, (const int64_t *)w.row_u, (const int64_t *)w.nuniq, nnzC, P_large);
+  TSAMD_HIP_TRY(hipMemsetAsync(w.queue, 0, 64, stream));
+  hipLaunchKernelGGL(spspmm_large_count_kernel, dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream, rows,
+                     w.nr, w.ntask, (const int64_t *)w.hist, (const uint32_t *)w.bcol, (1 << w.lg_range) / 32,
+                     w.bin_cnt, reinterpret_cast<unsigned long long *>(nnzC), w.queue);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }
@@ -754,22 +901,26 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *r
 template <typename T>
 int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
                   const int64_t *colB, const void *valB, const int64_t *rows, int64_t n_large,
-                  int64_t P_large, const int64_t *rowptrC, int64_t *colC, void *valC, void *workspace,
-                  hipStream_t stream) {
+                  int64_t P_large, int64_t N, const int64_t *rowptrC, int64_t *colC, void *valC,
+                  void *workspace, hipStream_t stream) {
   LargeWs w;
-  carve_large(workspace, n_large, P_large, &w);
-  T *ev = valC ? reinterpret_cast<T *>(w.eval) : nullptr;
-  if (ev != nullptr) {
-    hipLaunchKernelGGL((spspmm_expand_large_kernel<T>), dim3((unsigned int)n_large), dim3(256), 0,
+  carve_large(workspace, n_large, P_large, N, sizeof(T), &w);
+  if (w.nr > kMaxRanges) return TSAMD_ERR_UNSUPPORTED;
+  T *bv = reinterpret_cast<T *>(w.bval);
+  if (valC != nullptr) {  // the symbolic stage binned the columns; the values follow the same offsets
+    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
                        stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
-                       reinterpret_cast<const T *>(valB), rows, (const int64_t *)w.lp,
-                       (int64_t *)nullptr, (int64_t *)nullptr, ev);
+                       reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, (const int64_t *)w.hist,
+                       w.bcol, bv);
     TSAMD_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL((spspmm_scatter_large_kernel<T>), dim3((unsigned int)ceil_div(P_large, 256)),
-                     dim3(256), 0, stream, (const int64_t *)w.row_u, (const int64_t *)w.col_u,
-                     (const int64_t *)w.seg, (const int64_t *)w.perm, (const T *)ev,
-                     (const int64_t *)w.nuniq, rowptrC, colC, reinterpret_cast<T *>(valC), P_large);
+  TSAMD_HIP_TRY(hipMemsetAsync(w.bin_cnt + w.ntask, 0, 8, stream));
+  int st = exclusive_scan_i64(w.bin_cnt, w.bin_cnt, w.ntask + 1, nullptr, w.scan_ws, stream);
+  if (st != TSAMD_OK) return st;
+  TSAMD_HIP_TRY(hipMemsetAsync(w.queue, 0, 64, stream));
+  hipLaunchKernelGGL((spspmm_large_accum_kernel<T>), dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream,
+                     rows, w.nr, w.ntask, (const int64_t *)w.hist, (const uint32_t *)w.bcol, (const T *)bv,
+                     (const int64_t *)w.bin_cnt, rowptrC, colC, reinterpret_cast<T *>(valC), w.queue);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }
@@ -836,12 +987,12 @@ extern "C" int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA,
   return TSAMD_OK;
 }
 
-extern "C" size_t tsamd_spspmm_workspace_bytes(int64_t n_large, int64_t P_large) {
+extern "C" size_t tsamd_spspmm_workspace_bytes(int dtype, int64_t n_large, int64_t P_large, int64_t N) {
   if (n_large <= 0) return 0;
-  return carve_large(nullptr, n_large, P_large, nullptr);
+  return carve_large(nullptr, n_large, P_large, N, dtype == TSAMD_F64 ? 8 : 4, nullptr);
 }
 
-extern "C" int tsamd_spspmm_symbolic(const int64_t *rowptrA, const int64_t *colA,
+extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const int64_t *colA,
                                      const int64_t *rowptrB, const int64_t *colB, int64_t M,
                                      int64_t N, const int64_t *prod, const int64_t *bins,
                                      int64_t n_medium, int64_t n_large, int64_t P_large,
@@ -852,7 +1003,8 @@ extern "C" int tsamd_spspmm_symbolic(const int64_t *rowptrA, const int64_t *colA
   if (M == 0) return TSAMD_OK;
   if (!nnzC || !rowptrA || !colA || !rowptrB || !colB || !prod || !bins) return TSAMD_ERR_INVALID;
   if (n_medium < 0 || n_large < 0 || n_medium + n_large > M) return TSAMD_ERR_INVALID;
-  if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(n_large, P_large)))
+  if (dtype != TSAMD_F32 && dtype != TSAMD_F64) return TSAMD_ERR_UNSUPPORTED;
+  if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(dtype, n_large, P_large, N)))
     return TSAMD_ERR_WORKSPACE;
   TSAMD_HIP_TRY(hipMemsetAsync(nnzC, 0, sizeof(int64_t) * (size_t)M, stream));
   hipLaunchKernelGGL((spspmm_symbolic_kernel<64, 10>), dim3((unsigned int)M), dim3(64), 0, stream, rowptrA,
@@ -864,8 +1016,8 @@ extern "C" int tsamd_spspmm_symbolic(const int64_t *rowptrA, const int64_t *colA
     TSAMD_LAUNCH_CHECK();
   }
   if (n_large > 0)
-    return symbolic_large(rowptrA, colA, rowptrB, colB, prod, bins + M, n_large, P_large, M, N, nnzC,
-                          workspace, stream);
+    return symbolic_large(rowptrA, colA, rowptrB, colB, bins + M, n_large, P_large, N,
+                          dtype == TSAMD_F64 ? 8 : 4, nnzC, workspace, stream);
   return TSAMD_OK;
 }
 
@@ -882,7 +1034,7 @@ extern "C" int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int
   if (M == 0) return TSAMD_OK;
   if (!rowptrA || !colA || !rowptrB || !colB || !prod || !bins || !rowptrC) return TSAMD_ERR_INVALID;
   if (n_medium < 0 || n_large < 0 || n_medium + n_large > M) return TSAMD_ERR_INVALID;
-  if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(n_large, P_large)))
+  if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(dtype, n_large, P_large, N)))
     return TSAMD_ERR_WORKSPACE;
   int st;
   if (dtype == TSAMD_F32)
@@ -893,8 +1045,8 @@ extern "C" int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int
                               colC, valC, stream);
   if (st != TSAMD_OK || n_large == 0) return st;
   if (dtype == TSAMD_F32)
-    return numeric_large<float>(rowptrA, colA, valA, rowptrB, colB, valB, bins + M, n_large, P_large,
+    return numeric_large<float>(rowptrA, colA, valA, rowptrB, colB, valB, bins + M, n_large, P_large, N,
                                 rowptrC, colC, valC, workspace, stream);
-  return numeric_large<double>(rowptrA, colA, valA, rowptrB, colB, valB, bins + M, n_large, P_large,
+  return numeric_large<double>(rowptrA, colA, valA, rowptrB, colB, valB, bins + M, n_large, P_large, N,
                                rowptrC, colC, valC, workspace, stream);
 }

@@ -604,7 +604,7 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   const int64_t *hs = h.data_ptr<int64_t>();
   const int64_t n_medium = hs[2], n_large = hs[3], P_large = hs[4];
 
-  const size_t ws_bytes = tsamd_spspmm_workspace_bytes(n_large, P_large);
+  const size_t ws_bytes = tsamd_spspmm_workspace_bytes(dt, n_large, P_large, N);
   if (n_large > 0) {  // data dependent scratch: refuse politely instead of an allocator OOM
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
@@ -614,7 +614,7 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   }
   Tensor ws1 = workspace(ws_bytes, rowptrA);
   Tensor rowptrC = torch::zeros({M + 1}, iopt);  // nnzC in [0, M), scanned in place below
-  check_status(tsamd_spspmm_symbolic(rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
+  check_status(tsamd_spspmm_symbolic(dt, rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
                                      rowptrB.data_ptr<int64_t>(), colB.data_ptr<int64_t>(), M, N,
                                      prod.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_medium,
                                      n_large, P_large, rowptrC.data_ptr<int64_t>(),
