@@ -128,7 +128,8 @@ def secondary(dev, cpu=True):
     from tests import baseline_configs as bc
     res = []
     for fn in (lambda: bc.run_c2(dev, cpu=cpu), lambda: bc.run_c3(dev, False, cpu=cpu),
-               lambda: bc.run_c3(dev, True, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu)):
+               lambda: bc.run_c3(dev, True, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu),
+               lambda: bc.run_spspmm(dev, 'stress', cpu=False, iters=2)):  # SURVEY 8d stress row: property checks
         try:
             res.append(fn())
         except Exception as exc:  # a failing secondary must not take the headline down

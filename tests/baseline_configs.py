@@ -266,6 +266,46 @@ def spspmm_inputs(dev, kind='c4'):
     return A, A.t()
 
 
+def spspmm_properties(A, B, C, sample_rows=48):
+    """Size-independent checks of C = A * B where the host SpGEMM would take minutes (the R-MAT stress
+    product): structure (rows sorted by column, no duplicates), the two checksums
+        sum_j C_ij = sum_k A_ik (sum_j B_kj)      and      sum_ij C_ij = sum_k (sum_i A_ik)(sum_j B_kj)
+    evaluated with ATen in fp64 (independent of the kernels under test), and `sample_rows` random rows
+    (plus the longest one) compared exactly with torch.sparse.mm on the host (the reference's call)."""
+    rowA, colA, valA = A.coo()
+    rowB, colB, valB = B.coo()
+    row, col, val = C.coo()
+    m = A.sparse_size(0)
+    dev = row.device
+    same_row = row[1:] == row[:-1]
+    sorted_unique = bool(((col[1:] > col[:-1]) | ~same_row).all())
+    b_rowsum = torch.zeros(B.sparse_size(0), dtype=torch.float64, device=dev).index_add_(0, rowB, valB.double())
+    want_rows = torch.zeros(m, dtype=torch.float64, device=dev).index_add_(0, rowA, valA.double() * b_rowsum[colA])
+    l1_rows = torch.zeros(m, dtype=torch.float64, device=dev).index_add_(0, rowA, valA.double().abs() * torch.zeros_like(
+        b_rowsum).index_add_(0, rowB, valB.double().abs())[colA])
+    got_rows = torch.zeros(m, dtype=torch.float64, device=dev).index_add_(0, row, val.double())
+    row_err = float(((got_rows - want_rows).abs() / l1_rows.clamp(min=1e-30)).max())
+    total_err = float(abs(got_rows.sum() - want_rows.sum()) / l1_rows.sum())
+    # sampled rows, exactly
+    rp = C.storage.rowptr()
+    deg = rp[1:] - rp[:-1]
+    g = torch.Generator().manual_seed(0)
+    pick = torch.cat([torch.randint(0, m, (sample_rows, ), generator=g), deg.argmax().cpu().view(1)]).unique()
+    Asub = A.index_select(0, pick.to(dev))
+    ref = torch.sparse.mm(Asub.cpu().to_torch_sparse_coo_tensor(), B.cpu().to_torch_sparse_coo_tensor()).coalesce()
+    Csub = C.index_select(0, pick.to(dev))
+    r2, c2, v2 = Csub.coo()
+    idx_ok = torch.equal(torch.stack([r2, c2]).cpu(), ref._indices())
+    l1s = (Asub.set_value(Asub.storage.value().abs(), 'coo') @ B.set_value(valB.abs(), 'coo')).storage.value()
+    verr = float(((v2.cpu().double() - ref._values().double()).abs() / l1s.cpu().double().clamp(min=1e-30)).max()) \
+        if idx_ok else float('inf')
+    ok = sorted_unique and row_err <= 1e-5 and total_err <= 1e-6 and idx_ok and verr <= 1e-5
+    return dict(against='structure + fp64 ATen checksums (all rows) + torch.sparse.mm on %d sampled rows' % pick.numel(),
+                nnz=int(col.numel()), rows_sorted_unique=sorted_unique, row_sum_max_err_over_l1=row_err,
+                total_sum_rel_err=total_err, sampled_rows_index_bit_exact=bool(idx_ok),
+                sampled_rows_value_max_err_over_l1=verr, ok=bool(ok))
+
+
 def run_spspmm(dev, kind='c4', cpu=True, iters=5):
     A, At = spspmm_inputs(dev, kind)
     rpB = At.storage.rowptr()
@@ -282,6 +322,8 @@ def run_spspmm(dev, kind='c4', cpu=True, iters=5):
                roofline=dict(bound='hbm', algorithmic_bytes=comp, achieved=round(comp / ms / 1e6, 1),
                              peak=HBM_PEAK_GBS, unit='GB/s', frac=round(comp / ms / 1e6 / HBM_PEAK_GBS, 4),
                              scope='whole op incl. its host syncs; bytes = compulsory (SURVEY 8d)'))
+    if not cpu and kind != 'c4':
+        res['parity'] = spspmm_properties(A, At, C)
     if cpu:
         Ac, Bc = A.cpu().to_torch_sparse_coo_tensor(), At.cpu().to_torch_sparse_coo_tensor()
         cores = os.cpu_count() or 1

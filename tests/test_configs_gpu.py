@@ -46,3 +46,14 @@ def test_c4_spspmm_full_size(dev, ops):
     p = r['parity']
     assert p['index_bit_exact'], p
     assert p['value_max_err_over_l1'] <= 1e-5, p
+
+
+def test_spspmm_rmat_stress_row(dev, ops):
+    """SURVEY 8d stress row: A * A^T of an R-MAT scale-19 graph (2.3 G products, hub rows of 10^7 products go
+    through the binned dense accumulation).  torch.sparse.mm on the host would take minutes, so: structure,
+    fp64 checksums of every row, and 49 rows (incl. the longest) compared exactly with torch.sparse.mm."""
+    r = bc.run_spspmm(dev, 'stress', cpu=False, iters=1)
+    p = r['parity']
+    assert p['rows_sorted_unique'] and p['sampled_rows_index_bit_exact'], p
+    assert p['row_sum_max_err_over_l1'] <= 1e-5 and p['sampled_rows_value_max_err_over_l1'] <= 1e-5, p
+    assert p['ok']
