@@ -447,7 +447,10 @@ static bool minmax_bw_shadow(int dtype) {
 extern "C" size_t tsamd_spmm_minmax_bw_workspace_bytes(int dtype, int64_t B, int64_t N, int64_t K,
                                                        int64_t E) {
   (void)E;
-  if (minmax_bw_shadow(dtype)) return align_up(sizeof(float) * (size_t)(B * N * K), 256);
+  const bool narrow = dtype == TSAMD_F16 || dtype == TSAMD_BF16;
+  // packed atomics need whole 4-byte words inside the buffer: an odd element count takes the shadow
+  if (minmax_bw_shadow(dtype) || (narrow && ((B * N * K) % 2) != 0))
+    return align_up(sizeof(float) * (size_t)(B * N * K), 256);
   return 0;
 }
 

@@ -1001,7 +1001,8 @@ extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const in
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || N < 0 || N >= ((int64_t)1 << 32) - 1 || M >= ((int64_t)1 << 31)) return TSAMD_ERR_UNSUPPORTED;
   if (M == 0) return TSAMD_OK;
-  if (!nnzC || !rowptrA || !colA || !rowptrB || !colB || !prod || !bins) return TSAMD_ERR_INVALID;
+  // colA / colB may be NULL for operands without entries (every row then has zero products)
+  if (!nnzC || !rowptrA || !rowptrB || !prod || !bins) return TSAMD_ERR_INVALID;
   if (n_medium < 0 || n_large < 0 || n_medium + n_large > M) return TSAMD_ERR_INVALID;
   if (dtype != TSAMD_F32 && dtype != TSAMD_F64) return TSAMD_ERR_UNSUPPORTED;
   if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(dtype, n_large, P_large, N)))
@@ -1032,7 +1033,7 @@ extern "C" int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int
   if (dtype != TSAMD_F32 && dtype != TSAMD_F64) return TSAMD_ERR_UNSUPPORTED;
   if (M < 0 || N < 0 || N >= ((int64_t)1 << 32) - 1 || M >= ((int64_t)1 << 31)) return TSAMD_ERR_UNSUPPORTED;
   if (M == 0) return TSAMD_OK;
-  if (!rowptrA || !colA || !rowptrB || !colB || !prod || !bins || !rowptrC) return TSAMD_ERR_INVALID;
+  if (!rowptrA || !rowptrB || !prod || !bins || !rowptrC) return TSAMD_ERR_INVALID;
   if (n_medium < 0 || n_large < 0 || n_medium + n_large > M) return TSAMD_ERR_INVALID;
   if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(dtype, n_large, P_large, N)))
     return TSAMD_ERR_WORKSPACE;

@@ -173,7 +173,8 @@ def minmax_bw_bound(col, value, grad_out, arg, n, dtype):
     cnt = z().scatter_add_(0, ind, (~invalid).double())
     u = {torch.float32: 2.0 ** -24, torch.float64: 2.0 ** -53, torch.float16: 2.0 ** -11,
          torch.bfloat16: 2.0 ** -8}[dtype]
-    return exact, (cnt + 1) * u * l1 * 1.01 + 1e-30
+    floor = 2.0 ** -25 if dtype == torch.float16 else 1e-40  # half a subnormal step per addition
+    return exact, (cnt + 1) * (u * l1 * 1.01 + floor)
 
 
 def run_c3(dev, has_value, cpu=True, iters=10):
