@@ -620,7 +620,6 @@ __global__ __launch_bounds__(BLOCK) void spspmm_numeric_pairs_kernel(
 // (an entry exists when its bit is set).  The sums of such a row are formed in atomic order: unlike the
 // small / medium rows they are not bit-reproducible from run to run (fp32 rounding order).
 // ---------------------------------------------------------------------------
-constexpr int kRangeBytes = 128 * 1024;  // LDS accumulators of one range
 constexpr int kLargeThreads = 256;   // hist / bin kernels: one workgroup per large row
 constexpr int kAccumThreads = 1024;  // count / accum kernels: ONE workgroup per CU (LDS), so make it a big one
 constexpr int kBinBatch = 4;         // bin entries fetched per thread before they are consumed
