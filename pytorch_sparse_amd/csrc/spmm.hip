@@ -375,7 +375,9 @@ __device__ __forceinline__ void write_carry(void *cval, int64_t *carg, uint64_t 
 // 2. main kernel: wave p consumes merge-path items [table[p], table[p+1])
 //    grid = (ceil(P / waves per block), B * ktiles)
 // ---------------------------------------------------------------------------
-template <typename T, int VEC, int RED>
+// SHORT: instantiate the "short rows side by side" path (launched for rows of <= 128 bytes only: its
+// registers would cost the wide-row instantiation two waves per SIMD)
+template <typename T, int VEC, int RED, bool SHORT>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
     const T *__restrict__ value, const T *__restrict__ mat, T *__restrict__ out,
@@ -463,8 +465,119 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
   int64_t r = r0;
   int64_t estart = e0;  // first edge of the current row that belongs to this partition
   int64_t trow = -1;
-  // rows (or row pieces) inside the window [wbase, wbase + 64); true when the partition is done
-  auto process_window = [&](const uint32_t c_w, const A w_w) __attribute__((always_inline)) -> bool {
+  // ---- short rows side by side (narrow feature matrices) ------------------------------------
+  // With G >= 8 lane groups (rows of <= 128 bytes) a row of ~20 entries fills one partly used batch
+  // of gathers, and the wave pays one global-memory round trip per ROW (measured: F = 4 / 8 / 16 all
+  // take ~0.75 ms on the north-star graph).  When the next rows are all short, up to G of them are
+  // therefore processed at once, one row per lane group: the group's lanes fetch lpr consecutive
+  // entries of their row (prefetched one step ahead), every lane of the group consumes them, and
+  // each group writes its own row -- no reduction across groups, ~len / lpr round trips for G rows.
+  // Rows longer than kShortFactor * lpr entries, the row that was started by an earlier partition
+  // and the unfinished last row keep the cooperative path below.
+  constexpr int kShortFactor = 8;
+  auto short_rows = [&]() __attribute__((always_inline)) -> bool {
+    if constexpr (!SHORT) return false;
+    if (lgG < 3 || r >= r1) return false;
+    int j = (int)(r - rp_base);
+    if (j >= kWave) {
+      rp_base = r;
+      rp_l = load_rowends(rp_base);
+      j = 0;
+    }
+    const int G = 1 << lgG;
+    int navail = (int)(r1 - r < (int64_t)G ? r1 - r : (int64_t)G);
+    if (navail > kWave - j) navail = kWave - j;
+    if (navail < 2) return false;
+    const uint32_t rel_l = (uint32_t)(uint64_t)(rp_l - e0);  // row ends relative to e0 (rows < r1: < 2^31)
+    const uint32_t end_g = lane_read(rel_l, j + (g < navail ? g : navail - 1));
+    const uint32_t prev_g = lane_read(rel_l, j + (g > 0 ? (g <= navail ? g - 1 : navail - 1) : 0));
+    const uint32_t beg_g = g == 0 ? (uint32_t)(e - e0) : prev_g;
+    bool mine = g < navail;
+    const uint32_t len = mine ? end_g - beg_g : 0u;
+    const unsigned long long too_long = __ballot(mine && len > (uint32_t)(kShortFactor * lpr));
+    const int n = too_long ? (int)(__builtin_ctzll(too_long) >> (6 - lgG)) : navail;
+    if (n < 2) return false;
+    mine = g < n;
+    const uint32_t stop_g = mine ? end_g : beg_g;
+    const int grp0 = lane & ~(lpr - 1);
+    auto fetch = [&](uint32_t q, uint32_t &c_l, A &w_l) {
+      c_l = 0;
+      w_l = A(1);
+      if (q < stop_g) {
+        c_l = (uint32_t)col[e0 + q];
+        if (relabel) c_l = hash_row(c_l, (uint32_t)N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
+        if (value != nullptr) w_l = Traits<T>::to_acc(value[e0 + q]);
+      }
+    };
+    uint32_t pos = beg_g;
+    uint32_t c_l, c_n;
+    A w_l, w_n;
+    fetch(pos + (uint32_t)kl, c_l, w_l);
+    while (__any(pos < stop_g)) {
+      fetch(pos + (uint32_t)lpr + (uint32_t)kl, c_n, w_n);  // the next step's entries are on their way
+#pragma unroll
+      for (int u0 = 0; u0 < 8; u0 += 4) {
+        if (u0 >= lpr) break;  // wave-uniform
+        Pack<T, VEC> x[4];
+        A w[4];
+        bool ok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int u = u0 + t;
+          const int srcl = grp0 + (u < lpr ? u : 0);
+          const uint32_t c = lane_read(c_l, srcl);
+          w[t] = lane_read(w_l, srcl);
+          ok[t] = u < lpr && pos + (uint32_t)u < stop_g;
+          x[t] = *reinterpret_cast<const Pack<T, VEC> *>(matk + (uint64_t)(ok[t] ? c : 0u) * K);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+          for (int jj = 0; jj < VEC; ++jj) {
+            const A xv = Traits<T>::to_acc(x[t].v[jj]);
+            if constexpr (RED == RED_ADD) {
+              const A pr = w[t] * xv;
+              val[jj] += ok[t] ? pr : A(0);
+            } else {
+              const A pr = has_value ? Traits<T>::round_acc(w[t] * xv) : xv;
+              const bool better = ok[t] && (RED == RED_MIN ? (pr < val[jj]) : (pr > val[jj]));
+              val[jj] = better ? pr : val[jj];
+              arg[jj] = better ? pos + (uint32_t)(u0 + t) : arg[jj];
+            }
+          }
+        }
+      }
+      pos += (uint32_t)lpr;
+      c_l = c_n;
+      w_l = w_n;
+    }
+    if (mine && kok) {
+      if constexpr (RED != RED_ADD) widen_args();
+      const uint64_t o = out_b + out_position(ws, r + g, M) * K;
+      write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, (int64_t)len, mean, E);
+    }
+    init_acc<T, VEC, RED>(val, arg);
+    const uint32_t done_rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, j + n - 1);
+    r += n;
+    e = e0 + (int64_t)done_rel;
+    estart = e;
+    return true;
+  };
+  // as many batches of short rows as there are; then the cooperative path continues behind them:
+  // refill both window register sets
+  auto short_row_batches = [&]() __attribute__((always_inline)) -> bool {
+    if (!short_rows()) return false;
+    while (short_rows()) {
+    }
+    wbase = e;
+    load_window(wbase, c_cur, w_cur);
+    load_window(wbase + kWave, c_nxt, w_nxt);
+    return true;
+  };
+
+  // rows (or row pieces) inside the window [wbase, wbase + 64): 0 = window exhausted, 1 = partition done,
+  // 2 = a batch of short rows was processed side by side and the windows were re-based (start over)
+  auto process_window = [&](const uint32_t c_w, const A w_w) __attribute__((always_inline)) -> int {
     const int64_t wend_raw = wbase + kWave;
     const int64_t wend = wend_raw < e1 ? wend_raw : e1;
     for (;;) {
@@ -487,8 +600,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
                                        c_w, w_w, has_value, matk, K, lgG, g, val, arg);
         e = stop;
       }
-      if (e < rend) return false;  // window exhausted inside the row
-      if (tail) return true;
+      if (e < rend) return 0;  // window exhausted inside the row
+      if (tail) return 1;
       // row r ends here
       if (estart < rend) reduce_groups<A, VEC, RED>(lgG, val, arg);
       if (writer) {
@@ -503,13 +616,19 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
       init_acc<T, VEC, RED>(val, arg);
       ++r;
       estart = e;
+      if (short_row_batches()) return 2;
     }
   };
+  if (!incoming) short_row_batches();  // the partition starts at a row start
   for (;;) {
-    if (process_window(c_cur, w_cur)) break;
+    int st = process_window(c_cur, w_cur);
+    if (st == 1) break;
+    if (st == 2) continue;
     load_window(wbase + 2 * kWave, c_cur, w_cur);
     wbase += kWave;
-    if (process_window(c_nxt, w_nxt)) break;
+    st = process_window(c_nxt, w_nxt);
+    if (st == 1) break;
+    if (st == 2) continue;
     load_window(wbase + 2 * kWave, c_nxt, w_nxt);
     wbase += kWave;
   }
@@ -625,9 +744,16 @@ int ilog2_ceil(uint32_t x) {
 // fp32, every f16/bf16 width up to 256: more, shorter waves fill the machine better and the tail is
 // shorter), 1024 items beat 256 by 4-8 % for rows of 1 KB and more (F = 256/512 fp32: every partition
 // pays a K-wide carry record and a fix-up).  TSAMD_ITEMS_MAX caps both.
+constexpr int64_t kShortRowItems = 1024;
+
 void plan_partition(int64_t M, int64_t E, int64_t row_bytes, int64_t *P, int64_t *items) {
   const int64_t total = M + E > 0 ? M + E : 1;
   int64_t cap = row_bytes <= 512 ? 256 : (row_bytes < 1024 ? 512 : 1024);
+  if (row_bytes <= 128) cap = kShortRowItems;  // side-by-side short rows: long partitions amortise the batches
+  if (const char *env = getenv("TSAMD_SPMM_ITEMS")) {  // experiments
+    const long v = atol(env);
+    if (v >= 64 && v <= 4096) cap = v;
+  }
   if (cap > TSAMD_ITEMS_MAX) cap = TSAMD_ITEMS_MAX;
   int64_t it = ceil_div(total, (int64_t)TSAMD_TARGET_WAVES);
   if (it < TSAMD_ITEMS_MIN) it = TSAMD_ITEMS_MIN;
@@ -737,9 +863,14 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   TSAMD_LAUNCH_CHECK();
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[1], stream));
   const unsigned int gx = (unsigned int)ceil_div(ws.P, kWavesPerBlock);
-  hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED>), dim3(gx, (unsigned int)(B * ktiles), 1),
-                     dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N,
-                     (uint32_t)K, E, ktiles, lgG, mean, ws);
+  if (lgG >= 3)
+    hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                       dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N,
+                       (uint32_t)K, E, ktiles, lgG, mean, ws);
+  else
+    hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, false>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                       dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N,
+                       (uint32_t)K, E, ktiles, lgG, mean, ws);
   TSAMD_LAUNCH_CHECK();
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[2], stream));
   if (ws.P > 1) {

@@ -69,7 +69,7 @@ if 'coalesce' in which:
     t_tr = wall(lambda: ts.transpose(index, val, m, n))
     A = ts.SparseTensor(row=row, col=col, value=val, sparse_sizes=(m, n))
     def tt():
-        A.storage._cache['csr2csc'] = None; A.storage._cache['colptr'] = None; A.storage._cache['csc2csr'] = None
+        A.storage._csr2csc = None; A.storage._colptr = None; A.storage._csc2csr = None
         return A.t()
     t_t = wall(tt)
     key = row * n + col
