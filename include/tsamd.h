@@ -90,6 +90,17 @@ int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
                int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
                void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same product with the entries of the CSR taken through a permutation: entry e is
+ * (col[perm[e]], value[perm[e]]), perm [E] int64.  With (rowptr, col, perm) = (colptr, row, csr2csc)
+ * this multiplies by the TRANSPOSE of a matrix straight from its COO/CSR arrays -- the
+ * grad_mat = A^T * grad_out of SPMMSum::backward (csrc/spmm.cpp:100-108), where the reference first
+ * materialises row.index_select(0, csr2csc) and value.index_select(0, csr2csc).  arg_out (MIN/MAX)
+ * holds positions in the permuted order (e, not perm[e]).  Workspace: tsamd_spmm_workspace_bytes. */
+int tsamd_spmm_permuted(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
+                        const void *value, const int64_t *perm, const void *mat, void *out,
+                        int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* Measurement aid (bench.py): same as tsamd_spmm, but brackets the three
  * kernels of the launch sequence (merge-path partition, merge, carry fix-up)
  * with hipEvents on `stream`, waits for the last one and writes their

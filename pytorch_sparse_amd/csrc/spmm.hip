@@ -91,6 +91,9 @@ struct Workspace {
   // hash_row(m, M, ...), `col` already holds hashed ids and `mat` is already in hashed row order
   int out_relabel;
   uint32_t ohash_bits, ohash_shift;
+  // entries taken through a permutation (tsamd_spmm_permuted): entry e of the CSR is
+  // (col[perm[e]], value[perm[e]]) -- the CSC view of a matrix without materialising it
+  const int64_t *perm;
 };
 
 // ---------------------------------------------------------------------------
@@ -420,13 +423,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
     c_l = 0;
     w_l = A(1);
     if (e < e1) {
-#if defined(TSAMD_NT_LOAD)
-      c_l = (uint32_t)__builtin_nontemporal_load(col + e);
-#else
-      c_l = (uint32_t)col[e];
-#endif
+      const int64_t src_e = ws.perm != nullptr ? ws.perm[e] : e;  // windows are fetched two ahead:
+      c_l = (uint32_t)col[src_e];                                  // the indirection is off the critical path
       if (relabel) c_l = hash_row(c_l, (uint32_t)N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
-      if (value != nullptr) w_l = Traits<T>::to_acc(value[e]);
+      if (value != nullptr) w_l = Traits<T>::to_acc(value[src_e]);
     }
   };
   load_window(wbase, c_cur, w_cur);
@@ -504,9 +504,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
       c_l = 0;
       w_l = A(1);
       if (q < stop_g) {
-        c_l = (uint32_t)col[e0 + q];
+        const int64_t src_e = ws.perm != nullptr ? ws.perm[e0 + q] : e0 + (int64_t)q;
+        c_l = (uint32_t)col[src_e];
         if (relabel) c_l = hash_row(c_l, (uint32_t)N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
-        if (value != nullptr) w_l = Traits<T>::to_acc(value[e0 + q]);
+        if (value != nullptr) w_l = Traits<T>::to_acc(value[src_e]);
       }
     };
     uint32_t pos = beg_g;
@@ -816,6 +817,7 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.hash_mul = 0x9E3779B1u;  // odd (golden-ratio) multiplier
   w.hash_shift = w.hash_bits > 1 ? w.hash_bits / 2 : 1;
   w.out_relabel = 0;
+  w.perm = nullptr;
   w.ohash_bits = 1;
   while (w.ohash_bits < 32 && ((uint64_t)1 << w.ohash_bits) < (uint64_t)(M > 1 ? M : 2)) ++w.ohash_bits;
   w.ohash_shift = w.ohash_bits > 1 ? w.ohash_bits / 2 : 1;
@@ -939,7 +941,7 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
                       const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
                       int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
                       size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev,
-                      bool relabelled = false) {
+                      bool relabelled = false, const int64_t *perm = nullptr) {
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
@@ -958,6 +960,7 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
     if (M >= (int64_t)1 << 32) return TSAMD_ERR_UNSUPPORTED;
     ws.out_relabel = 1;
   }
+  ws.perm = perm;
   const size_t es = dtype_size(dtype);
   int vec = es <= 2 ? 4 : (int)(16 / es);  // widest packet for the type (see dispatch_spmm)
   while (vec > 1 && !((K % vec) == 0 && ((uintptr_t)mat % (vec * es)) == 0 &&
@@ -1087,6 +1090,16 @@ extern "C" int tsamd_spmm_relabelled(int dtype, int reduce, const int64_t *rowpt
                                      size_t workspace_bytes_given, void *stream_) {
   return spmm_entry(dtype, reduce, rowptr, col_h, value, mat_h, out_h, arg_out_h, B, M, N, K, E, workspace,
                     workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, true);
+}
+
+extern "C" int tsamd_spmm_permuted(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
+                                   const void *value, const int64_t *perm, const void *mat, void *out,
+                                   int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K,
+                                   int64_t E, void *workspace, size_t workspace_bytes_given,
+                                   void *stream_) {
+  if (E > 0 && !perm) return TSAMD_ERR_INVALID;
+  return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, workspace,
+                    workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, false, perm);
 }
 
 extern "C" int tsamd_spmm_profiled(int dtype, int reduce, const int64_t *rowptr,

@@ -86,7 +86,7 @@ int reduce_code(const std::string &r) {
 // Forward launch: mirrors the argument checks of spmm_cpu.cpp:12-24 / spmm_cuda.cu:96-109.
 std::tuple<Tensor, OptTensor> spmm_fw(const Tensor &rowptr, const Tensor &col,
                                       const OptTensor &opt_value, Tensor mat,
-                                      const std::string &reduce) {
+                                      const std::string &reduce, const OptTensor &opt_perm = std::nullopt) {
   check_gpu(rowptr, "rowptr");
   check_gpu(col, "col");
   if (opt_value.has_value()) check_gpu(opt_value.value(), "value");
@@ -122,6 +122,17 @@ std::tuple<Tensor, OptTensor> spmm_fw(const Tensor &rowptr, const Tensor &col,
   const int dt = dtype_code(mat);
   const size_t need = tsamd_spmm_workspace_bytes(dt, red, B, M, N, K, E);
   Tensor ws = workspace(need, mat);
+  if (opt_perm.has_value()) {  // entries through a permutation (the CSC view in the backward)
+    check_index(opt_perm.value(), "perm");
+    TORCH_CHECK(opt_perm.value().numel() == E, "Input mismatch");
+    Tensor perm = opt_perm.value().contiguous();
+    check_status(tsamd_spmm_permuted(dt, red, rp.data_ptr<int64_t>(), c.data_ptr<int64_t>(),
+                                     ptr_or_null(value), perm.data_ptr<int64_t>(), mat.data_ptr(),
+                                     out.data_ptr(), arg_ptr, B, M, N, K, E, ws.data_ptr(),
+                                     (size_t)ws.numel(), current_stream(mat)),
+                 "tsamd_spmm_permuted");
+    return std::make_tuple(out, arg_out);
+  }
   check_status(tsamd_spmm(dt, red, rp.data_ptr<int64_t>(), c.data_ptr<int64_t>(),
                           ptr_or_null(value), mat.data_ptr(), out.data_ptr(), arg_ptr, B, M, N, K,
                           E, ws.data_ptr(), (size_t)ws.numel(), current_stream(mat)),
@@ -193,16 +204,18 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
 
     if (needs_grad(mat)) {
       // grad_mat = A^T * grad_out: the CSC arrays are the CSR of A^T; per-edge weights are
-      // value (sum) or value / max(deg(row), 1) (mean), both permuted into CSC order.
-      Tensor row_t = row.index_select(0, csr2csc);
-      OptTensor w = std::nullopt;
-      if (mean) {
+      // value (sum) or value / max(deg(row), 1) (mean) in CSC order.
+      if (!mean) {
+        // sum: the kernel reads (row, value) THROUGH csr2csc -- no row.index_select(0, csr2csc) /
+        // value.index_select(0, csr2csc) temporaries as in the reference (spmm.cpp:104-106)
+        OptTensor w = has_value ? OptTensor(value.detach()) : std::nullopt;
+        grad_mat = std::get<0>(spmm_fw(colptr, row, w, grad_out, "sum", csr2csc));
+      } else {
+        Tensor row_t = row.index_select(0, csr2csc);
         Tensor cnt = rowcount.index_select(0, row_t).to(mat.scalar_type()).clamp_min_(1);
-        w = has_value ? value.detach().index_select(0, csr2csc).div_(cnt) : cnt.reciprocal_();
-      } else if (has_value) {
-        w = value.detach().index_select(0, csr2csc);
+        Tensor w = has_value ? value.detach().index_select(0, csr2csc).div_(cnt) : cnt.reciprocal_();
+        grad_mat = std::get<0>(spmm_fw(colptr, row_t, w, grad_out, "sum"));
       }
-      grad_mat = std::get<0>(spmm_fw(colptr, row_t, w, grad_out, "sum"));
     }
     return {Tensor(), Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_mat,
             Tensor(), Tensor()};
