@@ -386,3 +386,49 @@ def test_backward_kernels_full_size_exact(dev):
     ref_gmat = torch.zeros(n, K, dtype=torch.float64, device=dev).scatter_add_(0, ind, (v[a] * go).masked_fill(invalid, 0).double())
     assert torch.equal(gval.double(), ref_gval)
     assert torch.equal(gmat.double(), ref_gmat)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float64, torch.uint8])
+def test_gather_rows_matches_index_select(dev, dtype):
+    """tsamd_gather_rows (pack step of the sharded SpMM's row exchange): every packet width (16 / 8 / 4 / 2 / 1
+    bytes by pitch), duplicates, negative ids."""
+    import pytorch_sparse_amd  # noqa: F401
+    g = torch.Generator().manual_seed(2)
+    for n, k in ((1000, 128), (777, 6), (50, 3), (4096, 1), (300, 7), (10, 33)):
+        src = (torch.rand(n, k, generator=g) * 200).to(dtype).to(dev)
+        idx = torch.randint(-n, n, (2 * n + 3, ), generator=g).to(dev)
+        got = torch.ops.tsamd.gather_rows(src, idx)
+        assert bits_equal(got, src[idx])
+    assert torch.ops.tsamd.gather_rows(src, idx[:0]).shape == (0, 33)
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'max'])
+def test_spmm_permuted_equals_materialised_view(dev, reduce):
+    """tsamd_spmm_permuted(colptr, row, value, csr2csc) == tsamd_spmm on the materialised CSC arrays, bit for
+    bit (the entries are the same, in the same order)."""
+    import ctypes
+    rp, c = synth.rmat_csr(11, 10, seed=8, device=dev)
+    n, E = 1 << 11, c.numel()
+    v = synth.values(E, device=dev)
+    row = nat.ptr2ind(rp, E)
+    perm = torch.argsort(c * n + row)
+    colptr = nat.ind2ptr(c[perm].contiguous(), n)
+    for K in (64, 12):
+        x = synth.features(n, K, seed=4, device=dev)
+        want, warg = nat.spmm(colptr, row[perm].contiguous(), v[perm].contiguous(), x, reduce)
+        out = torch.empty_like(want)
+        arg = torch.empty_like(warg) if warg is not None else None
+        L = nat.lib()
+        red = nat.REDUCES[reduce]
+        nb = L.tsamd_spmm_workspace_bytes(0, red, ctypes.c_int64(1), ctypes.c_int64(n), ctypes.c_int64(n),
+                                          ctypes.c_int64(K), ctypes.c_int64(E))
+        ws = nat.workspace(nb, x.device)
+        p = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+        st = L.tsamd_spmm_permuted(0, red, p(colptr), p(row), p(v), p(perm), p(x), p(out), p(arg), ctypes.c_int64(1),
+                                   ctypes.c_int64(n), ctypes.c_int64(n), ctypes.c_int64(K), ctypes.c_int64(E), p(ws),
+                                   ctypes.c_size_t(ws.numel()), nat.stream_ptr(x.device))
+        assert st == 0
+        torch.cuda.synchronize()
+        assert bits_equal(out, want)
+        if arg is not None:
+            assert torch.equal(arg, warg)
