@@ -248,7 +248,9 @@ __device__ __forceinline__ void accumulate_window(
           const A p = has_value ? Traits<T>::round_acc(w[u] * xv) : xv;
           const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
           val[j] = better ? p : val[j];
+#if !defined(TSAMD_EXP_NO_ARG_TRACK)
           arg[j] = better ? wrel + (uint32_t)idx[u] : arg[j];
+#endif
         }
       }
     }
@@ -352,8 +354,14 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
     }
     // written once, never re-read here: keep them out of L2 (1.3 GB of arg ids at config-3 size
     // would otherwise evict the gathered rows of `mat`)
+#if !defined(TSAMD_EXP_NO_OUT_STORE)
     nt_store(outk, o);
+#endif
+#if !defined(TSAMD_EXP_NO_ARG_STORE)
     nt_store(argk, a);
+#else
+    asm volatile("" ::"v"(a.v[0]), "v"(a.v[VEC - 1]));
+#endif
   }
 }
 

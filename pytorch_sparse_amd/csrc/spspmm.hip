@@ -352,6 +352,15 @@ __device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane) {
   else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, (int)v);
 }
 
+// One half of a compare-exchange between two lanes: the lower lane keeps min(a, b), the upper one
+// max(a, b).  The median of (a, b, 0) is the minimum and the median of (a, b, 2^32 - 1) the maximum, so a
+// single v_med3_u32 with a per-lane constant does it (min + max + select otherwise).
+__device__ __forceinline__ uint32_t keep_lower_or_upper(uint32_t a, uint32_t b, uint32_t bound) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(bound));
+  return r;
+}
+
 __device__ __forceinline__ void cmpswap(uint32_t &a, uint32_t &b) {
   const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo;
@@ -378,10 +387,7 @@ __device__ __forceinline__ void cross_phase(uint32_t (&key)[I], int lane) {
 #pragma unroll
     for (int j = 0; j < I; ++j) p[j] = xor_lane<(1 << B) - 1>(key[I - 1 - j], lane);
 #pragma unroll
-    for (int j = 0; j < I; ++j) {
-      const uint32_t lo = key[j] < p[j] ? key[j] : p[j], hi = key[j] < p[j] ? p[j] : key[j];
-      key[j] = lower ? lo : hi;
-    }
+    for (int j = 0; j < I; ++j) key[j] = keep_lower_or_upper(key[j], p[j], lower ? 0u : 0xFFFFFFFFu);
   }
   auto butterfly = [&](auto tc) {
     constexpr int t = decltype(tc)::value;
@@ -390,8 +396,7 @@ __device__ __forceinline__ void cross_phase(uint32_t (&key)[I], int lane) {
 #pragma unroll
       for (int j = 0; j < I; ++j) {
         const uint32_t q = xor_lane<(1 << t)>(key[j], lane);
-        const uint32_t lo = key[j] < q ? key[j] : q, hi = key[j] < q ? q : key[j];
-        key[j] = lower ? lo : hi;
+        key[j] = keep_lower_or_upper(key[j], q, lower ? 0u : 0xFFFFFFFFu);
       }
     }
   };
@@ -470,8 +475,14 @@ __device__ __forceinline__ void compress_and_store(int p, int64_t out, int64_t *
       c = col_at(idx);
       head = idx == 0 || col_at(idx - 1) != c;
     }
-    int tot;
-    const int pos = base + block_exclusive_scan_small<BLOCK / 64>(head ? 1 : 0, sscan, &tot);
+    int tot, pos;
+    if constexpr (BLOCK == 64) {  // one wave: positions from the ballot of the heads
+      const unsigned long long m = __ballot(head);
+      pos = base + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+      tot = __popcll(m);
+    } else {
+      pos = base + block_exclusive_scan_small<BLOCK / 64>(head ? 1 : 0, sscan, &tot);
+    }
     if (head) {
       colC[out + pos] = (int64_t)c;
       if (valC != nullptr) {

@@ -2,7 +2,7 @@
 import os, subprocess, sys, concurrent.futures as cf
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'pytorch_sparse_amd', 'csrc')
-OUT = os.path.join(ROOT, 'build', 'variants')
+OUT = os.path.join(ROOT, 'build', os.environ.get('TSAMD_VARIANT_DIR', 'ab'))
 def build(name, defs, sources=('api.hip', 'spmm.hip', 'spmm_bw.hip', 'convert.hip')):
     os.makedirs(OUT, exist_ok=True)
     so = os.path.join(OUT, name + '.so')
