@@ -274,7 +274,9 @@ int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t
  *        it references); bins[2*M] = ids of the rows with more than 512 products by size class
  *        (medium <= 4096 | large, M slots each; rows of <= 512 products are not listed, their
  *        kernels run over all rows in natural order); stats (DEVICE int64[8]): [2]=#medium
- *        [3]=#large  [4]=products in large rows.
+ *        [3]=#large  [4]=products in large rows.  colB32 [nnz(B)] = the column ids of B as 32-bit
+ *        words (caller-allocated): stages 2 and 4 gather short B rows from all over the array and read
+ *        this copy (half the lines per row).
  *        --> host reads stats (sync 1: grid sizes and the workspace of the large rows).
  *   2. tsamd_spspmm_symbolic  nnzC[i] = exact number of entries of row i of C (LDS hash sets for
  *        small / medium rows; large rows: products binned by column range into `workspace`
@@ -290,14 +292,15 @@ int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t
  * M < 2^31, N < 2^32 - 1.
  * ------------------------------------------------------------------------ */
 int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
-                      int64_t M, int64_t *prod, int64_t *bins, int64_t *stats, void *stream);
+                      const int64_t *colB, int64_t nnzB, int64_t M, int64_t *prod, int64_t *bins,
+                      uint32_t *colB32, int64_t *stats, void *stream);
 size_t tsamd_spspmm_workspace_bytes(int dtype, int64_t n_large, int64_t P_large, int64_t N);
 int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
-                          const int64_t *colB, int64_t M, int64_t N, const int64_t *prod,
+                          const uint32_t *colB32, int64_t M, int64_t N, const int64_t *prod,
                           const int64_t *bins, int64_t n_medium, int64_t n_large, int64_t P_large,
                           int64_t *nnzC, void *workspace, size_t workspace_bytes, void *stream);
 int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int64_t *colA, const void *valA,
-                         const int64_t *rowptrB, const int64_t *colB, const void *valB, int64_t M,
+                         const int64_t *rowptrB, const uint32_t *colB32, const void *valB, int64_t M,
                          int64_t N, const int64_t *prod, const int64_t *bins, int64_t n_medium,
                          int64_t n_large, int64_t P_large, const int64_t *rowptrC, int64_t *colC,
                          void *valC, void *workspace, size_t workspace_bytes, void *stream);

@@ -62,6 +62,14 @@ __global__ __launch_bounds__(256) void spspmm_count_kernel(
   if (i < M && sub == 0) prod[i] = p;
 }
 
+// Column ids of B as 32-bit words (N < 2^32 - 1): the expansion gathers short B rows from all over the
+// array, and a row of ~15 ids then straddles one or two 128-byte lines instead of two or three.
+__global__ __launch_bounds__(256) void spspmm_narrow_cols_kernel(const int64_t *__restrict__ col, int64_t n,
+                                                                uint32_t *__restrict__ col32) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    col32[i] = (uint32_t)col[i];
+}
+
 // Rows of more than kSmallCap products are listed by size class (medium | large); small rows are
 // not listed: their kernels run over all rows in natural order and skip the others (better locality
 // of the A rows and of the output, and no atomics at all when every row is small).  One thread per
@@ -213,7 +221,7 @@ struct ExpandScratch {
 template <typename T, int BLOCK, bool WITH_VAL, typename Emit>
 __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, const T *__restrict__ valA,
                                           const int64_t *__restrict__ rowptrB,
-                                          const int64_t *__restrict__ colB, const T *__restrict__ valB,
+                                          const uint32_t *__restrict__ colB, const T *__restrict__ valB,
                                           int64_t as, int64_t ae,
                                           ExpandScratch<typename Traits<T>::acc_t> &sc, Emit emit) {
   using A = typename Traits<T>::acc_t;
@@ -265,7 +273,7 @@ __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, cons
       A b[kExpandBatch];
 #pragma unroll
       for (int u = 0; u < kExpandBatch; ++u) {
-        c[u] = (uint32_t)colB[src[u]];
+        c[u] = colB[src[u]];
         b[u] = (WITH_VAL && valB != nullptr) ? Traits<T>::to_acc(valB[src[u]]) : A(1);
       }
 #pragma unroll
@@ -288,7 +296,7 @@ constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;  // column ids are < 2^32 - 1
 template <int BLOCK, int LOG_T>
 __global__ __launch_bounds__(BLOCK) void spspmm_symbolic_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
-    const int64_t *__restrict__ rowptrB, const int64_t *__restrict__ colB,
+    const int64_t *__restrict__ rowptrB, const uint32_t *__restrict__ colB,
     const int64_t *__restrict__ prod, const int64_t *__restrict__ rows, int64_t *__restrict__ nnzC) {
   constexpr int kT = 1 << LOG_T;
   __shared__ uint32_t tab[kT];
@@ -504,7 +512,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
     const T *__restrict__ valA, const int64_t *__restrict__ rowptrB,
-    const int64_t *__restrict__ colB, const T *__restrict__ valB,
+    const uint32_t *__restrict__ colB, const T *__restrict__ valB,
     const int64_t *__restrict__ prod, const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC,
     T *__restrict__ valC) {
   using A = typename Traits<T>::acc_t;
@@ -548,7 +556,7 @@ template <typename T, int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void spspmm_numeric_pairs_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
     const T *__restrict__ valA, const int64_t *__restrict__ rowptrB,
-    const int64_t *__restrict__ colB, const T *__restrict__ valB,
+    const uint32_t *__restrict__ colB, const T *__restrict__ valB,
     const int64_t *__restrict__ prod, const int64_t *__restrict__ rows,
     const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC, T *__restrict__ valC, int passes) {
   using A = typename Traits<T>::acc_t;
@@ -641,7 +649,7 @@ constexpr int kLgRange = sizeof(typename Traits<T>::acc_t) == 4 ? 15 : 14;  // 3
 
 __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
-    const int64_t *__restrict__ rowptrB, const int64_t *__restrict__ colB,
+    const int64_t *__restrict__ rowptrB, const uint32_t *__restrict__ colB,
     const int64_t *__restrict__ rows, int lg_range, int nr, int64_t *__restrict__ hist) {
   __shared__ int cnt[kMaxRanges];
   __shared__ ExpandScratch<float> sc;
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
 template <typename T, bool WITH_VAL>
 __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA, const T *__restrict__ valA,
-    const int64_t *__restrict__ rowptrB, const int64_t *__restrict__ colB, const T *__restrict__ valB,
+    const int64_t *__restrict__ rowptrB, const uint32_t *__restrict__ colB, const T *__restrict__ valB,
     const int64_t *__restrict__ rows, int lg_range, int nr, const int64_t *__restrict__ bin_off,
     uint32_t *__restrict__ bcol, T *__restrict__ bval) {
   using A = typename Traits<T>::acc_t;
@@ -885,7 +893,7 @@ unsigned int persistent_blocks() {
 }
 
 int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
-                   const int64_t *colB, const int64_t *rows, int64_t n_large, int64_t P_large, int64_t N,
+                   const uint32_t *colB, const int64_t *rows, int64_t n_large, int64_t P_large, int64_t N,
                    size_t esize, int64_t *nnzC, void *workspace, hipStream_t stream) {
   LargeWs w;
   carve_large(workspace, n_large, P_large, N, esize, &w);
@@ -910,7 +918,7 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *r
 
 template <typename T>
 int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
-                  const int64_t *colB, const void *valB, const int64_t *rows, int64_t n_large,
+                  const uint32_t *colB, const void *valB, const int64_t *rows, int64_t n_large,
                   int64_t P_large, int64_t N, const int64_t *rowptrC, int64_t *colC, void *valC,
                   void *workspace, hipStream_t stream) {
   LargeWs w;
@@ -937,7 +945,7 @@ int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA,
 
 template <typename T>
 int numeric_rows(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
-                 const int64_t *colB, const void *valB, const int64_t *prod, const int64_t *bins,
+                 const uint32_t *colB, const void *valB, const int64_t *prod, const int64_t *bins,
                  int64_t M, int64_t N, int64_t n_medium, const int64_t *rowptrC, int64_t *colC, void *valC,
                  hipStream_t stream) {
   int bits = 1;
@@ -981,10 +989,17 @@ extern "C" int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t
 }
 
 extern "C" int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA,
-                                 const int64_t *rowptrB, int64_t M, int64_t *prod, int64_t *bins,
-                                 int64_t *stats, void *stream_) {
+                                 const int64_t *rowptrB, const int64_t *colB64, int64_t nnzB, int64_t M,
+                                 int64_t *prod, int64_t *bins, uint32_t *colB32, int64_t *stats,
+                                 void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (M < 0 || !stats) return TSAMD_ERR_INVALID;
+  if (M < 0 || !stats || nnzB < 0 || (nnzB > 0 && (!colB64 || !colB32))) return TSAMD_ERR_INVALID;
+  if (nnzB > 0) {
+    const int64_t blocks = ceil_div(nnzB, 256 * 8);
+    hipLaunchKernelGGL(spspmm_narrow_cols_kernel, dim3((unsigned int)(blocks < 65536 ? blocks : 65536)), dim3(256),
+                       0, stream, colB64, nnzB, colB32);
+    TSAMD_LAUNCH_CHECK();
+  }
   if (M > 0 && (!rowptrA || !rowptrB || !bins || !prod)) return TSAMD_ERR_INVALID;
   TSAMD_HIP_TRY(hipMemsetAsync(stats, 0, 8 * sizeof(int64_t), stream));
   if (M == 0) return TSAMD_OK;
@@ -1003,7 +1018,7 @@ extern "C" size_t tsamd_spspmm_workspace_bytes(int dtype, int64_t n_large, int64
 }
 
 extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const int64_t *colA,
-                                     const int64_t *rowptrB, const int64_t *colB, int64_t M,
+                                     const int64_t *rowptrB, const uint32_t *colB, int64_t M,
                                      int64_t N, const int64_t *prod, const int64_t *bins,
                                      int64_t n_medium, int64_t n_large, int64_t P_large,
                                      int64_t *nnzC, void *workspace, size_t workspace_bytes,
@@ -1033,7 +1048,7 @@ extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const in
 }
 
 extern "C" int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int64_t *colA,
-                                    const void *valA, const int64_t *rowptrB, const int64_t *colB,
+                                    const void *valA, const int64_t *rowptrB, const uint32_t *colB,
                                     const void *valB, int64_t M, int64_t N, const int64_t *prod,
                                     const int64_t *bins, int64_t n_medium, int64_t n_large,
                                     int64_t P_large, const int64_t *rowptrC, int64_t *colC,

@@ -609,9 +609,12 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
 
   Tensor prod = torch::empty({M + 1}, iopt), bins = torch::empty({2 * M + 1}, iopt);
   Tensor stats = torch::empty({8}, iopt);
+  Tensor colB32 = torch::empty({colB.numel()}, iopt.dtype(at::kInt));  // 32-bit copy for the gathers
+  uint32_t *cb32 = reinterpret_cast<uint32_t *>(colB32.data_ptr<int32_t>());
   check_status(tsamd_spspmm_plan(rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
-                                 rowptrB.data_ptr<int64_t>(), M, prod.data_ptr<int64_t>(),
-                                 bins.data_ptr<int64_t>(), stats.data_ptr<int64_t>(), stream),
+                                 rowptrB.data_ptr<int64_t>(), colB.data_ptr<int64_t>(), colB.numel(), M,
+                                 prod.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), cb32,
+                                 stats.data_ptr<int64_t>(), stream),
                "tsamd_spspmm_plan");
   Tensor h = stats.cpu();  // sync 1: grid sizes, workspace of the rows beyond the LDS capacity
   const int64_t *hs = h.data_ptr<int64_t>();
@@ -628,7 +631,7 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   Tensor ws1 = workspace(ws_bytes, rowptrA);
   Tensor rowptrC = torch::zeros({M + 1}, iopt);  // nnzC in [0, M), scanned in place below
   check_status(tsamd_spspmm_symbolic(dt, rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
-                                     rowptrB.data_ptr<int64_t>(), colB.data_ptr<int64_t>(), M, N,
+                                     rowptrB.data_ptr<int64_t>(), cb32, M, N,
                                      prod.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_medium,
                                      n_large, P_large, rowptrC.data_ptr<int64_t>(),
                                      ws1.data_ptr(), (size_t)ws1.numel(), stream),
@@ -645,7 +648,7 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   check_status(
       tsamd_spspmm_numeric(dt, rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
                            valA.has_value() ? va.data_ptr() : nullptr, rowptrB.data_ptr<int64_t>(),
-                           colB.data_ptr<int64_t>(), valB.has_value() ? vb.data_ptr() : nullptr, M, N,
+                           cb32, valB.has_value() ? vb.data_ptr() : nullptr, M, N,
                            prod.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_medium, n_large,
                            P_large, rowptrC.data_ptr<int64_t>(), colC.data_ptr<int64_t>(),
                            with_value ? valC.data_ptr() : nullptr, ws1.data_ptr(), (size_t)ws1.numel(),
