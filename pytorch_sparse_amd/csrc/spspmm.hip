@@ -631,21 +631,40 @@ __global__ __launch_bounds__(BLOCK) void spspmm_numeric_pairs_kernel(
 //   (scan)    -> bin offsets: the products of (row, range) get a contiguous segment of a scratch array
 //   bin       workgroup per large row: expand again, every product (column inside the range [, value])
 //             goes to its segment (LDS cursors); 4 + sizeof(T) bytes of scratch per product
-//   count     (symbolic) persistent workgroups over the non-empty bins: set the occupancy bits, popcount
-//   accum     (numeric)  persistent workgroups over the non-empty bins: atomicAdd into the LDS accumulators,
-//             then walk the bitmap in column order, store (column, sum) at the bin's final position and
-//             put the touched accumulators back to zero
+//   classify  bins of at most 512 products | bigger ones (two lists, one atomic per wave)
+//   count     (symbolic) small bins: one wave each, occupancy bitmap of the range in LDS, popcount;
+//             big bins: persistent workgroups, same bitmap
+//   accum     (numeric)  small bins: one wave each, the register sort of the small rows on
+//             (column inside the range << 9 | index) keys -- bit-reproducible;
+//             big bins: persistent workgroups, atomicAdd into the LDS accumulators, then walk the bitmap
+//             in column order, store (column, sum) at the bin's final position and put the touched
+//             accumulators back to zero
 // Duplicates cost nothing extra, the output comes out sorted by construction, explicit zeros are kept
-// (an entry exists when its bit is set).  The sums of such a row are formed in atomic order: unlike the
+// (an entry exists when its bit is set).  The sums of a big bin are formed in atomic order: unlike the
 // small / medium rows they are not bit-reproducible from run to run (fp32 rounding order).
+// Limit: kMaxRanges ranges, i.e. N <= 2^26 (fp32) / 2^25 (fp64) columns for operands that have such rows.
 // ---------------------------------------------------------------------------
+// Range size / workgroup shape of the dense accumulation, same-box A/B on the R-MAT scale-19 stress product
+// (whole op): 2^15 columns x 1024 threads x 1 workgroup per CU 86 ms, 2^14 x 512 x 2: 77 ms,
+// 2^13 x 256 x 4: 72 ms, 2^12 x 256 x 8: 75 ms.  Smaller ranges send more bins down the one-wave path and
+// keep several bins in flight per CU; below 2^13 the scatter of the bin kernel into more, shorter
+// segments costs more than that gains.
+#ifndef TSAMD_SPSPMM_LG_RANGE
+#define TSAMD_SPSPMM_LG_RANGE 13
+#endif
+#ifndef TSAMD_SPSPMM_ACCUM_THREADS
+#define TSAMD_SPSPMM_ACCUM_THREADS 256
+#endif
+#ifndef TSAMD_SPSPMM_ACCUM_WGS
+#define TSAMD_SPSPMM_ACCUM_WGS 4
+#endif
 constexpr int kLargeThreads = 256;   // hist / bin kernels: one workgroup per large row
-constexpr int kAccumThreads = 1024;  // count / accum kernels: ONE workgroup per CU (LDS), so make it a big one
+constexpr int kAccumThreads = TSAMD_SPSPMM_ACCUM_THREADS;  // count / accum kernels (persistent, LDS-bound occupancy)
 constexpr int kBinBatch = 4;         // bin entries fetched per thread before they are consumed
 constexpr int kMaxRanges = 8192;         // LDS counters / cursors of the hist and bin kernels
 
 template <typename T>
-constexpr int kLgRange = sizeof(typename Traits<T>::acc_t) == 4 ? 15 : 14;  // 32 Ki fp32 / 16 Ki fp64 columns
+constexpr int kLgRange = sizeof(typename Traits<T>::acc_t) == 4 ? TSAMD_SPSPMM_LG_RANGE : TSAMD_SPSPMM_LG_RANGE - 1;  // fp32 / fp64 columns per range
 
 __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
@@ -714,22 +733,20 @@ struct Tickets {
 
 // symbolic: distinct columns per bin, added up per row
 __global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
-    const int64_t *__restrict__ rows, int nr, int64_t ntask, const int64_t *__restrict__ bin_off,
-    const uint32_t *__restrict__ bcol, int range_words, int64_t *__restrict__ bin_cnt,
-    unsigned long long *__restrict__ nnzC, unsigned long long *queue) {
+    const int64_t *__restrict__ rows, int nr, const int64_t *__restrict__ big, const int64_t *__restrict__ n_big,
+    const int64_t *__restrict__ bin_off, const uint32_t *__restrict__ bcol, int range_words,
+    int64_t *__restrict__ bin_cnt, unsigned long long *__restrict__ nnzC, unsigned long long *queue) {
   __shared__ uint32_t bits[(1 << 15) / 32];
   __shared__ int s_part[kAccumThreads / 64];
   const int tid = (int)threadIdx.x;
   __shared__ int64_t s_ticket[2];
   for (int w = tid; w < range_words; w += kAccumThreads) bits[w] = 0;
   Tickets tk{queue, s_ticket};
-  for (int64_t task = tk.first(); task < ntask; task = tk.next()) {
+  const int64_t nbig = *n_big;
+  for (int64_t t = tk.first(); t < nbig; t = tk.next()) {
     tk.prefetch();
+    const int64_t task = big[t];
     const int64_t b0 = bin_off[task], b1 = bin_off[task + 1];
-    if (b0 == b1) {
-      if (tid == 0) bin_cnt[task] = 0;
-      continue;
-    }
     for (int64_t p0 = b0 + tid; p0 < b1; p0 += (int64_t)kAccumThreads * kBinBatch) {
       uint32_t c[kBinBatch];
 #pragma unroll
@@ -762,8 +779,9 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
 // numeric: accumulate a bin in LDS, emit it in column order at its final position
 template <typename T>
 __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
-    const int64_t *__restrict__ rows, int nr, int64_t ntask, const int64_t *__restrict__ bin_off,
-    const uint32_t *__restrict__ bcol, const T *__restrict__ bval, const int64_t *__restrict__ bin_pref,
+    const int64_t *__restrict__ rows, int nr, const int64_t *__restrict__ big, const int64_t *__restrict__ n_big,
+    const int64_t *__restrict__ bin_off, const uint32_t *__restrict__ bcol, const T *__restrict__ bval,
+    const int64_t *__restrict__ bin_pref,
     const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC, T *__restrict__ valC,
     unsigned long long *queue) {
   using A = typename Traits<T>::acc_t;
@@ -779,10 +797,11 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
   __shared__ int64_t s_ticket[2];
   for (int w = tid; w < kWords; w += kAccumThreads) bits[w] = 0;
   Tickets tk{queue, s_ticket};
-  for (int64_t task = tk.first(); task < ntask; task = tk.next()) {
+  const int64_t nbig = *n_big;
+  for (int64_t t = tk.first(); t < nbig; t = tk.next()) {
     tk.prefetch();
+    const int64_t task = big[t];
     const int64_t b0 = bin_off[task], b1 = bin_off[task + 1];
-    if (b0 == b1) continue;
     for (int64_t p0 = b0 + tid; p0 < b1; p0 += (int64_t)kAccumThreads * kBinBatch) {
       uint32_t c[kBinBatch];
       A v[kBinBatch];
@@ -844,12 +863,126 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
   }
 }
 
+// Bins by size: those of at most kSmallCap products go to one WAVE each (many in flight per CU), the
+// others to the persistent workgroups above.  Most bins of a power-law product are small (a few hundred
+// products), and a persistent workgroup spends ~8 us of barriers, dependent loads and ticket traffic on
+// each regardless of its size.  lists[0 .. ntask) = small bins, lists[ntask .. 2 ntask) = big bins (in no
+// particular order), counts[0] / counts[1] their numbers; empty bins get bin_cnt = 0 here.
+__global__ __launch_bounds__(256) void spspmm_large_classify_kernel(const int64_t *__restrict__ bin_off,
+                                                                   int64_t ntask, int64_t *__restrict__ lists,
+                                                                   unsigned long long *counts,
+                                                                   int64_t *__restrict__ bin_cnt) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int64_t task = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t n = 0;
+  if (task < ntask) {
+    n = bin_off[task + 1] - bin_off[task];
+    if (n == 0) bin_cnt[task] = 0;
+  }
+  const int cls = n == 0 ? -1 : (n <= kSmallCap ? 0 : 1);
+  for (int k = 0; k < 2; ++k) {
+    const unsigned long long m = __ballot(cls == k);
+    if (m == 0) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&counts[k], (unsigned long long)__popcll(m));
+    base = (unsigned long long)lane_read((int64_t)base, 0);
+    if (cls == k) lists[(int64_t)k * ntask + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = task;
+  }
+}
+
+constexpr int kSmallBinWaves = 8192;  // resident waves of the small-bin kernels (grid-stride over the list)
+
+// symbolic, small bins: occupancy bitmap of the range in LDS, one wave per bin
+__global__ __launch_bounds__(64) void spspmm_smallbin_count_kernel(
+    const int64_t *__restrict__ rows, int nr, const int64_t *__restrict__ small,
+    const unsigned long long *__restrict__ n_small, const int64_t *__restrict__ bin_off,
+    const uint32_t *__restrict__ bcol, int range_words, int64_t *__restrict__ bin_cnt,
+    unsigned long long *__restrict__ nnzC) {
+  __shared__ uint32_t bits[(1 << 15) / 32];
+  const int lane = (int)threadIdx.x;
+  for (int w = lane; w < range_words; w += 64) bits[w] = 0;
+  const int64_t ns = (int64_t)*n_small;
+  for (int64_t t = blockIdx.x; t < ns; t += gridDim.x) {
+    const int64_t task = small[t];
+    const int64_t b0 = bin_off[task];
+    const int n = (int)(bin_off[task + 1] - b0);
+    uint32_t c[kSmallCap / 64];
+#pragma unroll
+    for (int u = 0; u < kSmallCap / 64; ++u) {
+      const int q = u * 64 + lane;
+      if (u * 64 < n) c[u] = bcol[b0 + (q < n ? q : n - 1)];  // (wave-uniform) a repeat sets the same bit again
+    }
+#pragma unroll
+    for (int u = 0; u < kSmallCap / 64; ++u)
+      if (u * 64 < n) atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
+    __syncthreads();
+    int cnt = 0;
+    for (int w = lane; w < range_words; w += 64) {
+      const uint32_t b = bits[w];
+      if (b) {
+        cnt += __popc(b);
+        bits[w] = 0;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += lane_xor(cnt, off);
+    if (lane == 0) {
+      bin_cnt[task] = cnt;
+      atomicAdd(&nnzC[rows[task / nr]], (unsigned long long)cnt);
+    }
+    __syncthreads();
+  }
+}
+
+// numeric, small bins: the register sort of the small rows on (column inside the range << 9 | index) keys
+template <typename T>
+__global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
+    const int64_t *__restrict__ rows, int nr, const int64_t *__restrict__ small,
+    const unsigned long long *__restrict__ n_small, const int64_t *__restrict__ bin_off,
+    const uint32_t *__restrict__ bcol, const T *__restrict__ bval, const int64_t *__restrict__ bin_pref,
+    const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC, T *__restrict__ valC) {
+  using A = typename Traits<T>::acc_t;
+  __shared__ alignas(16) uint32_t skey[kSmallCap];
+  __shared__ A sval[kSmallCap];
+  __shared__ int sscan[8];
+  const int lane = (int)threadIdx.x;
+  const int64_t ns = (int64_t)*n_small;
+  for (int64_t t = blockIdx.x; t < ns; t += gridDim.x) {
+    const int64_t task = small[t];
+    const int64_t b0 = bin_off[task];
+    const int p = (int)(bin_off[task + 1] - b0);
+    const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : 8));
+    for (int q = lane; q < 64 * items; q += 64) {
+      uint32_t k = kEmptyKey;
+      if (q < p) {
+        k = (bcol[b0 + q] << kIdxBits) | (uint32_t)q;
+        if (valC != nullptr) sval[q] = Traits<T>::to_acc(bval[b0 + q]);
+      }
+      skey[q] = k;
+    }
+    __syncthreads();
+    if (items == 1) sort_lds_keys<1>(skey, lane);
+    else if (items == 2) sort_lds_keys<2>(skey, lane);
+    else if (items == 4) sort_lds_keys<4>(skey, lane);
+    else sort_lds_keys<8>(skey, lane);
+    __syncthreads();
+    const int64_t r = task / nr, q0 = task - r * nr;
+    const int64_t out0 = rowptrC[rows[r]] + (bin_pref[task] - bin_pref[r * nr]);
+    const uint32_t col0 = (uint32_t)(q0 << kLgRange<T>);
+    compress_and_store<T, 64>(
+        p, out0, colC, valC, sscan, [&](int idx) { return col0 + (skey[idx] >> kIdxBits); },
+        [&](int idx) { return sval[skey[idx] & (uint32_t)(kSmallCap - 1)]; });
+    __syncthreads();
+  }
+}
+
 struct LargeWs {
   int64_t *hist;      // [n_large * nr + 1] products per bin, scanned in place -> bin offsets
   int64_t *bin_cnt;   // [n_large * nr + 1] distinct columns per bin, scanned at numeric time
   uint32_t *bcol;     // [P_large] column inside its range
   void *bval;         // [P_large] value (numeric stage)
   unsigned long long *queue;  // ticket counters of the persistent kernels
+  int64_t *lists;             // [2 * ntask] small bins | big bins (spspmm_large_classify_kernel)
+  unsigned long long *counts; // [2] their numbers
   void *scan_ws;
   int nr, lg_range;
   int64_t ntask;
@@ -865,7 +998,7 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, int64_t N, size
     return r;
   };
   LargeWs l;
-  l.lg_range = esize == 8 ? 14 : 15;
+  l.lg_range = esize == 8 ? TSAMD_SPSPMM_LG_RANGE - 1 : TSAMD_SPSPMM_LG_RANGE;
   l.nr = (int)((N + ((int64_t)1 << l.lg_range) - 1) >> l.lg_range);
   if (l.nr < 1) l.nr = 1;
   l.ntask = n_large * (int64_t)l.nr;
@@ -874,13 +1007,15 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, int64_t N, size
   l.bcol = (uint32_t *)take(4 * (size_t)P_large);
   l.bval = take(esize * (size_t)P_large);
   l.queue = (unsigned long long *)take(64);
+  l.lists = (int64_t *)take(16 * (size_t)l.ntask);
+  l.counts = (unsigned long long *)take(64);
   l.scan_ws = take(scan_workspace_bytes(l.ntask + 1));
   if (w) *w = l;
   return off;
 }
 
 unsigned int persistent_blocks() {
-  static int cus = 0;  // the LDS footprint allows one workgroup per CU
+  static int cus = 0;  // the LDS footprint allows TSAMD_SPSPMM_ACCUM_WGS workgroups per CU
   if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -889,7 +1024,7 @@ unsigned int persistent_blocks() {
         prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
   }
-  return (unsigned int)cus;
+  return (unsigned int)cus * TSAMD_SPSPMM_ACCUM_WGS;
 }
 
 int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
@@ -909,9 +1044,20 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *r
                      rows, w.lg_range, w.nr, (const int64_t *)w.hist, w.bcol, (float *)nullptr);
   TSAMD_LAUNCH_CHECK();
   TSAMD_HIP_TRY(hipMemsetAsync(w.queue, 0, 64, stream));
+  TSAMD_HIP_TRY(hipMemsetAsync(w.counts, 0, 64, stream));
+  hipLaunchKernelGGL(spspmm_large_classify_kernel, dim3((unsigned int)ceil_div(w.ntask, 256)), dim3(256), 0, stream,
+                     (const int64_t *)w.hist, w.ntask, w.lists, w.counts, w.bin_cnt);
+  TSAMD_LAUNCH_CHECK();
+  const unsigned int small_grid = (unsigned int)(w.ntask < kSmallBinWaves ? w.ntask : kSmallBinWaves);
+  hipLaunchKernelGGL(spspmm_smallbin_count_kernel, dim3(small_grid), dim3(64), 0, stream, rows, w.nr,
+                     (const int64_t *)w.lists, (const unsigned long long *)w.counts, (const int64_t *)w.hist,
+                     (const uint32_t *)w.bcol, (1 << w.lg_range) / 32, w.bin_cnt,
+                     reinterpret_cast<unsigned long long *>(nnzC));
+  TSAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(spspmm_large_count_kernel, dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream, rows,
-                     w.nr, w.ntask, (const int64_t *)w.hist, (const uint32_t *)w.bcol, (1 << w.lg_range) / 32,
-                     w.bin_cnt, reinterpret_cast<unsigned long long *>(nnzC), w.queue);
+                     w.nr, (const int64_t *)(w.lists + w.ntask), (const int64_t *)(w.counts + 1),
+                     (const int64_t *)w.hist, (const uint32_t *)w.bcol, (1 << w.lg_range) / 32, w.bin_cnt,
+                     reinterpret_cast<unsigned long long *>(nnzC), w.queue);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }
@@ -936,9 +1082,17 @@ int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA,
   int st = exclusive_scan_i64(w.bin_cnt, w.bin_cnt, w.ntask + 1, nullptr, w.scan_ws, stream);
   if (st != TSAMD_OK) return st;
   TSAMD_HIP_TRY(hipMemsetAsync(w.queue, 0, 64, stream));
+  // (the lists of small / big bins were left in the workspace by the symbolic stage)
+  const unsigned int small_grid = (unsigned int)(w.ntask < kSmallBinWaves ? w.ntask : kSmallBinWaves);
+  hipLaunchKernelGGL((spspmm_smallbin_accum_kernel<T>), dim3(small_grid), dim3(64), 0, stream, rows, w.nr,
+                     (const int64_t *)w.lists, (const unsigned long long *)w.counts, (const int64_t *)w.hist,
+                     (const uint32_t *)w.bcol, (const T *)bv, (const int64_t *)w.bin_cnt, rowptrC, colC,
+                     reinterpret_cast<T *>(valC));
+  TSAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL((spspmm_large_accum_kernel<T>), dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream,
-                     rows, w.nr, w.ntask, (const int64_t *)w.hist, (const uint32_t *)w.bcol, (const T *)bv,
-                     (const int64_t *)w.bin_cnt, rowptrC, colC, reinterpret_cast<T *>(valC), w.queue);
+                     rows, w.nr, (const int64_t *)(w.lists + w.ntask), (const int64_t *)(w.counts + 1),
+                     (const int64_t *)w.hist, (const uint32_t *)w.bcol, (const T *)bv, (const int64_t *)w.bin_cnt,
+                     rowptrC, colC, reinterpret_cast<T *>(valC), w.queue);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }
