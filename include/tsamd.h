@@ -282,7 +282,10 @@ int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t
  *        small / medium rows; large rows: products binned by column range into `workspace`
  *        -- 4 + sizeof(value) bytes per product, which stage 4 reuses -- and counted with LDS
  *        bitmaps).  nnzC has M entries, all written.  `dtype` is the value type of stage 4 (it
- *        fixes the width of a column range).
+ *        fixes the width of a column range).  bin_values != 0: the products of the large rows are
+ *        binned together with their values (valA / valB of type `dtype`, either may be NULL = ones),
+ *        and stage 4 is then called with values_binned = 1 and does not expand those rows again;
+ *        with bin_values = 0 (structure only, or values not known yet) valA / valB are ignored.
  *   3. host: rowptrC = exclusive scan of nnzC over M + 1 entries (tsamd_exclusive_scan_i64, entry
  *        M = 0), reads nnz(C) (sync 2), allocates colC / valC at their FINAL size.
  *   4. tsamd_spspmm_numeric   every row is expanded, sorted by column (registers / LDS), its equal
@@ -295,15 +298,17 @@ int tsamd_spspmm_plan(const int64_t *rowptrA, const int64_t *colA, const int64_t
                       const int64_t *colB, int64_t nnzB, int64_t M, int64_t *prod, int64_t *bins,
                       uint32_t *colB32, int64_t *stats, void *stream);
 size_t tsamd_spspmm_workspace_bytes(int dtype, int64_t n_large, int64_t P_large, int64_t N);
-int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
-                          const uint32_t *colB32, int64_t M, int64_t N, const int64_t *prod,
-                          const int64_t *bins, int64_t n_medium, int64_t n_large, int64_t P_large,
-                          int64_t *nnzC, void *workspace, size_t workspace_bytes, void *stream);
+int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const int64_t *colA, const void *valA,
+                          const int64_t *rowptrB, const uint32_t *colB32, const void *valB, int bin_values,
+                          int64_t M, int64_t N, const int64_t *prod, const int64_t *bins, int64_t n_medium,
+                          int64_t n_large, int64_t P_large, int64_t *nnzC, void *workspace,
+                          size_t workspace_bytes, void *stream);
 int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int64_t *colA, const void *valA,
                          const int64_t *rowptrB, const uint32_t *colB32, const void *valB, int64_t M,
                          int64_t N, const int64_t *prod, const int64_t *bins, int64_t n_medium,
                          int64_t n_large, int64_t P_large, const int64_t *rowptrC, int64_t *colC,
-                         void *valC, void *workspace, size_t workspace_bytes, void *stream);
+                         void *valC, int values_binned, void *workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* ------------------------------------------------------------------------
  * Sub-matrix extraction (the callers either side of the sharded

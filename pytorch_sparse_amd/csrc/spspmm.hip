@@ -1027,9 +1027,14 @@ unsigned int persistent_blocks() {
   return (unsigned int)cus * TSAMD_SPSPMM_ACCUM_WGS;
 }
 
-int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *rowptrB,
-                   const uint32_t *colB, const int64_t *rows, int64_t n_large, int64_t P_large, int64_t N,
-                   size_t esize, int64_t *nnzC, void *workspace, hipStream_t stream) {
+// valA / valB given (either may be NULL): the products are binned WITH their values, so that the numeric
+// stage does not have to expand the large rows a third time.
+template <typename T>
+int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
+                   const uint32_t *colB, const void *valB, bool with_values, const int64_t *rows,
+                   int64_t n_large, int64_t P_large, int64_t N, int64_t *nnzC, void *workspace,
+                   hipStream_t stream) {
+  constexpr size_t esize = sizeof(T);
   LargeWs w;
   carve_large(workspace, n_large, P_large, N, esize, &w);
   if (w.nr > kMaxRanges) return TSAMD_ERR_UNSUPPORTED;
@@ -1039,9 +1044,15 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const int64_t *r
   TSAMD_HIP_TRY(hipMemsetAsync(w.hist + w.ntask, 0, 8, stream));
   int st = exclusive_scan_i64(w.hist, w.hist, w.ntask + 1, nullptr, w.scan_ws, stream);
   if (st != TSAMD_OK) return st;
-  hipLaunchKernelGGL((spspmm_large_bin_kernel<float, false>), dim3((unsigned int)n_large), dim3(kLargeThreads),
-                     0, stream, rowptrA, colA, (const float *)nullptr, rowptrB, colB, (const float *)nullptr,
-                     rows, w.lg_range, w.nr, (const int64_t *)w.hist, w.bcol, (float *)nullptr);
+  if (with_values)
+    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
+                       stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
+                       reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, (const int64_t *)w.hist,
+                       w.bcol, reinterpret_cast<T *>(w.bval));
+  else
+    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, false>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
+                       stream, rowptrA, colA, (const T *)nullptr, rowptrB, colB, (const T *)nullptr, rows,
+                       w.lg_range, w.nr, (const int64_t *)w.hist, w.bcol, (T *)nullptr);
   TSAMD_LAUNCH_CHECK();
   TSAMD_HIP_TRY(hipMemsetAsync(w.queue, 0, 64, stream));
   TSAMD_HIP_TRY(hipMemsetAsync(w.counts, 0, 64, stream));
@@ -1066,12 +1077,12 @@ template <typename T>
 int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA, const int64_t *rowptrB,
                   const uint32_t *colB, const void *valB, const int64_t *rows, int64_t n_large,
                   int64_t P_large, int64_t N, const int64_t *rowptrC, int64_t *colC, void *valC,
-                  void *workspace, hipStream_t stream) {
+                  bool values_binned, void *workspace, hipStream_t stream) {
   LargeWs w;
   carve_large(workspace, n_large, P_large, N, sizeof(T), &w);
   if (w.nr > kMaxRanges) return TSAMD_ERR_UNSUPPORTED;
   T *bv = reinterpret_cast<T *>(w.bval);
-  if (valC != nullptr) {  // the symbolic stage binned the columns; the values follow the same offsets
+  if (valC != nullptr && !values_binned) {  // the symbolic stage binned the columns only; the values follow the same offsets
     hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
                        stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
                        reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, (const int64_t *)w.hist,
@@ -1172,8 +1183,9 @@ extern "C" size_t tsamd_spspmm_workspace_bytes(int dtype, int64_t n_large, int64
 }
 
 extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const int64_t *colA,
-                                     const int64_t *rowptrB, const uint32_t *colB, int64_t M,
-                                     int64_t N, const int64_t *prod, const int64_t *bins,
+                                     const void *valA, const int64_t *rowptrB, const uint32_t *colB,
+                                     const void *valB, int bin_values, int64_t M, int64_t N,
+                                     const int64_t *prod, const int64_t *bins,
                                      int64_t n_medium, int64_t n_large, int64_t P_large,
                                      int64_t *nnzC, void *workspace, size_t workspace_bytes,
                                      void *stream_) {
@@ -1195,9 +1207,13 @@ extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const in
                        stream, rowptrA, colA, rowptrB, colB, prod, bins, nnzC);
     TSAMD_LAUNCH_CHECK();
   }
-  if (n_large > 0)
-    return symbolic_large(rowptrA, colA, rowptrB, colB, bins + M, n_large, P_large, N,
-                          dtype == TSAMD_F64 ? 8 : 4, nnzC, workspace, stream);
+  if (n_large > 0) {
+    if (dtype == TSAMD_F64)
+      return symbolic_large<double>(rowptrA, colA, valA, rowptrB, colB, valB, bin_values != 0, bins + M, n_large,
+                                    P_large, N, nnzC, workspace, stream);
+    return symbolic_large<float>(rowptrA, colA, valA, rowptrB, colB, valB, bin_values != 0, bins + M, n_large,
+                                 P_large, N, nnzC, workspace, stream);
+  }
   return TSAMD_OK;
 }
 
@@ -1206,8 +1222,8 @@ extern "C" int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int
                                     const void *valB, int64_t M, int64_t N, const int64_t *prod,
                                     const int64_t *bins, int64_t n_medium, int64_t n_large,
                                     int64_t P_large, const int64_t *rowptrC, int64_t *colC,
-                                    void *valC, void *workspace, size_t workspace_bytes,
-                                    void *stream_) {
+                                    void *valC, int values_binned, void *workspace,
+                                    size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (dtype != TSAMD_F32 && dtype != TSAMD_F64) return TSAMD_ERR_UNSUPPORTED;
   if (M < 0 || N < 0 || N >= ((int64_t)1 << 32) - 1 || M >= ((int64_t)1 << 31)) return TSAMD_ERR_UNSUPPORTED;
@@ -1226,7 +1242,7 @@ extern "C" int tsamd_spspmm_numeric(int dtype, const int64_t *rowptrA, const int
   if (st != TSAMD_OK || n_large == 0) return st;
   if (dtype == TSAMD_F32)
     return numeric_large<float>(rowptrA, colA, valA, rowptrB, colB, valB, bins + M, n_large, P_large, N,
-                                rowptrC, colC, valC, workspace, stream);
+                                rowptrC, colC, valC, values_binned != 0, workspace, stream);
   return numeric_large<double>(rowptrA, colA, valA, rowptrB, colB, valB, bins + M, n_large, P_large, N,
-                               rowptrC, colC, valC, workspace, stream);
+                               rowptrC, colC, valC, values_binned != 0, workspace, stream);
 }

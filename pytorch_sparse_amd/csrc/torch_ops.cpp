@@ -630,8 +630,12 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   }
   Tensor ws1 = workspace(ws_bytes, rowptrA);
   Tensor rowptrC = torch::zeros({M + 1}, iopt);  // nnzC in [0, M), scanned in place below
+  // with values: the large rows are binned once, values included (no third expansion in the numeric stage)
+  const int bin_values = with_value ? 1 : 0;
   check_status(tsamd_spspmm_symbolic(dt, rowptrA.data_ptr<int64_t>(), colA.data_ptr<int64_t>(),
-                                     rowptrB.data_ptr<int64_t>(), cb32, M, N,
+                                     valA.has_value() ? va.data_ptr() : nullptr,
+                                     rowptrB.data_ptr<int64_t>(), cb32,
+                                     valB.has_value() ? vb.data_ptr() : nullptr, bin_values, M, N,
                                      prod.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_medium,
                                      n_large, P_large, rowptrC.data_ptr<int64_t>(),
                                      ws1.data_ptr(), (size_t)ws1.numel(), stream),
@@ -651,8 +655,8 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
                            cb32, valB.has_value() ? vb.data_ptr() : nullptr, M, N,
                            prod.data_ptr<int64_t>(), bins.data_ptr<int64_t>(), n_medium, n_large,
                            P_large, rowptrC.data_ptr<int64_t>(), colC.data_ptr<int64_t>(),
-                           with_value ? valC.data_ptr() : nullptr, ws1.data_ptr(), (size_t)ws1.numel(),
-                           stream),
+                           with_value ? valC.data_ptr() : nullptr, bin_values, ws1.data_ptr(),
+                           (size_t)ws1.numel(), stream),
       "tsamd_spspmm_numeric");
   return std::make_tuple(rowptrC, colC, valC);
 }

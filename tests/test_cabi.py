@@ -94,9 +94,9 @@ def test_argument_validation_returns_status_codes():
     assert L.tsamd_sort_coo(fake, fake, i64(5), i64(9), i64(9), None, None, fake, None, sz(0), None) == 4
     assert L.tsamd_segment_reduce(0, 9, fake, None, fake, i64(3), i64(1), fake, None) == 2
     assert L.tsamd_spspmm_numeric(2, fake, fake, None, fake, fake, None, i64(4), i64(4), fake, fake, i64(0),
-                                  i64(0), i64(0), fake, fake, None, None, sz(0), None) == 2  # f16: like torch.sparse.mm
-    assert L.tsamd_spspmm_symbolic(0, fake, fake, fake, fake, i64(4), i64(4), fake, fake, i64(0), i64(1), i64(9000),
-                                   fake, None, sz(0), None) == 4  # rows beyond the LDS capacity need the workspace
+                                  i64(0), i64(0), fake, fake, None, 0, None, sz(0), None) == 2  # f16: like torch.sparse.mm
+    assert L.tsamd_spspmm_symbolic(0, fake, fake, None, fake, fake, None, 0, i64(4), i64(4), fake, fake, i64(0), i64(1),
+                                   i64(9000), fake, None, sz(0), None) == 4  # rows beyond the LDS capacity need the workspace
     # workspace sizes grow with the problem and include the relabel copy only when it can pay off
     small = L.tsamd_spmm_workspace_bytes(0, 0, i64(1), i64(1000), i64(1000), i64(128), i64(5000))
     big = L.tsamd_spmm_workspace_bytes(0, 0, i64(1), i64(1 << 21), i64(1 << 21), i64(128), i64(40 << 20))
