@@ -62,6 +62,15 @@ def build_kernels(verbose=True, force=False):
     headers = _headers()
     flags = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-I' + INCLUDE, '-I' + CSRC,
              '-Wall', '-Wno-unused-function']
+    # extra -D / -m flags (tuning constants such as -DTSAMD_SPSPMM_LG_RANGE=14); a change of the flag
+    # set rebuilds every object (the objects record nothing about the flags they were built with)
+    flags += os.environ.get('TSAMD_HIPCC_FLAGS', '').split()
+    stamp = os.path.join(OBJDIR, 'hipcc_flags.txt')
+    old_flags = open(stamp).read() if os.path.exists(stamp) else None
+    if old_flags != ' '.join(flags):
+        force = force or old_flags is not None or bool(os.environ.get('TSAMD_HIPCC_FLAGS'))
+        with open(stamp, 'w') as f:
+            f.write(' '.join(flags))
     jobs = []
     objs = []
     for src in HIP_SOURCES:
