@@ -707,27 +707,51 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
 }
 
 // The persistent count / accum workgroups draw their bins from a global ticket counter (bins differ by
-// five orders of magnitude in size, and a fixed stride hands every hub-range bin to the same few
-// workgroups: measured 46 -> 111 ms).  The ticket for the NEXT bin is drawn while the current one is
-// being processed, so its round trip is not exposed.
-struct Tickets {
+// orders of magnitude in size, and a fixed stride hands every hub-range bin to the same few workgroups:
+// measured 46 -> 111 ms).  A bin costs four dependent round trips before its first product can be loaded
+// (ticket -> list entry -> segment offsets / row -> row pointer), so they are taken through a two-deep
+// pipeline: while bin k is processed, thread 0 draws the ticket of bin k+2 and fetches the descriptor of
+// bin k+1 in three steps spread over the phases of bin k; the finished descriptor (task, segment, output
+// position or row) waits in LDS for the next iteration.
+struct BinFeed {
   unsigned long long *queue;
-  int64_t *slot;  // LDS
-  __device__ __forceinline__ int64_t first() {
-    if (threadIdx.x == 0) slot[0] = (int64_t)atomicAdd(queue, 1ull);
-    __syncthreads();
-    return slot[0];
+  const int64_t *list;
+  int64_t n;
+  const int64_t *bin_off, *rows, *bin_pref, *rowptrC;  // bin_pref / rowptrC: NULL in the count kernel
+  int nr;
+  // thread 0 only
+  int64_t t_next = 0, t_next2 = 0, task = -1, b0 = 0, b1 = 0, row = 0, pref = 0;
+
+  __device__ __forceinline__ void step_a() {  // top of an iteration
+    if (threadIdx.x != 0) return;
+    t_next2 = (int64_t)atomicAdd(queue, 1ull);
+    task = t_next < n ? list[t_next] : -1;
   }
-  // call once per bin, before the work on `current` starts
-  __device__ __forceinline__ void prefetch() {
-    if (threadIdx.x == 0) slot[1] = (int64_t)atomicAdd(queue, 1ull);
+  __device__ __forceinline__ void step_b() {  // middle of an iteration
+    if (threadIdx.x != 0 || task < 0) return;
+    b0 = bin_off[task];
+    b1 = bin_off[task + 1];
+    const int64_t r = task / nr;
+    row = rows[r];
+    if (bin_pref != nullptr) pref = bin_pref[task] - bin_pref[r * nr];
   }
-  // call after the work (all threads): hands out the prefetched ticket
-  __device__ __forceinline__ int64_t next() {
+  __device__ __forceinline__ void step_c(int64_t *desc) {  // end of an iteration (a barrier follows)
+    if (threadIdx.x != 0) return;
+    desc[0] = task;
+    desc[1] = b0;
+    desc[2] = b1;
+    desc[3] = task < 0 ? 0 : (rowptrC != nullptr ? rowptrC[row] + pref : row);
+    t_next = t_next2;
+  }
+  __device__ __forceinline__ void start(int64_t *desc) {  // descriptor of the first bin, ticket of the second
+    if (threadIdx.x == 0) {
+      t_next = (int64_t)atomicAdd(queue, 1ull);
+      t_next2 = (int64_t)atomicAdd(queue, 1ull);
+      task = t_next < n ? list[t_next] : -1;
+    }
+    step_b();
+    step_c(desc);
     __syncthreads();
-    if (threadIdx.x == 0) slot[0] = slot[1];
-    __syncthreads();
-    return slot[0];
   }
 };
 
@@ -739,14 +763,15 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
   __shared__ uint32_t bits[(1 << 15) / 32];
   __shared__ int s_part[kAccumThreads / 64];
   const int tid = (int)threadIdx.x;
-  __shared__ int64_t s_ticket[2];
+  __shared__ int64_t s_desc[2][4];
   for (int w = tid; w < range_words; w += kAccumThreads) bits[w] = 0;
-  Tickets tk{queue, s_ticket};
-  const int64_t nbig = *n_big;
-  for (int64_t t = tk.first(); t < nbig; t = tk.next()) {
-    tk.prefetch();
-    const int64_t task = big[t];
-    const int64_t b0 = bin_off[task], b1 = bin_off[task + 1];
+  BinFeed feed{queue, big, *n_big, bin_off, rows, nullptr, nullptr, nr};
+  feed.start(s_desc[0]);
+  for (int cur = 0;; cur ^= 1) {
+    const int64_t task = s_desc[cur][0];
+    if (task < 0) break;
+    const int64_t b0 = s_desc[cur][1], b1 = s_desc[cur][2], crow = s_desc[cur][3];
+    feed.step_a();
     for (int64_t p0 = b0 + tid; p0 < b1; p0 += (int64_t)kAccumThreads * kBinBatch) {
       uint32_t c[kBinBatch];
 #pragma unroll
@@ -758,6 +783,7 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
       for (int u = 0; u < kBinBatch; ++u) atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
     }
     __syncthreads();
+    feed.step_b();
     int n = 0;
     for (int w = tid; w < range_words; w += kAccumThreads) {
       n += __popc(bits[w]);
@@ -765,13 +791,14 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
     }
     for (int off = 32; off > 0; off >>= 1) n += lane_xor(n, off);
     if ((tid & 63) == 0) s_part[tid >> 6] = n;
-    __syncthreads();
+    feed.step_c(s_desc[cur ^ 1]);
+    __syncthreads();  // (also: the bitmap is clear before the next bin sets bits)
     if (tid == 0) {
       int tot = 0;
 #pragma unroll
       for (int w = 0; w < kAccumThreads / 64; ++w) tot += s_part[w];
       bin_cnt[task] = tot;
-      atomicAdd(&nnzC[rows[task / nr]], (unsigned long long)tot);
+      atomicAdd(&nnzC[crow], (unsigned long long)tot);
     }
   }
 }
@@ -794,14 +821,15 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
   __shared__ int wpre[kWords];
   const int tid = (int)threadIdx.x;
   for (int c = tid; c < kCols; c += kAccumThreads) acc[c] = A(0);
-  __shared__ int64_t s_ticket[2];
+  __shared__ int64_t s_desc[2][4];
   for (int w = tid; w < kWords; w += kAccumThreads) bits[w] = 0;
-  Tickets tk{queue, s_ticket};
-  const int64_t nbig = *n_big;
-  for (int64_t t = tk.first(); t < nbig; t = tk.next()) {
-    tk.prefetch();
-    const int64_t task = big[t];
-    const int64_t b0 = bin_off[task], b1 = bin_off[task + 1];
+  BinFeed feed{queue, big, *n_big, bin_off, rows, bin_pref, rowptrC, nr};
+  feed.start(s_desc[0]);
+  for (int cur = 0;; cur ^= 1) {
+    const int64_t task = s_desc[cur][0];
+    if (task < 0) break;
+    const int64_t b0 = s_desc[cur][1], b1 = s_desc[cur][2], out0 = s_desc[cur][3];
+    feed.step_a();
     for (int64_t p0 = b0 + tid; p0 < b1; p0 += (int64_t)kAccumThreads * kBinBatch) {
       uint32_t c[kBinBatch];
       A v[kBinBatch];
@@ -819,7 +847,8 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
       }
     }
     __syncthreads();
-    const int64_t r = task / nr, q = task - r * nr;
+    feed.step_b();
+    const int64_t q = task % nr;
     // bitmap word t -> exclusive prefix of the set bits (thread t owns word t)
     const uint32_t wd = tid < kWords ? bits[tid] : 0u;
     int tot;
@@ -829,7 +858,6 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
     // lane = OUTPUT position, so that the stores are coalesced (a thread that walks its own word writes
     // 64 different cache lines per store instruction: measured 2x slower for the whole kernel): find the
     // word that holds the o-th set bit (binary search over the prefixes), then the bit inside the word
-    const int64_t out0 = rowptrC[rows[r]] + (bin_pref[task] - bin_pref[r * nr]);
     const int64_t col0 = q << kLgRange<T>;
     for (int o = tid; o < tot; o += kAccumThreads) {
       int lo = 0, hi = kWords;  // last word whose prefix is <= o
@@ -858,8 +886,10 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
         acc[idx] = A(0);
       }
     }
+    feed.step_c(s_desc[cur ^ 1]);
     __syncthreads();
     if (wd) bits[tid] = 0;
+    __syncthreads();  // the bitmap is clear before the next bin sets bits
   }
 }
 
@@ -880,13 +910,25 @@ __global__ __launch_bounds__(256) void spspmm_large_classify_kernel(const int64_
     if (n == 0) bin_cnt[task] = 0;
   }
   const int cls = n == 0 ? -1 : (n <= kSmallCap ? 0 : 1);
+  // one atomic per workgroup and list (the two counters are hot addresses: ~12 ns per atomic, serialised)
+  __shared__ int s_cnt[2][4];
+  __shared__ unsigned long long s_base[2];
+  const int wid = (int)(threadIdx.x >> 6);
+  unsigned long long m[2];
   for (int k = 0; k < 2; ++k) {
-    const unsigned long long m = __ballot(cls == k);
-    if (m == 0) continue;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&counts[k], (unsigned long long)__popcll(m));
-    base = (unsigned long long)lane_read((int64_t)base, 0);
-    if (cls == k) lists[(int64_t)k * ntask + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = task;
+    m[k] = __ballot(cls == k);
+    if (lane == 0) s_cnt[k][wid] = __popcll(m[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int tot = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+    s_base[threadIdx.x] = tot ? atomicAdd(&counts[threadIdx.x], (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
+  if (cls >= 0) {
+    int before = 0;
+    for (int w = 0; w < wid; ++w) before += s_cnt[cls][w];
+    lists[(int64_t)cls * ntask + (int64_t)s_base[cls] + before + __popcll(m[cls] & ((1ull << lane) - 1ull))] = task;
   }
 }
 
