@@ -1,9 +1,13 @@
-"""Build A/B variants of libtsamd.so with -D overrides into build/variants/<name>.so."""
+"""Build A/B variants of libtsamd.so with -D overrides into build/ab/<name>.so (build/variants/ is
+gpurun-ignored).  Usage: python scripts/variants.py base: fast:TSAMD_UNROLL=8,TSAMD_WPB=2"""
 import os, subprocess, sys, concurrent.futures as cf
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'pytorch_sparse_amd', 'csrc')
 OUT = os.path.join(ROOT, 'build', os.environ.get('TSAMD_VARIANT_DIR', 'ab'))
-def build(name, defs, sources=('api.hip', 'spmm.hip', 'spmm_bw.hip', 'convert.hip')):
+def build(name, defs, sources=None):
+    # every translation unit: a variant that is preloaded in front of the shipped library (LD_PRELOAD for the
+    # torch-op path) or selected with TSAMD_LIB (ctypes path) must resolve all tsamd_* symbols by itself
+    sources = sources or sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
     os.makedirs(OUT, exist_ok=True)
     so = os.path.join(OUT, name + '.so')
     cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
