@@ -123,12 +123,14 @@ def cpu_baseline(rowptr, col, value, x, reduce, out):
 
 
 def secondary(dev, cpu=True):
-    """BASELINE.json configs[1..3] at their stated size (tests/baseline_configs.py): C2, C3 (value-less and
-    with values, forward + backward), C4 -- each with ms, roofline, cpu_baseline and whole-output parity."""
+    """BASELINE.json configs[0..3] at their stated size (tests/baseline_configs.py): C1 (legacy spmm), C2 forward, C2
+    value-grad + sum forward/backward, C3 (value-less and with values, forward + backward), construct / coalesce /
+    transpose / t() on the C4 input, C4, SpSpMM stress -- each with ms, roofline, cpu_baseline and whole-output parity."""
     from tests import baseline_configs as bc
     res = []
-    for fn in (lambda: bc.run_c2(dev, cpu=cpu), lambda: bc.run_c3(dev, False, cpu=cpu),
-               lambda: bc.run_c3(dev, True, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu),
+    for fn in (lambda: bc.run_c1(dev, cpu=cpu), lambda: bc.run_c2(dev, cpu=cpu), lambda: bc.run_c2_backward(dev, cpu=cpu),
+               lambda: bc.run_c3(dev, False, cpu=cpu), lambda: bc.run_c3(dev, True, cpu=cpu),
+               lambda: bc.run_construct(dev, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu),
                lambda: bc.run_spspmm(dev, 'stress', cpu=False, iters=2)):  # SURVEY 8d stress row: property checks
         try:
             res.append(fn())

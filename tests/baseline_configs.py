@@ -94,11 +94,19 @@ def ref_spmm_cpu(rp, c, v, x, reduce):
 # parity statistics
 # ------------------------------------------------------------------------------------------------
 def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5):
-    """fp32 SpMM-sum/mean, WHOLE output against the reference CPU kernel's fp32 output:
-         max_err_over_l1 = max |a - b| / sum_e |v_e x_e|      (bar: 1e-5, tests/util.py)
-         max_rel / frac_rel_gt_tol: the element-wise |a - b| / |b| statistic (it blows up on
-             cancelled sums, for the reference's own fp32 result as well -- which is why the same
-             figures are given for both against the fp64 result of the reference kernel).
+    """fp32 SpMM-sum/mean, WHOLE output against the reference CPU kernel's fp32 output.
+
+    The north star's "fp32 within 1e-5 rel" is checked in the two readings it admits:
+      * norm-wise (the pass / fail bar, tests/util.py):  |a - b| <= 1e-5 * sum_e |v_e x_e|  for EVERY element,
+        for ours-vs-reference and for ours-vs-fp64;
+      * element-wise |a - b| <= 1e-5 * |b|, which no fp32 kernel with a different summation order than
+        spmm_cpu.cpp:73-87 can meet on cancelled sums (the reference's own result misses it against fp64 just
+        as often) -- so it is required only where the sum is well conditioned:
+            n_rel_gt_1e_5_where_ref_ge_1e_1_l1   elements with |b| >= 0.1 L1 violating it   (must be 0)
+            n_rel_gt_1e_5_where_ref_ge_1e_2_l1   the same for |b| >= 0.01 L1               (reported; the worst
+                                                 case there is 100 * (2.0e-7 + 3.7e-7) = 5.7e-5)
+        and the unconditional figures max_rel_vs_ref / frac_rel_vs_ref_gt_1e_5 are printed next to the same
+        two figures of the reference against fp64.
     All operands are host tensors except out_gpu."""
     a = out_gpu.detach().cpu()
     if ref_out is None:
@@ -106,15 +114,26 @@ def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5):
     l1 = ref_spmm_cpu(rp, c, None if v is None else v.abs(), x.abs(), 'sum')[0].double()
     exact = ref_spmm_cpu(rp, c, None if v is None else v.double(), x.double(), 'sum')[0]
     l1c = l1.clamp(min=1e-30)
-    d = (a.double() - ref_out.double()).abs()
-    relb = d / ref_out.double().abs().clamp(min=1e-30)
+    refd = ref_out.double()
+    d = (a.double() - refd).abs()
+    relb = d / refd.abs().clamp(min=1e-30)
+    bad = relb > 1e-5
     e_ours = (a.double() - exact).abs() / l1c
-    e_ref = (ref_out.double() - exact).abs() / l1c
-    res = dict(elements=int(a.numel()), against='reference CPU kernel, whole output',
+    e_ref = (refd - exact).abs() / l1c
+    rel_ref64 = (refd - exact).abs() / exact.abs().clamp(min=1e-30)
+    res = dict(elements=int(a.numel()),
+               against='reference CPU kernel (csrc/cpu/spmm_cpu.cpp via oracle/_ref), whole output; criterion: '
+                       '|gpu - ref| <= 1e-5 * sum_e|v_e x_e| for every element (and the same against fp64), '
+                       'plus |gpu - ref| <= 1e-5 * |ref| for every element with |ref| >= 0.1 * sum_e|v_e x_e|',
                max_err_over_l1=float((d / l1c).max()), tol_over_l1=tol,
-               max_rel_vs_ref=float(relb.max()), frac_rel_vs_ref_gt_1e_5=float((relb > 1e-5).double().mean()),
+               max_rel_vs_ref=float(relb.max()), frac_rel_vs_ref_gt_1e_5=float(bad.double().mean()),
+               n_rel_gt_1e_5_where_ref_ge_1e_1_l1=int((bad & (refd.abs() >= 1e-1 * l1)).sum()),
+               n_rel_gt_1e_5_where_ref_ge_1e_2_l1=int((bad & (refd.abs() >= 1e-2 * l1)).sum()),
+               n_elements_ref_ge_1e_2_l1=int((refd.abs() >= 1e-2 * l1).sum()),
+               ref_vs_fp64_frac_rel_gt_1e_5=float((rel_ref64 > 1e-5).double().mean()),
                ours_vs_fp64_over_l1=float(e_ours.max()), ref_vs_fp64_over_l1=float(e_ref.max()))
-    res['ok'] = bool(res['max_err_over_l1'] <= tol and res['ours_vs_fp64_over_l1'] <= tol)
+    res['ok'] = bool(res['max_err_over_l1'] <= tol and res['ours_vs_fp64_over_l1'] <= tol and
+                     res['n_rel_gt_1e_5_where_ref_ge_1e_1_l1'] == 0)
     return res
 
 
@@ -325,6 +344,25 @@ def run_spspmm(dev, kind='c4', cpu=True, iters=5):
                              scope='whole op incl. its host syncs; bytes = compulsory (SURVEY 8d)'))
     if not cpu and kind != 'c4':
         res['parity'] = spspmm_properties(A, At, C)
+    if kind == 'c4':
+        # what the reference itself does with GPU operands (torch_sparse/matmul.py:94-111): torch.sparse.mm on
+        # device tensors = PyTorch-ROCm's hipSPARSE SpGEMM.  Context for a maintainer, not a target.
+        try:
+            Ad, Bd = A.to_torch_sparse_coo_tensor(), At.to_torch_sparse_coo_tensor()
+            Cd = torch.sparse.mm(Ad, Bd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Cd = torch.sparse.mm(Ad, Bd)
+            torch.cuda.synchronize()
+            td = (time.perf_counter() - t0) * 1e3
+            res['reference_gpu_route'] = dict(what='torch.sparse.mm on device COO tensors (PyTorch-ROCm hipSPARSE SpGEMM), '
+                                                   'the call torch_sparse/matmul.py:104 makes for GPU inputs; 1 warm-up + 1 run',
+                                              ms=round(td, 2), gproducts_per_s=round(P / td / 1e6, 3), nnz=int(Cd._nnz()),
+                                              speedup_of_this_repo=round(td / ms, 2))
+            del Ad, Bd, Cd
+        except Exception as exc:  # noqa: BLE001
+            res['reference_gpu_route'] = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
+        torch.cuda.empty_cache()
     if cpu:
         Ac, Bc = A.cpu().to_torch_sparse_coo_tensor(), At.cpu().to_torch_sparse_coo_tensor()
         cores = os.cpu_count() or 1
@@ -343,4 +381,282 @@ def run_spspmm(dev, kind='c4', cpu=True, iters=5):
         err = float(((val.cpu().double() - ev).abs() / l1.cpu().double().clamp(min=1e-30)).max()) if idx_ok else float('inf')
         res['parity'] = dict(against='torch.sparse.mm (CPU), whole output', nnz=int(nnzC), index_bit_exact=bool(idx_ok),
                              value_max_err_over_l1=err, tol_over_l1=1e-5, ok=bool(idx_ok and err <= 1e-5))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers of the rows below
+# ------------------------------------------------------------------------------------------------
+def wall_ms(fn, iters=5, warm=1):
+    """Median host wall time of fn() with the device idle on both sides -- for calls that contain host
+    syncs (data-dependent output sizes), where HIP events on the stream would miss the host part."""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def _roof(nbytes, ms, scope):
+    return dict(bound='hbm', algorithmic_bytes=int(nbytes), achieved=round(nbytes / ms / 1e6, 1), peak=HBM_PEAK_GBS,
+                unit='GB/s', frac=round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), scope=scope)
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+# ------------------------------------------------------------------------------------------------
+# C1: legacy torch_sparse.spmm(index, value, 1000, 1000, x) on 5 000 unsorted draws, F = 16 fp32
+# ------------------------------------------------------------------------------------------------
+def run_c1(dev, cpu=True, iters=50):
+    """BASELINE.json configs[0] at its exact size.  Inputs and expected output come from the fixture
+    tests/golden/py7_c1_spmm.npz, written by RUNNING the reference's torch_sparse/spmm.py:5-31
+    (make_golden.py part7).  The CPU baseline is that pipeline (index_select * value, scatter_add)
+    restated with ATen on the host, one thread (OpenMP fork/join dominates tiny inputs)."""
+    import pytorch_sparse_amd as ts
+    z = np.load(os.path.join(GOLDEN, 'py7_c1_spmm.npz'))
+    m, n = int(z['m']), int(z['n'])
+    index = torch.from_numpy(z['index']).to(dev)
+    value = torch.from_numpy(z['value']).to(dev)
+    x = torch.from_numpy(z['mat']).to(dev)
+    E, K = index.size(1), x.size(1)
+    fn = lambda: ts.spmm(index, value, m, n, x)  # noqa: E731
+    ms_wall = wall_ms(fn, iters=iters, warm=3)
+    ms_dev = gpu_ms(fn, iters=iters, warm=1)
+    out = fn()
+    ba = b_alg(E, m, K, 4, True, False) + E * 16  # + the (row, col) ids the sort reads once more
+    res = dict(config='c1', workload='configs[0]: torch_sparse.spmm(index, value, 1000, 1000, x), %d unsorted COO draws '
+                                     '(duplicates kept), F=%d fp32' % (E, K),
+               dtype='f32', ms=round(ms_wall, 4), ms_device=round(ms_dev, 4), gedges_per_s=round(E / ms_wall / 1e6, 5),
+               roofline=_roof(ba, ms_wall, 'whole call (order probe + host sync + radix sort + ind2ptr + SpMM), host wall '
+                              'time: launch/sync latency bound at this size, the byte roofline does not apply'))
+    ref, l1 = torch.from_numpy(z['out']).double(), torch.from_numpy(z['l1']).double()
+    a = out.cpu().double()
+    d = (a - ref).abs()
+    bad = d > 1e-5 * ref.abs()
+    par = dict(against='output of the reference Python torch_sparse.spmm on the same inputs (fixture py7_c1_spmm.npz); '
+                       'criterion |gpu - ref| <= 1e-5 * sum|v x| everywhere and <= 1e-5 * |ref| where |ref| >= 0.1 sum|v x|',
+               elements=int(a.numel()), max_err_over_l1=float((d / l1.clamp(min=1e-30)).max()), tol_over_l1=1e-5,
+               max_rel_vs_ref=float((d / ref.abs().clamp(min=1e-30)).max()),
+               n_rel_gt_1e_5_where_ref_ge_1e_1_l1=int((bad & (ref.abs() >= 1e-1 * l1)).sum()),
+               n_rel_gt_1e_5_where_ref_ge_1e_2_l1=int((bad & (ref.abs() >= 1e-2 * l1)).sum()),
+               vs_fp64_over_l1=float(((a - torch.from_numpy(z['out64'])).abs() / l1.clamp(min=1e-30)).max()))
+    par['ok'] = bool(par['max_err_over_l1'] <= 1e-5 and par['vs_fp64_over_l1'] <= 1e-5 and
+                     par['n_rel_gt_1e_5_where_ref_ge_1e_1_l1'] == 0)
+    res['parity'] = par
+    if cpu:
+        ic, vc, xc = index.cpu(), value.cpu(), x.cpu()
+        torch.set_num_threads(1)
+
+        def ref_pipeline():  # torch_sparse/spmm.py:24-30
+            o = xc.index_select(-2, ic[1]) * vc.unsqueeze(-1)
+            return torch.zeros(m, K).index_add_(0, ic[0], o)
+        t, ro, runs = cpu_time(ref_pipeline, budget_s=2.0, max_reps=200)
+        torch.set_num_threads(os.cpu_count() or 1)
+        res['cpu_baseline'] = dict(value=round(E / t / 1e9, 5), unit='GEdges/s', cores=1, kind='port', ms=round(t * 1e3, 4),
+                                   sample='full workload; torch_sparse/spmm.py:24-30 restated with ATen '
+                                          '(index_select * value, index_add_), best of %d' % runs)
+        res['cpu_baseline']['port_matches_fixture'] = bool(torch.allclose(ro, torch.from_numpy(z['out']), rtol=1e-5, atol=1e-6))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# construct / coalesce / transpose / t() on the 7.5 M-entry config-4 input
+# ------------------------------------------------------------------------------------------------
+def run_construct(dev, cpu=True, iters=5):
+    """SURVEY 8a rows a9-a12 on BASELINE.json configs[3]'s input (500k x 500k, 7.5 M unsorted uniform draws):
+    SparseTensor(row, col, value) (sort-on-construct + rowptr), functional coalesce, functional transpose and
+    t() (csr2csc sort + permutation).  Index outputs are compared bit-for-bit with the numpy restatement of the
+    reference Python (oracle/np_oracle.py, pinned to fixtures written by the reference itself); the CPU baseline
+    is that pipeline (torch_sparse/storage.py:149-162, 431-466) restated with ATen on the host."""
+    import pytorch_sparse_amd as ts
+    from pytorch_sparse_amd import synth
+    from oracle import np_oracle as npo
+    m = n = 500000
+    E = 7500000
+    row, col = synth.uniform_edges(m, n, E, seed=0, device=dev)
+    val = synth.values(E, device=dev)
+    index = torch.stack([row, col])
+    s = 4
+
+    def ctor():
+        A = ts.SparseTensor(row=row, col=col, value=val, sparse_sizes=(m, n))
+        A.storage.rowptr()
+        return A
+    A = ctor()
+
+    def t_fresh():
+        st = A.storage
+        st._csr2csc = None
+        st._csc2csr = None
+        st._colptr = None
+        st._colcount = None
+        return A.t()
+    ms = dict(construct=wall_ms(ctor, iters), coalesce=wall_ms(lambda: ts.coalesce(index, val, m, n), iters),
+              transpose=wall_ms(lambda: ts.transpose(index, val, m, n), iters), t=wall_ms(t_fresh, iters))
+    ci, cv = ts.coalesce(index, val, m, n)
+    ti, tv = ts.transpose(index, val, m, n)
+    At = t_fresh()
+    E2 = ci.size(1)
+    nbytes = dict(construct=E * (16 + s) + E * (16 + s) + (m + 1) * 8, coalesce=E * (16 + s) + E2 * (16 + s),
+                  transpose=E * (16 + s) + E2 * (16 + s), t=E * (16 + s) + E * (16 + s) + E * 8)
+    res = dict(config='construct', dtype='i64 ids + f32 values',
+               workload='a9-a12 on the configs[3] input: %d unsorted COO draws over 500k x 500k (%d after coalescing)' % (E, E2),
+               ms={k: round(v, 4) for k, v in ms.items()},
+               mentries_per_s={k: round(E / v / 1e3, 1) for k, v in ms.items()},
+               roofline={k: _roof(nbytes[k], ms[k], 'whole call incl. host syncs; bytes = E(16+s) in + E\'(16+s) out '
+                                  '(SURVEY 8d; the radix passes are implementation cost)') for k in ms})
+    res['ms_total'] = round(sum(ms.values()), 4)
+    # ---- parity: every index output bit-exact against the numpy restatement, on the host ----
+    rn, cn, vn = row.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    rs, cs, perm = npo.sort_coo(rn, cn, m, n)
+    ar, ac, av = A.coo()
+    rowptr_ref = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rs, minlength=m), out=rowptr_ref[1:])
+    par = dict(against='oracle/np_oracle.py (reference Python restated, pinned to reference-written fixtures), whole outputs',
+               entries=E,
+               construct_row_col_bit_exact=bool(np.array_equal(ar.cpu().numpy(), rs) and np.array_equal(ac.cpu().numpy(), cs)),
+               construct_value_bit_exact=bool(np.array_equal(av.cpu().numpy(), vn[perm])),
+               construct_rowptr_bit_exact=bool(np.array_equal(A.storage.rowptr().cpu().numpy(), rowptr_ref)))
+    orow, ocol, oval = npo.coalesce(rn, cn, vn, m, n)
+    par['coalesce_index_bit_exact'] = bool(np.array_equal(ci.cpu().numpy(), np.stack([orow, ocol])))
+    par['coalesce_value_max_abs_err'] = float(np.abs(cv.cpu().numpy().astype(np.float64) - oval.astype(np.float64)).max())
+    par['coalesce_value_bit_exact'] = bool(np.array_equal(cv.cpu().numpy(), oval))
+    trow, tcol, tval = npo.transpose(rn, cn, vn, m, n)
+    par['transpose_index_bit_exact'] = bool(np.array_equal(ti.cpu().numpy(), np.stack([trow, tcol])))
+    par['transpose_value_max_abs_err'] = float(np.abs(tv.cpu().numpy().astype(np.float64) - tval.astype(np.float64)).max())
+    p2 = npo.csr2csc(rs, cs, m, n)
+    tr, tc, tvv = At.coo()
+    par['t_row_col_bit_exact'] = bool(np.array_equal(tr.cpu().numpy(), cs[p2]) and np.array_equal(tc.cpu().numpy(), rs[p2]))
+    par['t_value_bit_exact'] = bool(np.array_equal(tvv.cpu().numpy(), vn[perm][p2]))
+    par['csr2csc_bit_exact'] = bool(np.array_equal(A.storage.csr2csc().cpu().numpy(), p2))
+    par['ok'] = bool(all(v for k, v in par.items() if k.endswith('bit_exact') and k != 'coalesce_value_bit_exact') and
+                     par['coalesce_value_max_abs_err'] <= 1e-6 and par['transpose_value_max_abs_err'] <= 1e-6)
+    res['parity'] = par
+    if cpu:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        rc, cc, vc = row.cpu(), col.cpu(), val.cpu()
+        r = _ref_ops()
+
+        def ref_construct():  # storage.py:149-162 + rowptr (storage.py:193)
+            idx = rc * n + cc
+            p = idx.argsort()
+            r2, c2, v2 = rc[p], cc[p], vc[p]
+            rp = r.ind2ptr(r2, m) if r is not None else torch._convert_indices_from_coo_to_csr(r2, m)
+            return r2, c2, v2, rp
+
+        def ref_coalesce():  # coalesce.py -> storage.py:149-162 + 431-466 (segment_csr = index_add_ over run ids)
+            idx = rc * n + cc
+            p = idx.argsort()
+            ids = idx[p]
+            mask = torch.ones_like(ids, dtype=torch.bool)
+            mask[1:] = ids[1:] > ids[:-1]
+            r2, c2 = rc[p][mask], cc[p][mask]
+            seg = mask.cumsum(0) - 1
+            v2 = torch.zeros(int(r2.numel()), dtype=vc.dtype).index_add_(0, seg, vc[p])
+            return r2, c2, v2
+        t1, _, n1 = cpu_time(ref_construct, budget_s=6.0, max_reps=1)
+        t2, _, n2 = cpu_time(ref_coalesce, budget_s=6.0, max_reps=1)
+        res['cpu_baseline'] = dict(value=round(E / t1 / 1e6, 2), unit='Mentries/s (construct)', cores=cores, kind='port',
+                                   ms=dict(construct=round(t1 * 1e3, 1), coalesce=round(t2 * 1e3, 1)),
+                                   sample='full workload; torch_sparse/storage.py:149-162,431-466 restated with ATen on the '
+                                          'host (argsort of row*N+col, gathers, ind2ptr / mask + index_add_), best of %d' % n1)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# C2 backward: value gradient (SDDMM) and sum forward + both gradients through the autograd op
+# ------------------------------------------------------------------------------------------------
+def run_c2_backward(dev, cpu=True, iters=10):
+    """SURVEY 8a rows a3 / a4 at config-2 size (2^20 R-MAT, F = 64 fp32): tsamd_spmm_value_bw alone, and
+    adj.matmul(x) + backward(g) with both gradients through torch.ops.torch_sparse.spmm_sum.  CPU baseline and
+    checker: the compiled reference's autograd op (csrc/spmm.cpp:55-113 over csrc/cpu/spmm_cpu.cpp:103-152 --
+    its value gradient is single-threaded)."""
+    import pytorch_sparse_amd as ts
+    from pytorch_sparse_amd import synth
+    from pytorch_sparse_amd import _native as nat
+    rp, c, n = rmat_graph(20, 20, dev)
+    E, K, s = c.numel(), 64, 4
+    v = synth.values(E, device=dev)
+    x = synth.features(n, K, device=dev)
+    g = synth.features(n, K, seed=3, device=dev)
+    A = ts.SparseTensor(rowptr=rp, col=c, value=v.clone().requires_grad_(), sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    A.storage.fill_cache_()
+    row = A.storage.row()
+    vb_ms = gpu_ms(lambda: nat.spmm_value_bw(row, rp, c, x, g, 'sum'), iters=iters)
+    xr = x.clone().requires_grad_()
+
+    def fwbw():
+        xr.grad = None
+        A.storage.value().grad = None
+        out = A.matmul(xr, 'sum')
+        out.backward(g)
+        return out
+    fb_ms = gpu_ms(fwbw, iters=iters)
+    out = fwbw()
+    gval, gmat = A.storage.value().grad, xr.grad
+    b_vb = E * (16 + K * s + s) + n * K * s          # SURVEY 8d "value-grad SDDMM"
+    b_fw = b_alg(E, n, K, s, True, False)
+    b_gm = b_alg(E, n, K, s, True, False) + E * 8    # A^T G on the CSC view, entries read through csr2csc
+    res = dict(config='c2_backward', dtype='f32',
+               workload='configs[1] graph (2^20 R-MAT, E=%d), F=64 fp32: value gradient alone; sum forward + grad_value + '
+                        'grad_mat through adj.matmul(x).backward(g)' % E,
+               value_bw_ms=round(vb_ms, 4), fw_bw_ms=round(fb_ms, 4), gedges_per_s_value_bw=round(E / vb_ms / 1e6, 3),
+               gedges_per_s_fw_bw=round(E / fb_ms / 1e6, 3),
+               roofline=_roof(b_vb, vb_ms, 'spmm_value_bw_kernel; bytes = E(16 + F s + s) + M F s (SURVEY 8d)'),
+               roofline_fw_bw=_roof(b_fw + b_vb + b_gm, fb_ms, 'three kernels families of one training step: forward B_alg + '
+                                    'value-grad bytes + B_alg of A^T G (+8 E for csr2csc)'))
+    # independent fp64 yardsticks with ATen on the device (chunked gathers), none of the kernels under test
+    ev = torch.empty(E, dtype=torch.float64, device=dev)
+    l1v = torch.empty(E, dtype=torch.float64, device=dev)
+    for a0 in range(0, E, 1 << 22):
+        sl = slice(a0, min(E, a0 + (1 << 22)))
+        xe, ge = x[c[sl]].double(), g[row[sl]].double()
+        ev[sl] = (xe * ge).sum(1)
+        l1v[sl] = (xe.abs() * ge.abs()).sum(1)
+    l1v.clamp_(min=1e-30)
+    par = dict(grad_value_vs_fp64_over_l1=float(((gval.double() - ev).abs() / l1v).max()), tol_over_l1=1e-5, elements_value=E)
+    if cpu:
+        r = _ref_ops()
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        st = A.storage
+        rowc, rpc, cc, colptrc, permc = row.cpu(), rp.cpu(), c.cpu(), st.colptr().cpu(), st.csr2csc().cpu()
+        vc, xc, gc = v.cpu(), x.cpu(), g.cpu()
+        if r is not None:
+            def ref_fwbw():
+                vv, xx = vc.clone().requires_grad_(), xc.clone().requires_grad_()
+                o = r.spmm_sum(rowc, rpc, cc, vv, colptrc, permc, xx)
+                o.backward(gc)
+                return o.detach(), vv.grad, xx.grad
+            t, (ro, rgv, rgm), runs = cpu_time(ref_fwbw, budget_s=25.0, max_reps=1)
+            res['cpu_baseline'] = dict(value=round(E / t / 1e9, 4), unit='GEdges/s (forward + both gradients)', cores=cores,
+                                       kind='reference', ms=round(t * 1e3, 1),
+                                       sample='full workload, compiled reference autograd op (value gradient serial, '
+                                              'spmm_cpu.cpp:134-147), best of %d' % runs)
+            par['against'] = ('compiled reference autograd op (csrc/spmm.cpp:55-113), whole grad_value [E] and grad_mat [N,F]; '
+                              'criterion |gpu - ref| <= 1e-5 * L1 mass of the sum behind each element, ours and the reference\'s '
+                              'also against fp64')
+            par['grad_value_vs_ref_over_l1'] = float(((gval.cpu().double() - rgv.double()).abs() / l1v.cpu()).max())
+            par['ref_grad_value_vs_fp64_over_l1'] = float(((rgv.double() - ev.cpu()).abs() / l1v.cpu()).max())
+            row_t, v_t = rowc[permc], vc[permc]
+            gm = sum_parity(gmat, colptrc, row_t, v_t, gc, rgm)
+            par['grad_mat'] = {k: gm[k] for k in ('elements', 'max_err_over_l1', 'ours_vs_fp64_over_l1', 'ref_vs_fp64_over_l1',
+                                                  'n_rel_gt_1e_5_where_ref_ge_1e_1_l1', 'n_rel_gt_1e_5_where_ref_ge_1e_2_l1',
+                                                  'max_rel_vs_ref', 'ok')}
+            fw = sum_parity(out.detach(), rpc, cc, vc, xc, ro)
+            par['forward_max_err_over_l1'] = fw['max_err_over_l1']
+            par['ok'] = bool(par['grad_value_vs_fp64_over_l1'] <= 1e-5 and par['grad_value_vs_ref_over_l1'] <= 1e-5 and
+                             gm['ok'] and fw['ok'])
+    if 'ok' not in par:
+        par['against'] = 'fp64 ATen gathers on the device (grad_value only; no CPU leg in this run)'
+        par['ok'] = bool(par['grad_value_vs_fp64_over_l1'] <= 1e-5)
+    res['parity'] = par
     return res

@@ -26,7 +26,12 @@ container (it cannot travel to the GPU box; the fixtures can).
 
   part 6  py6_random_cases.npz  : 672 randomised small cases of the whole Python surface (cases6.py).
 
-Usage:  python tests/golden/make_golden.py [part1] ... [part6]   (needs /root/reference)
+  part 7  py7_c1_spmm.npz       : BASELINE.json configs[0] at its exact size -- the reference's legacy
+                                  torch_sparse.spmm(index, value, 1000, 1000, x) on 5 000 UNSORTED
+                                  uniform draws (seed 0; duplicates occur), F = 16 fp32 -- inputs and
+                                  the reference's output (also in fp64, the well-conditioned yardstick).
+
+Usage:  python tests/golden/make_golden.py [part1] ... [part7]   (needs /root/reference)
 """
 import os
 import subprocess
@@ -425,9 +430,42 @@ def part6():
     subprocess.check_call([sys.executable, '-c', PART6], env=env)
 
 
+PART7 = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ['TS_SCRATCH'])
+from torch_sparse import spmm
+import importlib.util                     # the input generator only, loaded by path: importing the package
+spec = importlib.util.spec_from_file_location('synth', os.path.join(os.environ['TS_ROOT'], 'pytorch_sparse_amd', 'synth.py'))
+synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)   # would register torch_sparse:: twice
+m = n = 1000
+row, col = synth.uniform_edges(m, n, 5000, seed=0)
+index = torch.stack([row, col])
+value = synth.values(5000, seed=1)
+x = synth.features(n, 16, seed=2)
+out = spmm(index, value, m, n, x)                        # torch_sparse/spmm.py:5-31
+out64 = spmm(index, value.double(), m, n, x.double())
+l1 = spmm(index, value.abs().double(), m, n, x.abs().double())
+np.savez_compressed(os.path.join(os.environ['TS_OUT'], 'py7_c1_spmm.npz'), index=index.numpy(), value=value.numpy(),
+                    mat=x.numpy(), m=m, n=n, out=out.numpy(), out64=out64.numpy(), l1=l1.numpy())
+print('part 7: C1 fixture written; |out|max = %g' % float(out.abs().max()))
+'''
+
+
+def part7():
+    scratch, pkg = make_scratch(['spmm'], SPMM_SRCS)
+    with open(os.path.join(pkg, '__init__.py'), 'w') as f:
+        f.write("import os, torch\n"
+                "torch.ops.load_library(os.path.join(os.path.dirname(__file__), '_ops_cpu.so'))\n"
+                "from .storage import SparseStorage\nfrom .tensor import SparseTensor\n"
+                "from .spmm import spmm\n")
+    env = dict(os.environ, TS_SCRATCH=scratch, TS_OUT=HERE, TS_ROOT=ROOT, OMP_NUM_THREADS='1')
+    subprocess.check_call([sys.executable, '-c', PART7], env=env)
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree %s not present' % REF)
-    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4', 'part5', 'part6']
+    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4', 'part5', 'part6', 'part7']
     for name in todo:  # e.g. `make_golden.py part3` regenerates only the py3_* fixtures
-        {'part1': part1, 'part2': part2, 'part3': part3, 'part4': part4, 'part5': part5, 'part6': part6}[name]()
+        {'part1': part1, 'part2': part2, 'part3': part3, 'part4': part4, 'part5': part5, 'part6': part6,
+         'part7': part7}[name]()

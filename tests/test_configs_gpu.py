@@ -1,5 +1,5 @@
-"""BASELINE.json configs C2 / C3 / C4 at their STATED size, whole-output parity:
-the same functions bench.py puts into the `secondary` array of its JSON line."""
+"""BASELINE.json configs C1 / C2 / C3 / C4 at their STATED size plus the construct / coalesce / transpose and
+backward rows, whole-output parity: the same functions bench.py puts into the `secondary` array of its JSON line."""
 import pytest
 import torch
 
@@ -14,12 +14,50 @@ def ops():
     return torch.ops.torch_sparse
 
 
+def test_c1_legacy_spmm_exact_config(dev, ops):
+    """configs[0]: torch_sparse.spmm(index, value, 1000, 1000, x) on 5 000 unsorted draws, F = 16 fp32, against
+    the output the reference's own Python produced for these inputs (tests/golden/py7_c1_spmm.npz)."""
+    r = bc.run_c1(dev, iters=5)
+    p = r['parity']
+    assert p['elements'] == 1000 * 16
+    assert p['max_err_over_l1'] <= 1e-5 and p['vs_fp64_over_l1'] <= 1e-5, p
+    assert p['n_rel_gt_1e_5_where_ref_ge_1e_1_l1'] == 0, p
+    assert r['cpu_baseline']['port_matches_fixture']
+    assert p['ok']
+
+
+def test_construct_coalesce_transpose_7m5(dev, ops):
+    """a9-a12 on the 7.5 M-entry configs[3] input: sorted (row, col), rowptr, coalesced / transposed index and the
+    t() permutation bit-exact against the numpy restatement of the reference Python (independent of the product's sort)."""
+    r = bc.run_construct(dev, iters=2)
+    p = r['parity']
+    for k in ('construct_row_col_bit_exact', 'construct_value_bit_exact', 'construct_rowptr_bit_exact',
+              'coalesce_index_bit_exact', 'transpose_index_bit_exact', 't_row_col_bit_exact', 't_value_bit_exact',
+              'csr2csc_bit_exact'):
+        assert p[k], (k, p)
+    assert p['coalesce_value_max_abs_err'] <= 1e-6 and p['transpose_value_max_abs_err'] <= 1e-6, p
+    assert p['ok']
+
+
+def test_c2_value_grad_and_sum_fw_bw(dev, ops):
+    """a3 / a4 at config-2 size: grad_value and grad_mat of adj.matmul(x).backward(g) against the compiled
+    reference's autograd op, whole outputs, 1e-5 of the L1 mass of each sum."""
+    r = bc.run_c2_backward(dev, iters=2)
+    p = r['parity']
+    assert p['grad_value_vs_fp64_over_l1'] <= 1e-5 and p['grad_value_vs_ref_over_l1'] <= 1e-5, p
+    assert p['grad_mat']['ok'] and p['grad_mat']['elements'] == (1 << 20) * 64, p
+    assert p['forward_max_err_over_l1'] <= 1e-5, p
+    assert p['ok']
+
+
 def test_c2_sum_f32_full_output(dev, ops):
     """2^20 R-MAT, F = 64 fp32: all 67 M outputs against the compiled reference CPU kernel."""
     r = bc.run_c2(dev, iters=3)
     p = r['parity']
     assert p['elements'] == (1 << 20) * 64
     assert p['max_err_over_l1'] <= 1e-5 and p['ours_vs_fp64_over_l1'] <= 1e-5, p
+    # element-wise 1e-5 relative wherever the sum is well conditioned (|ref| >= 0.1 * L1 mass)
+    assert p['n_rel_gt_1e_5_where_ref_ge_1e_1_l1'] == 0, p
     # not less accurate than the reference's own sequential fp32 sum
     assert p['ours_vs_fp64_over_l1'] <= max(p['ref_vs_fp64_over_l1'], 2e-7) * 1.5, p
 
