@@ -192,6 +192,27 @@ int tsamd_spmm_minmax_bw(int dtype, const int64_t *rowptr, const int64_t *col,
                          int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same backward as a PULL over the transposed pattern, for callers that hold the CSC arrays
+ * (SparseTensor.matmul does: the sum backward uses the same three, csrc/spmm.cpp:84,100-108):
+ *   colptr [N+1], csr2csc [E] (CSC position -> CSR entry), row [E] (COO rows of the CSR order).
+ * grad_mat is produced column-parallel without atomics:
+ *   1. one pass over arg_out writes a winner mask per entry (ceil(K/32) words, bit k = "entry e is the
+ *      arg of feature k of its row");
+ *   2. the merge-path SpMM kernel runs on (colptr, row, value) through csr2csc with that mask as a
+ *      per-(entry, feature) predicate:  grad_mat[b, n, k] = sum_{e in column n, bit k set}
+ *      round_T(value[e] * grad_out[b, row[e], k]), accumulated in fp32 (fp64 for f64), rounded once.
+ * Deterministic (fixed summation order), every element of grad_mat written exactly once (no memset of
+ * the result), the device-scope atomics of tsamd_spmm_minmax_bw are gone.  grad_value is computed as
+ * in tsamd_spmm_minmax_bw.  Either output may be NULL.  E must be < 2^32.  Replaces the same ATen
+ * composition (csrc/spmm.cpp:204-242, 264-302). */
+size_t tsamd_spmm_minmax_bw_csc_workspace_bytes(int dtype, int64_t B, int64_t M, int64_t N, int64_t K,
+                                                int64_t E);
+int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const int64_t *col, const void *value,
+                             const void *mat, const void *grad_out, const int64_t *arg_out,
+                             const int64_t *colptr, const int64_t *csr2csc, const int64_t *row,
+                             void *grad_value, void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
+                             int64_t E, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * COO row ids <-> CSR row pointer.  Replace ind2ptr_cuda / ptr2ind_cuda
  * (csrc/cuda/convert_cuda.cu:26-67, csrc/cpu/convert_cpu.cpp:7-57).

@@ -19,6 +19,7 @@ SYMBOLS = [
     'tsamd_gather_rows', 'tsamd_relabel_ids', 'tsamd_spmm_relabelled_workspace_bytes', 'tsamd_spmm_relabelled',
     'tsamd_spmm_value_bw',
     'tsamd_spmm_minmax_bw_workspace_bytes', 'tsamd_spmm_minmax_bw',
+    'tsamd_spmm_minmax_bw_csc_workspace_bytes', 'tsamd_spmm_minmax_bw_csc',
     'tsamd_ind2ptr', 'tsamd_ptr2ind',
     'tsamd_coo_order', 'tsamd_sort_coo_workspace_bytes', 'tsamd_sort_coo',
     'tsamd_coalesce_workspace_bytes', 'tsamd_coalesce_index', 'tsamd_segment_reduce',
@@ -61,6 +62,7 @@ def lib():
         L.tsamd_status_string.restype = ctypes.c_char_p
         L.tsamd_spmm_workspace_bytes.restype = ctypes.c_size_t
         L.tsamd_spmm_minmax_bw_workspace_bytes.restype = ctypes.c_size_t
+        L.tsamd_spmm_minmax_bw_csc_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 
@@ -184,6 +186,31 @@ def spmm_minmax_bw(rowptr, col, value, mat, grad_out, arg_out, want_value=True, 
                                     _i64(K), _i64(E), _ptr(ws), ctypes.c_size_t(ws.numel()),
                                     stream_ptr(mat.device))
     check(st, 'tsamd_spmm_minmax_bw')
+    return gv, gm
+
+
+def spmm_minmax_bw_csc(rowptr, col, value, mat, grad_out, arg_out, colptr, csr2csc, row, want_value=True,
+                       want_mat=True):
+    """C-ABI ``tsamd_spmm_minmax_bw_csc`` (pull formulation over the CSC arrays, no atomics):
+    (grad_value or None, grad_mat or None)."""
+    require_gpu(rowptr, col, value, mat, grad_out, arg_out, colptr, csr2csc, row)
+    dt = dtype_code(mat.dtype)
+    mat, grad_out, arg_out = mat.contiguous(), grad_out.contiguous(), arg_out.contiguous()
+    E = col.numel()
+    N, K = mat.size(-2), mat.size(-1)
+    M = grad_out.size(-2)
+    B = mat.numel() // (N * K) if N * K > 0 else 1
+    gv = torch.empty(E, dtype=mat.dtype, device=mat.device) if want_value else None
+    gm = torch.empty_like(mat) if want_mat else None
+    L = lib()
+    nb = L.tsamd_spmm_minmax_bw_csc_workspace_bytes(dt, _i64(B), _i64(M), _i64(N), _i64(K), _i64(E))
+    ws = workspace(nb, mat.device)
+    with torch.cuda.device(mat.device):
+        st = L.tsamd_spmm_minmax_bw_csc(dt, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(grad_out),
+                                        _ptr(arg_out), _ptr(colptr), _ptr(csr2csc), _ptr(row), _ptr(gv), _ptr(gm),
+                                        _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
+                                        ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
+    check(st, 'tsamd_spmm_minmax_bw_csc')
     return gv, gm
 
 

@@ -33,6 +33,7 @@
 //
 // Deterministic: the partition only depends on rowptr, every combine order is fixed.
 #include "common.h"
+#include "spmm_internal.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -94,6 +95,12 @@ struct Workspace {
   // entries taken through a permutation (tsamd_spmm_permuted): entry e of the CSR is
   // (col[perm[e]], value[perm[e]]) -- the CSC view of a matrix without materialising it
   const int64_t *perm;
+  // masked sum (spmm_masked_sum, the pull formulation of the min/max backward): one record of
+  // `rec_stride` 32-bit words per (batch, entry) -- see WinRecord in spmm_internal.h: the mask words
+  // (bit k of word k / 32 = "feature k of this entry contributes"), then the entry's column id and
+  // value, so that one 32-byte line serves every random access an entry needs
+  const uint32_t *wmask;
+  uint32_t rec_stride, rec_meta;  // words per record; word offset of (id, value lo, value hi)
 };
 
 // ---------------------------------------------------------------------------
@@ -207,11 +214,15 @@ __device__ __forceinline__ void init_acc(typename Traits<T>::acc_t (&val)[VEC], 
 // offset from the partition's first edge (min/max args are kept as 32-bit offsets).
 // c_l / w_l hold the window's column ids / weights, one per lane.  All lanes
 // stay active; slots past `hi` re-read the last valid entry (masked for sums, harmless for min / max).
-template <typename T, int VEC, int RED>
+// MASKED (sums only): e_l holds the window's entry ids; feature j of this lane's packet contributes iff bit
+// (mask_shift + j) of maskk[entry * mask_words] is set, and the product is rounded to the element type
+// before it is added (what value.index_select(0, arg) * grad_out does in SPMMMin/Max::backward).
+template <typename T, int VEC, int RED, bool MASKED = false>
 __device__ __forceinline__ void accumulate_window(
     int lo, int hi, uint32_t wrel, uint32_t c_l, typename Traits<T>::acc_t w_l, bool has_value,
     const T *__restrict__ matk, uint32_t K, int lgG, int g,
-    typename Traits<T>::acc_t (&val)[VEC], uint32_t (&arg)[VEC]) {
+    typename Traits<T>::acc_t (&val)[VEC], uint32_t (&arg)[VEC], uint32_t e_l = 0,
+    const uint32_t *__restrict__ maskk = nullptr, uint32_t mask_words = 0, uint32_t mask_shift = 0) {
   using A = typename Traits<T>::acc_t;
   using P = Pack<T, VEC>;
   // min/max carry (value, arg) per element: fewer gathers in flight keep the VGPR count down
@@ -222,6 +233,7 @@ __device__ __forceinline__ void accumulate_window(
     P x[kU];
     A w[kU];
     int idx[kU];
+    uint32_t mb[MASKED ? kU : 1];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       idx[u] = lo + ((s + u) << lgG) + g;
@@ -230,6 +242,7 @@ __device__ __forceinline__ void accumulate_window(
       const uint32_t c = lane_read(c_l, src);
       w[u] = lane_read(w_l, src);
       x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
+      if constexpr (MASKED) mb[u] = maskk[(uint64_t)lane_read(e_l, src) * mask_words];
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -237,7 +250,10 @@ __device__ __forceinline__ void accumulate_window(
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const A xv = Traits<T>::to_acc(x[u].v[j]);
-        if constexpr (RED == RED_ADD) {
+        if constexpr (RED == RED_ADD && MASKED) {
+          const A p = Traits<T>::round_acc(w[u] * xv);
+          val[j] += (ok && ((mb[u] >> (mask_shift + (uint32_t)j)) & 1u)) ? p : A(0);
+        } else if constexpr (RED == RED_ADD) {
           const A p = w[u] * xv;
           val[j] += ok ? p : A(0);
         } else {
@@ -388,7 +404,7 @@ __device__ __forceinline__ void write_carry(void *cval, int64_t *carg, uint64_t 
 // ---------------------------------------------------------------------------
 // SHORT: instantiate the "short rows side by side" path (launched for rows of <= 128 bytes only: its
 // registers would cost the wide-row instantiation two waves per SIMD)
-template <typename T, int VEC, int RED, bool SHORT>
+template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
     const T *__restrict__ value, const T *__restrict__ mat, T *__restrict__ out,
@@ -418,6 +434,13 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
   const uint64_t out_b = (uint64_t)b * M * K + k0;
   const bool writer = g == 0 && kok;
   const uint64_t carry_off = ((uint64_t)b * ws.P + (uint64_t)p) * K + k0;  // [b][p][K]
+  // masked sums: this lane's VEC features sit in one 32-bit word of every entry's mask (VEC divides 32)
+  const uint32_t *maskk = nullptr;
+  uint32_t mask_shift = 0;
+  if constexpr (MASKED) {
+    maskk = ws.wmask + (uint64_t)b * (uint64_t)E * ws.rec_stride + (kok ? (k0 >> 5) : 0u);
+    mask_shift = kok ? (k0 & 31u) : 0u;
+  }
 
   // the first row may have been started by an earlier partition
   const bool incoming = r0 < M && e0 > rowptr[r0];
@@ -426,19 +449,37 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
   int64_t wbase = e0;
   uint32_t c_cur, c_nxt;
   A w_cur, w_nxt;
-  auto load_window = [&](int64_t base, uint32_t &c_l, A &w_l) {
+  uint32_t e_cur = 0, e_nxt = 0;  // MASKED only: the entries' ids (index of their mask)
+  auto load_window = [&](int64_t base, uint32_t &c_l, A &w_l, uint32_t &e_l) {
     const int64_t e = base + lane;
     c_l = 0;
     w_l = A(1);
+    if constexpr (MASKED) e_l = 0;
     if (e < e1) {
       const int64_t src_e = ws.perm != nullptr ? ws.perm[e] : e;  // windows are fetched two ahead:
-      c_l = (uint32_t)col[src_e];                                  // the indirection is off the critical path
+      if constexpr (MASKED) {                                      // the indirection is off the critical path
+        // column id and value come from the entry's record: the line the mask gathers will hit again
+        const uint32_t *rec = ws.wmask + ((uint64_t)b * (uint64_t)E + (uint64_t)src_e) * ws.rec_stride + ws.rec_meta;
+        c_l = rec[0];
+        if (value != nullptr) {
+          if constexpr (sizeof(A) == 8) {
+            const uint64_t bits = (uint64_t)rec[1] | ((uint64_t)rec[2] << 32);
+            __builtin_memcpy(&w_l, &bits, 8);
+          } else {
+            const uint32_t bits = rec[1];
+            __builtin_memcpy(&w_l, &bits, 4);
+          }
+        }
+        e_l = (uint32_t)src_e;
+      } else {
+        c_l = (uint32_t)col[src_e];
+        if (value != nullptr) w_l = Traits<T>::to_acc(value[src_e]);
+      }
       if (relabel) c_l = hash_row(c_l, (uint32_t)N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
-      if (value != nullptr) w_l = Traits<T>::to_acc(value[src_e]);
     }
   };
-  load_window(wbase, c_cur, w_cur);
-  load_window(wbase + kWave, c_nxt, w_nxt);
+  load_window(wbase, c_cur, w_cur, e_cur);
+  load_window(wbase + kWave, c_nxt, w_nxt, e_nxt);
 
   // row ends: lane j holds rowptr[rp_base + 1 + j]
   int64_t rp_base = r0;
@@ -579,14 +620,14 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
     while (short_rows()) {
     }
     wbase = e;
-    load_window(wbase, c_cur, w_cur);
-    load_window(wbase + kWave, c_nxt, w_nxt);
+    load_window(wbase, c_cur, w_cur, e_cur);
+    load_window(wbase + kWave, c_nxt, w_nxt, e_nxt);
     return true;
   };
 
   // rows (or row pieces) inside the window [wbase, wbase + 64): 0 = window exhausted, 1 = partition done,
   // 2 = a batch of short rows was processed side by side and the windows were re-based (start over)
-  auto process_window = [&](const uint32_t c_w, const A w_w) __attribute__((always_inline)) -> int {
+  auto process_window = [&](const uint32_t c_w, const A w_w, const uint32_t e_w) __attribute__((always_inline)) -> int {
     const int64_t wend_raw = wbase + kWave;
     const int64_t wend = wend_raw < e1 ? wend_raw : e1;
     for (;;) {
@@ -605,8 +646,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
       }
       const int64_t stop = rend < wend ? rend : wend;
       if (e < stop) {
-        accumulate_window<T, VEC, RED>((int)(e - wbase), (int)(stop - wbase), (uint32_t)(wbase - e0),
-                                       c_w, w_w, has_value, matk, K, lgG, g, val, arg);
+        accumulate_window<T, VEC, RED, MASKED>((int)(e - wbase), (int)(stop - wbase), (uint32_t)(wbase - e0),
+                                               c_w, w_w, has_value, matk, K, lgG, g, val, arg, e_w, maskk,
+                                               ws.rec_stride, mask_shift);
         e = stop;
       }
       if (e < rend) return 0;  // window exhausted inside the row
@@ -630,15 +672,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
   };
   if (!incoming) short_row_batches();  // the partition starts at a row start
   for (;;) {
-    int st = process_window(c_cur, w_cur);
+    int st = process_window(c_cur, w_cur, e_cur);
     if (st == 1) break;
     if (st == 2) continue;
-    load_window(wbase + 2 * kWave, c_cur, w_cur);
+    load_window(wbase + 2 * kWave, c_cur, w_cur, e_cur);
     wbase += kWave;
-    st = process_window(c_nxt, w_nxt);
+    st = process_window(c_nxt, w_nxt, e_nxt);
     if (st == 1) break;
     if (st == 2) continue;
-    load_window(wbase + 2 * kWave, c_nxt, w_nxt);
+    load_window(wbase + 2 * kWave, c_nxt, w_nxt, e_nxt);
     wbase += kWave;
   }
   // tail: the piece of the unfinished row r1 that falls into this partition
@@ -826,6 +868,8 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.hash_shift = w.hash_bits > 1 ? w.hash_bits / 2 : 1;
   w.out_relabel = 0;
   w.perm = nullptr;
+  w.wmask = nullptr;
+  w.rec_stride = w.rec_meta = 0;
   w.ohash_bits = 1;
   while (w.ohash_bits < 32 && ((uint64_t)1 << w.ohash_bits) < (uint64_t)(M > 1 ? M : 2)) ++w.ohash_bits;
   w.ohash_shift = w.ohash_bits > 1 ? w.ohash_bits / 2 : 1;
@@ -873,7 +917,16 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   TSAMD_LAUNCH_CHECK();
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[1], stream));
   const unsigned int gx = (unsigned int)ceil_div(ws.P, kWavesPerBlock);
-  if (lgG >= 3)
+  constexpr bool kMaskable = RED == RED_ADD && (std::is_same<T, float>::value || std::is_same<T, double>::value ||
+                                                std::is_same<T, f16_t>::value || std::is_same<T, bf16_t>::value);
+  if (ws.wmask != nullptr) {
+    if constexpr (kMaskable)
+      hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, false, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                         dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N, (uint32_t)K, E,
+                         ktiles, lgG, mean, ws);
+    else
+      return TSAMD_ERR_UNSUPPORTED;
+  } else if (lgG >= 3)
     hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
                        dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N,
                        (uint32_t)K, E, ktiles, lgG, mean, ws);
@@ -949,7 +1002,8 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
                       const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
                       int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
                       size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev,
-                      bool relabelled = false, const int64_t *perm = nullptr) {
+                      bool relabelled = false, const int64_t *perm = nullptr,
+                      const uint32_t *wmask = nullptr) {
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
@@ -969,6 +1023,12 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
     ws.out_relabel = 1;
   }
   ws.perm = perm;
+  if (wmask != nullptr) {
+    if (E >= (int64_t)1 << 32 || reduce != TSAMD_SUM) return TSAMD_ERR_UNSUPPORTED;  // 32-bit entry ids in the windows
+    ws.wmask = wmask;
+    ws.rec_stride = win_record_stride(K);
+    ws.rec_meta = (uint32_t)ceil_div(K, 32);
+  }
   const size_t es = dtype_size(dtype);
   int vec = es <= 2 ? 4 : (int)(16 / es);  // widest packet for the type (see dispatch_spmm)
   while (vec > 1 && !((K % vec) == 0 && ((uintptr_t)mat % (vec * es)) == 0 &&
@@ -1109,6 +1169,23 @@ extern "C" int tsamd_spmm_permuted(int dtype, int reduce, const int64_t *rowptr,
   return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, workspace,
                     workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, false, perm);
 }
+
+// internal (spmm_internal.h): the masked sum behind tsamd_spmm_minmax_bw_csc
+namespace tsamd {
+size_t spmm_masked_sum_workspace_bytes(int dtype, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E) {
+  return carve(nullptr, dtype, TSAMD_SUM, B, M, N, K, E, nullptr);
+}
+int spmm_masked_sum(int dtype, const int64_t *rowptr, bool has_value, const int64_t *perm,
+                    const uint32_t *records, const void *mat, void *out, int64_t B, int64_t M, int64_t N,
+                    int64_t K, int64_t E, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (E > 0 && !records) return TSAMD_ERR_INVALID;
+  // `col` / `value` are only tested against NULL in the masked kernel (their contents come from the records)
+  const int64_t *col = reinterpret_cast<const int64_t *>(records);
+  const void *value = has_value ? reinterpret_cast<const void *>(records) : nullptr;
+  return spmm_entry(dtype, TSAMD_SUM, rowptr, col, value, mat, out, nullptr, B, M, N, K, E, workspace,
+                    workspace_bytes, stream, nullptr, false, perm, records);
+}
+}  // namespace tsamd
 
 extern "C" int tsamd_spmm_profiled(int dtype, int reduce, const int64_t *rowptr,
                                    const int64_t *col, const void *value, const void *mat,

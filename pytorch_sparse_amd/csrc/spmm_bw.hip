@@ -7,6 +7,7 @@
 //    (masked_fill / index_select / gather / scatter_add_) in SPMMMin/SPMMMax::backward
 //    (csrc/spmm.cpp:204-242, 264-302) with one fused pass.
 #include "common.h"
+#include "spmm_internal.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -331,6 +332,111 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_minmax_bw_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Pull formulation of the min/max backward (tsamd_spmm_minmax_bw_csc), step 1: the winner records
+// (layout: WinRecord in spmm_internal.h -- mask words, row id, value -- `S` words per (batch, entry)).
+//   mask bit k of entry e  =  (arg_out[b, row(e), k] == e)
+// ENTRY-balanced (a row-parallel version spent 1.8 ms of a 2^20-row R-MAT matrix on its hub rows): a
+// wave owns 64 consecutive entries and writes their records exactly once, fully coalesced.  Lane j
+// holds row(e0 + j); for every DISTINCT row that intersects the chunk (~4 at 20 entries per row; the
+// 1 KB of winners of a hub row is re-read by each of its chunks from L2) lane l loads the winners of
+// features t * 64 + l and ORs its bit into the winner's mask in a per-wave LDS tile (ds_or_b32) when
+// that entry belongs to the chunk.  Two feature tiles (four mask words) per pass; the owners then read
+// their four words back and store them with one 16-byte store -- zeros included, nothing to memset, no
+// global atomics.  A winner is only trusted to lie inside the chunk (LDS bounds); a foreign arg_out
+// gives a wrong mask, never a wild store.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
+    const int64_t *__restrict__ row, const T *__restrict__ value, const int64_t *__restrict__ arg_out,
+    uint32_t *__restrict__ rec, int64_t B, int64_t M, uint32_t K, int64_t E, uint32_t W, uint32_t S) {
+  using A = typename Traits<T>::acc_t;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ uint32_t tile_[kWavesPerBlock][kWave * 4];
+  const int lane = (int)(threadIdx.x & 63);
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t *tile = tile_[wib];
+  const int64_t e0 = ((int64_t)blockIdx.x * kWavesPerBlock + wib) * kWave;
+  if (e0 >= E) return;
+  const int n = (int)(E - e0 < kWave ? E - e0 : kWave);
+  const uint32_t ntiles = (K + 63u) >> 6;
+  const bool mine = lane < n;
+  const uint32_t m_l = mine ? (uint32_t)row[e0 + lane] : 0xFFFFFFFFu;
+  // heads: lanes whose entry starts a new row inside the chunk (lane 0 always)
+  const uint32_t m_prev = lane_read(m_l, lane > 0 ? lane - 1 : 0);
+  const unsigned long long heads = __ballot(mine && (lane == 0 || m_l != m_prev));
+  uint32_t vlo = 0, vhi = 0;
+  if (mine) {
+    A v = A(1);
+    if (value != nullptr) v = Traits<T>::to_acc(value[e0 + lane]);
+    if constexpr (sizeof(A) == 8) {
+      uint64_t bits;
+      __builtin_memcpy(&bits, &v, 8);
+      vlo = (uint32_t)bits;
+      vhi = (uint32_t)(bits >> 32);
+    } else {
+      __builtin_memcpy(&vlo, &v, 4);
+    }
+  }
+  const uint32_t bit = 1u << (lane & 31), half = (uint32_t)lane >> 5;
+  for (int64_t b = 0; b < B; ++b) {
+    const int64_t *a_b = arg_out + (uint64_t)b * M * K;
+    uint32_t *rec_l = rec + ((uint64_t)b * (uint64_t)E + (uint64_t)(e0 + lane)) * S;
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += 2) {
+      if (mine) *reinterpret_cast<u32x4 *>(tile + lane * 4) = u32x4{0u, 0u, 0u, 0u};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t k0 = t0 * 64u + (uint32_t)lane, k1 = k0 + 64u;
+      unsigned long long todo = heads;
+      while (todo != 0) {  // two rows per step: their loads are independent
+        const int p0 = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const bool two = todo != 0;
+        const int p1 = two ? (int)__builtin_ctzll(todo) : p0;
+        if (two) todo &= todo - 1;
+        const uint64_t ra = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_l, p0) * K;
+        const uint64_t rb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_l, p1) * K;
+        int64_t a00 = -1, a01 = -1, a10 = -1, a11 = -1;
+        if (k0 < K) a00 = a_b[ra + k0];
+        if (k1 < K) a01 = a_b[ra + k1];
+        if (two && k0 < K) a10 = a_b[rb + k0];
+        if (two && k1 < K) a11 = a_b[rb + k1];
+        const int64_t r00 = a00 - e0, r01 = a01 - e0, r10 = a10 - e0, r11 = a11 - e0;
+        if (a00 >= 0 && r00 >= 0 && r00 < n) atomicOr(tile + (uint32_t)r00 * 4 + half, bit);
+        if (a01 >= 0 && r01 >= 0 && r01 < n) atomicOr(tile + (uint32_t)r01 * 4 + 2 + half, bit);
+        if (a10 >= 0 && r10 >= 0 && r10 < n) atomicOr(tile + (uint32_t)r10 * 4 + half, bit);
+        if (a11 >= 0 && r11 >= 0 && r11 < n) atomicOr(tile + (uint32_t)r11 * 4 + 2 + half, bit);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (mine) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + lane * 4);
+        uint32_t *dst = rec_l + 2u * t0;
+        const uint32_t left = W - 2u * t0;  // mask words of this entry from tile t0 on (>= 1)
+        if (left >= 4) {
+          *reinterpret_cast<u32x4 *>(dst) = v;  // S and 2 * t0 are multiples of 4 words: aligned
+        } else {
+          dst[0] = v.x;
+          if (left > 1) dst[1] = v.y;
+          if (left > 2) dst[2] = v.z;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (mine) {  // the entry's row id and value behind its mask
+      if ((W & 3u) == 0) {
+        *reinterpret_cast<u32x4 *>(rec_l + W) = u32x4{m_l, vlo, vhi, 0u};
+      } else {
+        rec_l[W] = m_l;
+        rec_l[W + 1] = vlo;
+        rec_l[W + 2] = vhi;
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void narrow_from_f32_kernel(const float *__restrict__ src, T *__restrict__ dst,
                                        int64_t n) {
@@ -516,4 +622,67 @@ extern "C" int tsamd_spmm_minmax_bw(int dtype, const int64_t *rowptr, const int6
     return narrow_out<bf16_t>(shadow_mat, grad_mat, (int64_t)nmat, stream);
   }
   return TSAMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// min/max backward, pull formulation over the transposed pattern (see include/tsamd.h)
+// ---------------------------------------------------------------------------
+static size_t winrec_bytes(int64_t B, int64_t K, int64_t E) {
+  return align_up(sizeof(uint32_t) * (size_t)(B * E) * win_record_stride(K), 256);
+}
+
+extern "C" size_t tsamd_spmm_minmax_bw_csc_workspace_bytes(int dtype, int64_t B, int64_t M, int64_t N,
+                                                           int64_t K, int64_t E) {
+  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
+  // the masked sum runs on the transposed matrix: N rows, M columns
+  return winrec_bytes(B, K, E) + spmm_masked_sum_workspace_bytes(dtype, B, N, M, K, E);
+}
+
+extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const int64_t *col,
+                                        const void *value, const void *mat, const void *grad_out,
+                                        const int64_t *arg_out, const int64_t *colptr,
+                                        const int64_t *csr2csc, const int64_t *row, void *grad_value,
+                                        void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
+                                        int64_t E, void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
+  if (dtype != TSAMD_F32 && dtype != TSAMD_F64 && dtype != TSAMD_F16 && dtype != TSAMD_BF16)
+    return TSAMD_ERR_UNSUPPORTED;
+  if (N >= (int64_t)1 << 32 || M >= (int64_t)1 << 32 || E >= (int64_t)1 << 32 || K >= (int64_t)1 << 31)
+    return TSAMD_ERR_UNSUPPORTED;
+  const int64_t total = B * M * K;
+  if (total > 0 && (!rowptr || !col || !mat || !grad_out || !arg_out)) return TSAMD_ERR_INVALID;
+  if (grad_mat && E > 0 && (!colptr || !csr2csc || !row)) return TSAMD_ERR_INVALID;
+  if (grad_value) {  // targets are the row's own entries: the row-parallel LDS kernel (no atomics either)
+    int st = tsamd_spmm_minmax_bw(dtype, rowptr, col, value, mat, grad_out, arg_out, grad_value, nullptr, B, M, N,
+                                  K, E, nullptr, 0, stream_);
+    if (st != TSAMD_OK) return st;
+  }
+  if (!grad_mat || B * N * K == 0) return TSAMD_OK;
+  const size_t es = dtype_size(dtype);
+  if (total == 0 || E == 0) {
+    TSAMD_HIP_TRY(hipMemsetAsync(grad_mat, 0, es * (size_t)(B * N * K), stream));
+    return TSAMD_OK;
+  }
+  const size_t rec_b = winrec_bytes(B, K, E);
+  const size_t spmm_b = spmm_masked_sum_workspace_bytes(dtype, B, N, M, K, E);
+  if (!workspace || workspace_bytes < rec_b + spmm_b || (uintptr_t)workspace % 256 != 0)
+    return TSAMD_ERR_WORKSPACE;
+  uint32_t *rec = reinterpret_cast<uint32_t *>(workspace);
+  const uint32_t W = (uint32_t)ceil_div(K, 32), S = win_record_stride(K);
+  const unsigned int blocks = (unsigned int)ceil_div(ceil_div(E, kWave), kWavesPerBlock);
+  int st = TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
+    if constexpr (std::is_integral<scalar_t>::value) {
+      return (int)TSAMD_ERR_UNSUPPORTED;
+    } else {
+      hipLaunchKernelGGL((minmax_winrec_kernel<scalar_t>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, stream,
+                         row, reinterpret_cast<const scalar_t *>(value), arg_out, rec, B, M, (uint32_t)K, E, W, S);
+      TSAMD_LAUNCH_CHECK();
+      return (int)TSAMD_OK;
+    }
+  });
+  if (st != TSAMD_OK) return st;
+  // grad_mat = masked (A^T) * grad_out: rows of A^T = columns of A, entries through csr2csc
+  return spmm_masked_sum(dtype, colptr, value != nullptr, csr2csc, rec, grad_out, grad_mat, B, N, M, K, E,
+                         reinterpret_cast<char *>(workspace) + rec_b, workspace_bytes - rec_b, stream);
 }

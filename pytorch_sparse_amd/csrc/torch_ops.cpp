@@ -223,23 +223,39 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
 };
 
 // ---- min / max ----------------------------------------------------------------------------
+// With the CSC arrays of the matrix (colptr, csr2csc, row -- SparseTensor.matmul hands them over when a
+// gradient w.r.t. `mat` is wanted, exactly as it does for sum) the backward is the atomic-free pull of
+// tsamd_spmm_minmax_bw_csc; the bare reference op (rowptr, col, value, mat) keeps the scatter kernel.
 class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> {
  public:
   static variable_list forward(AutogradContext *ctx, Tensor rowptr, Tensor col, Tensor value,
-                               Tensor mat, bool has_value, bool is_max) {
+                               Tensor mat, bool has_value, bool is_max, OptTensor opt_colptr,
+                               OptTensor opt_csr2csc, OptTensor opt_row) {
     OptTensor v = has_value ? OptTensor(value) : std::nullopt;
     auto res = spmm_fw(rowptr, col, v, mat, is_max ? "max" : "min");
     Tensor out = std::get<0>(res), arg_out = std::get<1>(res).value();
+    const bool has_csc = opt_colptr.has_value() && opt_csr2csc.has_value() && opt_row.has_value();
+    if (has_csc) {
+      check_index(opt_colptr.value(), "colptr");
+      check_index(opt_csr2csc.value(), "csr2csc");
+      check_index(opt_row.value(), "row");
+      TORCH_CHECK(opt_csr2csc.value().numel() == col.numel() && opt_row.value().numel() == col.numel() &&
+                      opt_colptr.value().numel() == mat.size(-2) + 1,
+                  "Input mismatch");
+    }
     ctx->saved_data["has_value"] = has_value;
+    ctx->saved_data["has_csc"] = has_csc;
     // the reference saves {col, value, mat, arg_out} (spmm.cpp:199); rowptr is kept as well so that
     // grad_value can be accumulated row by row (tsamd.h)
-    ctx->save_for_backward({col, value, mat, arg_out, rowptr});
+    ctx->save_for_backward({col, value, mat, arg_out, rowptr, opt_colptr.value_or(col),
+                            opt_csr2csc.value_or(col), opt_row.value_or(col)});
     ctx->mark_non_differentiable({arg_out});
     return {out, arg_out};
   }
 
   static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
     const bool has_value = ctx->saved_data["has_value"].toBool();
+    const bool has_csc = ctx->saved_data["has_csc"].toBool();
     Tensor grad_out = grad_outs[0].contiguous();
     auto s = ctx->get_saved_variables();
     Tensor col = s[0].contiguous(), value = s[1].contiguous(), mat = s[2].contiguous(),
@@ -254,17 +270,32 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
       if (want_value) grad_value = torch::empty({E}, mat.options().requires_grad(false));
       if (want_mat) grad_mat = torch::empty_like(mat, mat.options().requires_grad(false));
       const int dt = dtype_code(mat);
-      Tensor ws = workspace(tsamd_spmm_minmax_bw_workspace_bytes(dt, B, N, K, E), mat);
-      check_status(
-          tsamd_spmm_minmax_bw(dt, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
-                               has_value ? value.data_ptr() : nullptr,
-                               mat.data_ptr(), grad_out.data_ptr(), arg_out.data_ptr<int64_t>(),
-                               want_value ? grad_value.data_ptr() : nullptr,
-                               want_mat ? grad_mat.data_ptr() : nullptr, B, M, N, K, E,
-                               ws.data_ptr(), (size_t)ws.numel(), current_stream(mat)),
-          "tsamd_spmm_minmax_bw");
+      int st = TSAMD_ERR_UNSUPPORTED;
+      if (has_csc && want_mat) {
+        Tensor colptr = s[5].contiguous(), csr2csc = s[6].contiguous(), row = s[7].contiguous();
+        Tensor ws = workspace(tsamd_spmm_minmax_bw_csc_workspace_bytes(dt, B, M, N, K, E), mat);
+        st = tsamd_spmm_minmax_bw_csc(dt, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                                      has_value ? value.data_ptr() : nullptr, mat.data_ptr(),
+                                      grad_out.data_ptr(), arg_out.data_ptr<int64_t>(),
+                                      colptr.data_ptr<int64_t>(), csr2csc.data_ptr<int64_t>(),
+                                      row.data_ptr<int64_t>(), want_value ? grad_value.data_ptr() : nullptr,
+                                      grad_mat.data_ptr(), B, M, N, K, E, ws.data_ptr(), (size_t)ws.numel(),
+                                      current_stream(mat));
+        if (st != TSAMD_ERR_UNSUPPORTED) check_status(st, "tsamd_spmm_minmax_bw_csc");
+      }
+      if (st == TSAMD_ERR_UNSUPPORTED) {  // no CSC arrays (bare op), or sizes beyond the pull kernel's 32-bit ids
+        Tensor ws = workspace(tsamd_spmm_minmax_bw_workspace_bytes(dt, B, N, K, E), mat);
+        check_status(
+            tsamd_spmm_minmax_bw(dt, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                                 has_value ? value.data_ptr() : nullptr,
+                                 mat.data_ptr(), grad_out.data_ptr(), arg_out.data_ptr<int64_t>(),
+                                 want_value ? grad_value.data_ptr() : nullptr,
+                                 want_mat ? grad_mat.data_ptr() : nullptr, B, M, N, K, E,
+                                 ws.data_ptr(), (size_t)ws.numel(), current_stream(mat)),
+            "tsamd_spmm_minmax_bw");
+      }
     }
-    return {Tensor(), Tensor(), grad_value, grad_mat, Tensor(), Tensor()};
+    return {Tensor(), Tensor(), grad_value, grad_mat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -435,13 +466,23 @@ Tensor spmm_mean(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_val
 
 std::tuple<Tensor, Tensor> spmm_min(Tensor rowptr, Tensor col, OptTensor opt_value, Tensor mat) {
   auto r = SpmmMinMaxFunction::apply(rowptr, col, opt_value.value_or(col), mat,
-                                     opt_value.has_value(), false);
+                                     opt_value.has_value(), false, std::nullopt, std::nullopt, std::nullopt);
   return std::make_tuple(r[0], r[1]);
 }
 
 std::tuple<Tensor, Tensor> spmm_max(Tensor rowptr, Tensor col, OptTensor opt_value, Tensor mat) {
   auto r = SpmmMinMaxFunction::apply(rowptr, col, opt_value.value_or(col), mat,
-                                     opt_value.has_value(), true);
+                                     opt_value.has_value(), true, std::nullopt, std::nullopt, std::nullopt);
+  return std::make_tuple(r[0], r[1]);
+}
+
+// tsamd::spmm_minmax(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor? csr2csc, Tensor? row,
+//                    Tensor mat, bool is_max) -> (Tensor, Tensor)
+// spmm_min / spmm_max with the CSC arrays of the matrix: same forward, atomic-free deterministic backward.
+std::tuple<Tensor, Tensor> spmm_minmax(Tensor rowptr, Tensor col, OptTensor opt_value, OptTensor opt_colptr,
+                                       OptTensor opt_csr2csc, OptTensor opt_row, Tensor mat, bool is_max) {
+  auto r = SpmmMinMaxFunction::apply(rowptr, col, opt_value.value_or(col), mat, opt_value.has_value(), is_max,
+                                     opt_colptr, opt_csr2csc, opt_row);
   return std::make_tuple(r[0], r[1]);
 }
 
@@ -1172,6 +1213,7 @@ static auto registry = torch::RegisterOperators()
                            .op("torch_sparse::ind2ptr", &ind2ptr)
                            .op("torch_sparse::ptr2ind", &ptr2ind)
                            .op("torch_sparse::cuda_version", &cuda_version)
+                           .op("tsamd::spmm_minmax", &spmm_minmax)
                            .op("tsamd::coo_order", &coo_order)
                            .op("tsamd::sort_coo", &sort_coo)
                            .op("tsamd::coalesce_index", &coalesce_index)

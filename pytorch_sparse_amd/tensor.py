@@ -27,10 +27,16 @@ def storage_spmm(st: SparseStorage, other: Tensor, reduce: str) -> Tuple[Tensor,
     rowptr, col, value = st.rowptr(), st.col(), st.value()
     if value is not None:
         value = value.to(other.dtype)
-    if reduce == 'min':
-        out, arg = torch.ops.torch_sparse.spmm_min(rowptr, col, value, other)
-        return out, arg
-    if reduce == 'max':
+    if reduce == 'min' or reduce == 'max':
+        if other.requires_grad:
+            # training: hand the CSC arrays over (cached in the storage, as for sum) so that grad_mat is
+            # pulled column by column instead of scattered with atomics (tsamd_spmm_minmax_bw_csc)
+            out, arg = torch.ops.tsamd.spmm_minmax(rowptr, col, value, st.colptr(), st.csr2csc(), st.row(),
+                                                   other, reduce == 'max')
+            return out, arg
+        if reduce == 'min':
+            out, arg = torch.ops.torch_sparse.spmm_min(rowptr, col, value, other)
+            return out, arg
         out, arg = torch.ops.torch_sparse.spmm_max(rowptr, col, value, other)
         return out, arg
     row, csr2csc, colptr, rowcount = st._row, st._csr2csc, st._colptr, st._rowcount

@@ -1,6 +1,6 @@
 """Profile target for the PMC passes (scripts/profile_pmc.sh): every kernel family of the hot path, a few
 launches each, in one process.  Workloads are separated in the dispatch stream by a MARKER launch
-(tsamd gather_rows of one row -- no workload uses that kernel), so scripts/summarize_pmc.py can attribute
+(tsamd gather_rows of one row -- no workload uses that kernel) before and after, so scripts/summarize_pmc.py can attribute
 the per-dispatch counter rows of `rocprofv3 --pmc ... --kernel-include-regex tsamd` to a workload by order.
 
 Prints one JSON line: the workload order with the byte counts each kernel is priced against (algorithmic,
@@ -30,15 +30,19 @@ def marker():
 
 
 def run(label, fn, **info):
+    """warm call, MARKER, `reps` calls, MARKER: the dispatches between the two markers are the workload's;
+    whatever runs between workloads (set-up, warm calls) falls into a bucket that is thrown away."""
     if which and label not in which:
         return
-    fn()  # warm (allocator, caches) before the marker
+    fn()  # warm (allocator, caches)
     torch.cuda.synchronize()
     marker()
     for _ in range(reps):
         fn()
     torch.cuda.synchronize()
+    marker()
     plan.append(dict(label=label, launches=reps, **info))
+    plan.append(dict(label='_discard', launches=1))
 
 
 def balg(E, M, K, s, has_value, minmax):

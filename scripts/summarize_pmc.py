@@ -37,14 +37,14 @@ def split(rows, name_key, plan):
         if plan['marker_kernel'] in k:
             cur += 1
             continue
-        if cur < 0 or cur >= len(labels):
+        if cur < 0 or cur >= len(labels) or labels[cur] == '_discard':
             continue
         out.setdefault(labels[cur], {}).setdefault(k, []).append(r)
     return out
 
 
 plan = plan_of(os.path.join(src, 'trace.log'))
-res = {w['label']: dict(info=w, kernels={}) for w in plan['workloads']}
+res = {w['label']: dict(info=w, kernels={}) for w in plan['workloads'] if w['label'] != '_discard'}
 # ---- durations from the plain kernel trace ------------------------------------------------------------------
 tr = [r for r in csv.DictReader(open(os.path.join(src, 'trace', 'k_kernel_trace.csv'))) if 'tsamd' in r['Kernel_Name']]
 tr.sort(key=lambda r: int(r['Start_Timestamp']))

@@ -208,14 +208,29 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     op = torch.ops.torch_sparse.spmm_max
     fw_ms = gpu_ms(lambda: op(rp, c, v, x), iters=iters)
     out, arg = op(rp, c, v, x)
-    bw = lambda: nat.spmm_minmax_bw(rp, c, v, x, g, arg, want_value=has_value, want_mat=True)  # noqa: E731
+    # backward, both routes: the pull over the cached CSC arrays (what adj.matmul(x, 'max').backward() runs,
+    # tsamd_spmm_minmax_bw_csc) and the scatter with packed atomics behind the bare 4-argument op
+    import pytorch_sparse_amd as ts
+    vr = v.clone().requires_grad_() if has_value else None
+    A = ts.SparseTensor(rowptr=rp, col=c, value=vr, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    st = A.storage
+    colptr, perm, row = st.colptr(), st.csr2csc(), st.row()
+    bw = lambda: nat.spmm_minmax_bw_csc(rp, c, v, x, g, arg, colptr, perm, row, want_value=has_value, want_mat=True)  # noqa: E731
     bw_ms = gpu_ms(bw, iters=iters)
     gval, gmat = bw()
-    # autograd wiring of the drop-in op: out.backward(g) must give the same grad_mat kernel result
+    bw_atomic = lambda: nat.spmm_minmax_bw(rp, c, v, x, g, arg, want_value=has_value, want_mat=True)  # noqa: E731
+    bw_atomic_ms = gpu_ms(bw_atomic, iters=iters)
+    gval_a, gmat_a = bw_atomic()
+    deterministic = bool(torch.equal(bw()[1].view(torch.int16), gmat.view(torch.int16)))
+    # autograd wiring of the drop-in front-end: adj.matmul(x, 'max').backward(g) takes the pull route
     xr = x.clone().requires_grad_()
-    vr = v.clone().requires_grad_() if has_value else None
-    o2, _ = op(rp, c, vr, xr)
+    o2 = A.matmul(xr, 'max')
     o2.backward(g)
+    same_as_op = bool(torch.equal(xr.grad.view(torch.int16), gmat.view(torch.int16)))
+    # ... and the bare reference op (no CSC arrays) the scatter route
+    xr2 = x.clone().requires_grad_()
+    o3, _ = op(rp, c, v, xr2)
+    o3.backward(g)
     ba_fw = b_alg(E, n, K, 2, has_value, True)
     ba_bw = n * K * (8 + 2 * 2) + 2 * n * K * 2  # M*F*(8+2s) read + scatter RMW 2*M*F*s
     res = dict(config='c3', has_value=has_value,
@@ -225,16 +240,27 @@ def run_c3(dev, has_value, cpu=True, iters=10):
                roofline=dict(bound='hbm', algorithmic_bytes=ba_fw, achieved=round(ba_fw / fw_ms / 1e6, 1),
                              peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ba_fw / fw_ms / 1e6 / HBM_PEAK_GBS, 4),
                              scope='forward, whole op'),
-               roofline_bw=dict(bound='hbm atomics', algorithmic_bytes=ba_bw, achieved=round(ba_bw / bw_ms / 1e6, 1),
+               bw_atomic_ms=round(bw_atomic_ms, 4),
+               roofline_bw=dict(bound='hbm', algorithmic_bytes=ba_bw, achieved=round(ba_bw / bw_ms / 1e6, 1),
                                 peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ba_bw / bw_ms / 1e6 / HBM_PEAK_GBS, 4),
-                                note='bounded by the device-scope atomic rate (20 G 64-byte segments/s, '
-                                     'profiles/r02_ubench_atomics.csv), not by bytes'))
+                                scope='pull route (winner masks + masked merge-path SpMM over the cached CSC arrays); '
+                                      'bytes = SURVEY 8d\'s scatter model M F (8 + 2 s) + 2 M F s, which the pull does '
+                                      'not follow: it gathers one grad_out row per entry, E (16 + F s + F / 8)',
+                                bytes_pull_model=int(E * (16 + K * 2 + K // 8) + n * K * 8 + n * K * 2),
+                                frac_pull_model=round((E * (16 + K * 2 + K // 8) + n * K * 8 + n * K * 2) / bw_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                atomic_route_frac=round(ba_bw / bw_atomic_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                note='bw_atomic_ms = tsamd_spmm_minmax_bw (bare spmm_min/max op): bounded by the device-scope '
+                                     'atomic rate (20 G 64-byte segments/s, profiles/r02_ubench_atomics.csv), not by bytes'))
     par = dict()
     # backward: grad_mat against the fp64 formulas within the rounding bound of its arithmetic
     exact, bound = minmax_bw_bound(c, v, g, arg, n, dtype)
     err = (gmat.double() - exact).abs()
     par['grad_mat_max_err_over_bound'] = float((err / bound).max())
     par['grad_mat_autograd_equal_bound'] = float(((xr.grad.double() - exact).abs() / bound).max())
+    par['grad_mat_atomic_route_max_err_over_bound'] = float(((gmat_a.double() - exact).abs() / bound).max())
+    par['grad_mat_bare_op_autograd_max_err_over_bound'] = float(((xr2.grad.double() - exact).abs() / bound).max())
+    par['grad_mat_pull_deterministic'] = deterministic
+    par['grad_mat_autograd_bit_identical_to_c_abi'] = same_as_op
     del exact, bound, err
     if has_value:
         invalid = arg == E
@@ -262,6 +288,8 @@ def run_c3(dev, has_value, cpu=True, iters=10):
         par['against'] = 'reference CPU kernel (forward, bit-exact); fp64 formulas of csrc/spmm.cpp:204-242 (backward)'
     par['ok'] = bool(par.get('arg_out_mismatches', 0) == 0 and par.get('out_bit_mismatches', 0) == 0 and
                      par['grad_mat_max_err_over_bound'] <= 1.0 and par['grad_mat_autograd_equal_bound'] <= 1.0 and
+                     par['grad_mat_atomic_route_max_err_over_bound'] <= 1.0 and deterministic and same_as_op and
+                     par['grad_mat_bare_op_autograd_max_err_over_bound'] <= 1.0 and
                      par.get('grad_value_max_err_over_bound', 0.0) <= 1.0 and
                      par.get('grad_value_autograd_max_err_over_bound', 0.0) <= 1.0)
     res['parity'] = par

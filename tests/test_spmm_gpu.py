@@ -214,6 +214,88 @@ def test_minmax_bw(dev, dtype, reduce):
             assert np.allclose(gv.cpu().double().numpy(), egv, rtol=tol, atol=tol * scale)
 
 
+def _csc_arrays(rp, c, n_cols):
+    """(colptr, csr2csc, row) of a CSR pattern, by stable host argsort (independent of the product's sort)."""
+    E = c.numel()
+    row = torch.repeat_interleave(torch.arange(rp.numel() - 1), rp[1:] - rp[:-1])
+    perm = torch.from_numpy(np.argsort((c * (rp.numel() - 1) + row).numpy(), kind='stable'))
+    colptr = torch.zeros(n_cols + 1, dtype=torch.int64)
+    colptr[1:] = torch.cumsum(torch.bincount(c, minlength=n_cols), 0)
+    assert perm.numel() == E
+    return colptr, perm, row
+
+
+@pytest.mark.parametrize('reduce', ['min', 'max'])
+@pytest.mark.parametrize('dtype', FLOAT_DTYPES)
+def test_minmax_bw_csc_pull(dev, dtype, reduce):
+    """tsamd_spmm_minmax_bw_csc (winner masks + masked merge-path SpMM over the CSC view) against the fp64
+    formulas of csrc/spmm.cpp:204-242: fp32 (fp64) accumulation, one rounding -- so well inside the bound of the
+    scatter kernel -- deterministic, identical grad_value; rows above and below 64 entries, K that is not a
+    multiple of 32 / 64, batches, value-less."""
+    rp, c = synth.rmat_csr(9, 10, seed=6)
+    n, E = 1 << 9, c.numel()
+    assert int((rp[1:] - rp[:-1]).max()) > 64  # the long-row mask path is exercised
+    colptr, perm, row = _csc_arrays(rp, c, n)
+    for K, batch, has_value in ((16, (), True), (5, (2, ), True), (32, (), False), (70, (), True), (128, (2, ), False),
+                                (192, (), True)):
+        v, x = make_inputs(rp, c, n, K, dtype, has_value, batch)
+        gout = synth.features(n, K, seed=9, dtype=dtype, batch=batch)
+        out, arg = run_gpu(dev, rp, c, v, x, reduce)
+        args = (rp.to(dev), c.to(dev), None if v is None else v.to(dev), x.to(dev), gout.to(dev), arg,
+                colptr.to(dev), perm.to(dev), row.to(dev))
+        gv, gm = nat.spmm_minmax_bw_csc(*args, want_value=has_value, want_mat=True)
+        gv2, gm2 = nat.spmm_minmax_bw_csc(*args, want_value=has_value, want_mat=True)
+        assert bits_equal(gm, gm2), 'grad_mat is not deterministic'
+        egv, egm = oc.spmm_minmax_bw(oc.F64, c.numpy(), None if v is None else v.double().numpy(),
+                                     x.double().numpy(), gout.double().numpy(), arg.cpu().numpy(),
+                                     want_value=has_value)
+        absv = None if v is None else v.double().abs().numpy()
+        _, l1 = oc.spmm_minmax_bw(oc.F64, c.numpy(), absv, x.double().numpy(), gout.double().abs().numpy(),
+                                  arg.cpu().numpy(), want_value=False)
+        u = {torch.float32: 2.0 ** -24, torch.float64: 2.0 ** -53, torch.float16: 2.0 ** -11,
+             torch.bfloat16: 2.0 ** -8}[dtype]
+        # every product rounded to the element type (u * |term| each), summed in fp32 / fp64, rounded once
+        err = np.abs(gm.cpu().double().numpy() - egm)
+        floor = 2.0 ** -24 if dtype == torch.float16 else 1e-40
+        _, cnt = oc.spmm_minmax_bw(oc.F64, c.numpy(), None, x.double().numpy(), np.ones_like(gout.double().numpy()),
+                                   arg.cpu().numpy(), want_value=False)
+        acc_u = 2.0 ** -53 if dtype == torch.float64 else 2.0 ** -24
+        bound = u * l1 * 1.01 + u * np.abs(egm) * 1.01 + (cnt + 1) * acc_u * l1 + floor
+        assert (err <= bound).all(), (K, batch, float((err / (bound + 1e-300)).max()))
+        if has_value:
+            gv_ref, _ = nat.spmm_minmax_bw(*args[:6], want_value=True, want_mat=False)
+            assert bits_equal(gv, gv_ref)
+        # through autograd: the front-end hands the CSC arrays over when `mat` needs a gradient
+        if batch == ():
+            import pytorch_sparse_amd as ts
+            xr = x.to(dev).requires_grad_()
+            vr = None if v is None else v.to(dev).requires_grad_()
+            A = ts.SparseTensor(rowptr=rp.to(dev), col=c.to(dev), value=vr, sparse_sizes=(n, n), is_sorted=True,
+                                trust_data=True)
+            o = A.matmul(xr, reduce)
+            o.backward(gout.to(dev))
+            assert bits_equal(xr.grad, gm), 'autograd path differs from the C-ABI call'
+            assert A.storage.has_csr2csc() and A.storage.has_colptr()
+            if has_value:
+                assert bits_equal(vr.grad, gv)
+
+
+def test_minmax_bw_csc_no_winner_and_empty(dev):
+    """Rows without entries and elements without a winner (arg == E) contribute nothing; columns without
+    entries get zeros (every element of grad_mat is written)."""
+    rp = torch.tensor([0, 3, 3, 5, 5])
+    c = torch.tensor([0, 1, 2, 0, 0])
+    x = torch.tensor([[1., 5.], [1., 7.], [float('nan'), 7.], [0., 0.]])
+    g = torch.tensor([[1., 2.], [3., 4.], [5., 6.], [7., 8.]])
+    colptr, perm, row = _csc_arrays(rp, c, 4)
+    out, arg = nat.spmm(rp.to(dev), c.to(dev), None, x.to(dev), 'max')
+    gv, gm = nat.spmm_minmax_bw_csc(rp.to(dev), c.to(dev), None, x.to(dev), g.to(dev), arg, colptr.to(dev), perm.to(dev),
+                                    row.to(dev), want_value=False, want_mat=True)
+    _, gm_ref = nat.spmm_minmax_bw(rp.to(dev), c.to(dev), None, x.to(dev), g.to(dev), arg, want_value=False, want_mat=True)
+    assert torch.equal(gm.cpu(), gm_ref.cpu())
+    assert torch.equal(gm.cpu()[3], torch.zeros(2))
+
+
 def test_ind2ptr_ptr2ind(dev):
     assert nat.ind2ptr(torch.tensor([2, 2, 4, 5, 5, 6], device=dev), 8).tolist() == \
         [0, 0, 0, 2, 2, 3, 5, 6, 6]
