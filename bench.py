@@ -1,6 +1,6 @@
 """bench.py -- headline benchmark of the sparse-matmul hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c2|c5] [--reduce sum]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|c2|c5] [--reduce sum] [--exchange allgather|halo|pipelined]
 
 One *step* = one pass of the hot path over one batch of synthetic input that is already resident
 in HBM: at N = 1 a CSR SpMM (tsamd_spmm: merge-path partition + merge + carry fix-up kernels); at
@@ -9,11 +9,12 @@ N > 1 each rank owns a row block of A and the matching row block of X, and a ste
 Scaling is WEAK: every rank owns 2**scale rows with ~edge_factor entries each, whatever N is, so
 the global matrix is (N * 2**scale) square.
 
-Workloads (default = the north-star shape the BASELINE.json target is
-quoted on):
-    ns   R-MAT scale 21, edge factor 20, F = 128 fp32     (default)
+Workloads:
+    ns   R-MAT scale 21, edge factor 20, F = 128 fp32     (default at N = 1: the shape the BASELINE.json target is quoted on)
     c2   R-MAT scale 20, edge factor 20, F = 64  fp32     (BASELINE.json configs[1])
-    c5   R-MAT scale 21, edge factor 32, F = 256 fp32     (per-GPU share of configs[4])
+    c5   R-MAT scale 21, edge factor 32, F = 256 fp32     (default at N > 1: per-GPU share of configs[4]; the headline
+                                                           step is the all-gather of X + the local SpMM, the halo and
+                                                           pipelined exchanges are timed beside it)
 
 Rank 0 prints ONE JSON line (see README/DESIGN.md for the field meanings).  Timing: W warm-up
 steps, then K steps between barrier + torch.cuda.synchronize() on both sides, max over ranks.
@@ -45,6 +46,12 @@ WORKLOADS = {
     'c2': dict(scale=20, edge_factor=20, F=64, desc='configs[1]: CSR SpMM 1M x 1M R-MAT ~20 nnz/row, F=64 fp32'),
     'c5': dict(scale=21, edge_factor=32, F=256, desc='configs[4] per-GPU share: 2M rows x ~32 nnz/row, F=256 fp32'),
 }
+
+
+def default_workload(world):
+    """N = 1: the north-star shape; N > 1: BASELINE.json configs[4] (2^24 rows at 8 GPUs = 2^21 rows, ~32 nnz/row,
+    F = 256 per rank), weak scaling, RCCL all-gather of X in front of the local SpMM."""
+    return 'ns' if world == 1 else 'c5'
 
 
 def b_alg(E, M, K, esize, has_value, minmax):
@@ -188,16 +195,20 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='ns', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS),
+                    help='default: ns at N = 1 (the north-star shape the BASELINE target is quoted on), c5 at N > 1 '
+                         '(the per-GPU share of BASELINE.json configs[4])')
     ap.add_argument('--reduce', default='sum', choices=['sum', 'mean', 'min', 'max'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the C2 / C3 / C4 entries (N = 1 only)')
     ap.add_argument('--headline-only', action='store_true',
                     help='only the timed north-star steps + the roofline launches (for rocprofv3: every launch of the '
                          'dominant kernel in the trace is then the headline workload)')
-    ap.add_argument('--exchange', default='pipelined', choices=['pipelined', 'halo', 'allgather'],
-                    help='N > 1: all_gather of X | halo = all_to_all of the referenced rows only | '
-                         'pipelined = halo exchange in row pieces, overlapped with the SpMM of the previous piece')
+    ap.add_argument('--exchange', default='allgather', choices=['pipelined', 'halo', 'allgather'],
+                    help='N > 1, the exchange of the HEADLINE step: allgather (default: the north star names the RCCL '
+                         'all-gather of X) | halo = all_to_all of the referenced rows only | pipelined = halo exchange in '
+                         'row pieces, overlapped with the SpMM of the previous piece.  The other two are timed beside it '
+                         '(exchange_variants_ms_per_step)')
     ap.add_argument('--chunks', type=int, default=8, help='row pieces of the pipelined exchange')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak (default): every rank owns 2**scale rows; strong: the single-GPU matrix is cut '
@@ -205,6 +216,7 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    args.workload = args.workload or default_workload(world)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world == 1:
@@ -259,9 +271,17 @@ def main():
         sync=torch.cuda.synchronize)
     comm_rows = getattr(sharded, 'n_needed', n_global) if world > 1 else 0
 
+    from pytorch_sparse_amd.parallel import PipelinedHaloSpMM as _Pipelined
+
+    def run_op(op):
+        # inference steps: the pipelined plan is told so (otherwise it agrees on the path with one all_reduce per call)
+        if isinstance(op, _Pipelined):
+            return op(x_local, args.reduce, differentiable=False)
+        return op(x_local, args.reduce)
+
     def step():
         with torch.no_grad():
-            return sharded(x_local, args.reduce)  # (RCCL exchange of X rows,) then the local SpMM
+            return run_op(sharded)  # (RCCL exchange of X rows,) then the local SpMM
 
     # operands of ONE local SpMM launch, for the roofline / parity / cpu-baseline legs below
     if isinstance(sharded, RowShardedSpMM):
@@ -272,6 +292,10 @@ def main():
         ref_plan = HaloShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm)
         x_full, col_k = ref_plan.exchange(x_local), ref_plan.col
 
+    # The headline steps run with the operand cache OFF: every step does all of its work (probe, relabelled copy
+    # of X, partition, merge, fix-up), as if X were new each time.  What a caller sees who multiplies by the SAME X
+    # again (the cache's default-on behaviour) is measured separately below (`repeated_operand`).
+    torch.ops.tsamd.operand_cache(False)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -286,6 +310,31 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+
+    # N = 1: the same steps with the operand cache ON (default behaviour of the ops): the second and later calls
+    # with an unchanged X find its relabelled copy (tsamd_spmm_cached) -- bit-identical output
+    repeated = None
+    if world == 1:
+        torch.ops.tsamd.operand_cache(True)
+        with torch.no_grad():
+            first = step()
+            same = bool(torch.equal(first.view(torch.int32), out.view(torch.int32)))
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            ms_rep = (time.perf_counter() - t1) / args.steps * 1e3
+        _, hits, fills = torch.ops.tsamd.operand_cache(True)
+        repeated = dict(ms_per_step=round(ms_rep, 4), gedges_per_s=round(E / ms_rep / 1e6, 3), hits=int(hits), fills=int(fills),
+                        bit_identical_to_headline=same,
+                        note='operand cache on (the default of torch.ops.torch_sparse.spmm_*): calls after the first with the '
+                             'same X (same storage, version counter, shape, stream, pattern; sampled fingerprint re-checked '
+                             'on the device) skip spmm_probe_kernel and spmm_permute_rows_kernel.  NOT the headline: the '
+                             'headline steps above run with the cache off')
+    torch.ops.tsamd.operand_cache(True)
 
     # N > 1: the exchange alone and the local SpMM alone, timed after the headline region, next to the
     # xGMI model of the exchange
@@ -311,12 +360,12 @@ def main():
                     op_v = EXCHANGES[mode](rowptr, col, value, x_sizes, None, op_spmm, **kw)
                 reps = max(3, min(args.steps, 10))
                 with torch.no_grad():
-                    op_v(x_local, args.reduce)
+                    run_op(op_v)
                     torch.cuda.synchronize()
                     dist.barrier()
                     t1 = time.perf_counter()
                     for _ in range(reps):
-                        op_v(x_local, args.reduce)
+                        run_op(op_v)
                     torch.cuda.synchronize()
                     dist.barrier()
                     ms_v = (time.perf_counter() - t1) / reps * 1e3
@@ -402,6 +451,8 @@ def main():
             line['config']['exchange_fallback'] = 'requested %s; %s' % (requested, fallback_reason)
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             line['cpu_baseline'] = cpu_baseline(rowptr, col_k, value, x_full, args.reduce, out)
+        if repeated is not None:
+            line['repeated_operand'] = repeated
         if world == 1 and not args.headline_only:
             line['relabelled_layout'] = relabelled_leg(rowptr, col_k, value, x_full, out, args.reduce,
                                                        max(10, min(args.steps, 50)), dev)

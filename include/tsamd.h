@@ -101,6 +101,29 @@ int tsamd_spmm_permuted(int dtype, int reduce, const int64_t *rowptr, const int6
                         int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Operand cache.  On Kronecker-like graphs tsamd_spmm copies `mat` to hashed row positions before the
+ * gather (channel camping, see below) -- 15 % of a north-star call.  A caller that multiplies by the SAME
+ * dense operand again (inference with fixed features, the first layer of every training epoch) can keep
+ * that copy: tsamd_spmm_cached takes a caller-owned device buffer of tsamd_spmm_operand_cache_bytes()
+ * bytes (0 = this product never copies its operand; 256-byte aligned) that holds the copy, the verdict of
+ * the camping probe and a fingerprint of `mat` (64 x 256 sampled 16-byte packets).
+ *   cache_valid = 0: fill the buffer (the same work as tsamd_spmm);
+ *   cache_valid = 1: the buffer was filled by a call with the same (col, E, N, K, dtype, reduce class): the
+ *     fingerprint of `mat` is recomputed (microseconds) and the copy kernel returns at once when it still
+ *     matches; when it does not, the copy is redone -- the decision is taken on the device, no sync.
+ * The CALLER decides whether `mat` can still be the same matrix (the torch glue keys on storage identity,
+ * data pointer, version counter, shape and stream); the fingerprint is the second line of defence for writes
+ * that bypass such bookkeeping.  Results are bit-identical to tsamd_spmm.  The workspace
+ * (tsamd_spmm_cached_workspace_bytes) no longer contains the copy. */
+size_t tsamd_spmm_operand_cache_bytes(int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,
+                                      int64_t E);
+size_t tsamd_spmm_cached_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,
+                                         int64_t E);
+int tsamd_spmm_cached(int dtype, int reduce, const int64_t *rowptr, const int64_t *col, const void *value,
+                      const void *mat, void *out, int64_t *arg_out, int64_t B, int64_t M, int64_t N,
+                      int64_t K, int64_t E, void *workspace, size_t workspace_bytes, void *cache,
+                      size_t cache_bytes, int cache_valid, void *stream);
+
 /* Measurement aid (bench.py): same as tsamd_spmm, but brackets the three
  * kernels of the launch sequence (merge-path partition, merge, carry fix-up)
  * with hipEvents on `stream`, waits for the last one and writes their

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get('TSAMD_LIB') or os.path.join(_HERE, 'lib', 'libtsamd.s
 SYMBOLS = [
     'tsamd_hip_version', 'tsamd_last_hip_error', 'tsamd_status_string',
     'tsamd_spmm_workspace_bytes', 'tsamd_spmm', 'tsamd_spmm_permuted', 'tsamd_spmm_profiled',
+    'tsamd_spmm_operand_cache_bytes', 'tsamd_spmm_cached_workspace_bytes', 'tsamd_spmm_cached',
     'tsamd_gather_rows', 'tsamd_relabel_ids', 'tsamd_spmm_relabelled_workspace_bytes', 'tsamd_spmm_relabelled',
     'tsamd_spmm_value_bw',
     'tsamd_spmm_minmax_bw_workspace_bytes', 'tsamd_spmm_minmax_bw',

@@ -101,6 +101,11 @@ struct Workspace {
   // value, so that one 32-byte line serves every random access an entry needs
   const uint32_t *wmask;
   uint32_t rec_stride, rec_meta;  // words per record; word offset of (id, value lo, value hi)
+  // operand cache (tsamd_spmm_cached): xperm / relabel_flag live in a caller-owned buffer that survives the
+  // call; when both pointers are set the copy kernel returns at once if the two fingerprints agree
+  const unsigned long long *fp_stored, *fp_new;
+  unsigned long long *cache_fp;  // host side: [2][kFingerprintWords] stored | new, inside the cache buffer
+  int cache_state;               // host side: 0 no cache, 1 fill it, 2 reuse it if the fingerprint still matches
 };
 
 // ---------------------------------------------------------------------------
@@ -138,6 +143,32 @@ __device__ __forceinline__ bool use_relabel(int mode, const int *f) {
 
 constexpr int kProbeBlocks = 64;
 
+// Fingerprint of a dense operand for the operand cache: 64 x 256 sixteen-byte packets spread evenly over
+// the matrix, mixed with their sample index and summed per block (wrap-around, order independent).  Any
+// dense update (x += ..., a new epoch's activations) changes it with certainty for all practical purposes;
+// it is the second line of defence behind the tensor's version counter (torch_ops.cpp), for writes that
+// bypass it.
+constexpr int kFingerprintWords = 64;
+__global__ __launch_bounds__(256) void spmm_fingerprint_kernel(const uint4 *__restrict__ mat, uint64_t npackets,
+                                                               unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long part[4];
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t pos = (i * npackets) / ((uint64_t)kFingerprintWords * 256);
+  const uint4 v = mat[pos];
+  unsigned long long h = ((unsigned long long)v.x | ((unsigned long long)v.y << 32)) * 0x9E3779B97F4A7C15ull +
+                         ((unsigned long long)v.z | ((unsigned long long)v.w << 32)) * 0xC2B2AE3D27D4EB4Full;
+  h ^= h >> 29;
+  h *= (2 * i + 1);
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = lane_read_u32((uint32_t)h, (int)((threadIdx.x & 63) ^ off));
+    const uint32_t hi = lane_read_u32((uint32_t)(h >> 32), (int)((threadIdx.x & 63) ^ off));
+    h += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
 __global__ void spmm_probe_kernel(const int64_t *__restrict__ col, int64_t E, int *__restrict__ flag) {
   const int64_t samples = (int64_t)kProbeBlocks * blockDim.x;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -159,6 +190,10 @@ __global__ __launch_bounds__(256) void spmm_permute_rows_kernel(const T *__restr
                                                                uint32_t N, uint32_t K, int lgL,
                                                                Workspace ws) {
   if (!use_relabel(ws.relabel_mode, ws.relabel_flag)) return;
+  if (ws.fp_stored != nullptr) {  // cached copy still matches the operand's fingerprint: nothing to do
+    const int i = (int)(threadIdx.x & (kFingerprintWords - 1));
+    if (__syncthreads_and(ws.fp_stored[i] == ws.fp_new[i])) return;
+  }
   using P = Pack<T, VEC>;
   const uint32_t slots = K / VEC;
   const uint32_t lanes = 1u << lgL;
@@ -829,11 +864,18 @@ bool relabel_forced() {
   return env != nullptr && env[0] == '1';
 }
 
-bool relabel_possible(int dtype, int64_t N, int64_t K, int64_t E) {
+// Round 3 same-box A/B over reduction x element type x row size on the scale-20 / 21 R-MAT graphs
+// (scripts/ab_relabel.py, profiles/r03_ab_relabel.jsonl): the copy LOSES 3-11 % for min / max on f16 / bf16
+// at every row size (those kernels are bound by instruction issue, not by the camped channels, and pay
+// the copy and the per-entry hashing on top) and 15 % for fp32 min / max on 128-byte rows; 128-byte rows
+// of sums are a wash (-5 ... +5 %).  It stays for sums on power-of-two rows >= 256 bytes (3-23 % gain)
+// and for fp32 / fp64 min / max on rows >= 256 bytes (2-20 %).
+bool relabel_possible(int dtype, int reduce, int64_t N, int64_t K, int64_t E) {
   const int64_t row_bytes = K * (int64_t)dtype_size(dtype);
   const bool size_ok = E >= (1 << 20) && N >= 4096 && N < ((int64_t)1 << 32) && E >= 8 * N &&
                        row_bytes % 16 == 0;
-  const bool camps = row_bytes >= 128 && (row_bytes & (row_bytes - 1)) == 0;
+  const bool minmax = reduce == TSAMD_MIN || reduce == TSAMD_MAX;
+  const bool camps = row_bytes >= 256 && (row_bytes & (row_bytes - 1)) == 0 && !(minmax && dtype_size(dtype) < 4);
   return size_ok && (camps || relabel_forced());
 }
 
@@ -861,7 +903,7 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.tail_arg = reinterpret_cast<int64_t *>(minmax ? take(sizeof(int64_t) * plane) : nullptr);
   w.relabel_mode = 0;
   w.relabel_flag = reinterpret_cast<int *>(take(256));
-  w.xperm = (!relabelled && relabel_possible(dtype, N, K, E)) ? take(dtype_size(dtype) * (size_t)B * N * K) : nullptr;
+  w.xperm = (!relabelled && relabel_possible(dtype, reduce, N, K, E)) ? take(dtype_size(dtype) * (size_t)B * N * K) : nullptr;
   w.hash_bits = 1;
   while (w.hash_bits < 32 && ((uint64_t)1 << w.hash_bits) < (uint64_t)(N > 1 ? N : 2)) ++w.hash_bits;
   w.hash_mul = 0x9E3779B1u;  // odd (golden-ratio) multiplier
@@ -870,11 +912,21 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.perm = nullptr;
   w.wmask = nullptr;
   w.rec_stride = w.rec_meta = 0;
+  w.fp_stored = w.fp_new = nullptr;
+  w.cache_fp = nullptr;
+  w.cache_state = 0;
   w.ohash_bits = 1;
   while (w.ohash_bits < 32 && ((uint64_t)1 << w.ohash_bits) < (uint64_t)(M > 1 ? M : 2)) ++w.ohash_bits;
   w.ohash_shift = w.ohash_bits > 1 ? w.ohash_bits / 2 : 1;
   if (ws) *ws = w;
   return off;
+}
+
+// operand cache buffer: [probe counters 256 B | fingerprints 2 x 512 B | relabelled copy of mat]
+constexpr size_t kOperandCacheHeader = 256 + 2 * 512;
+size_t operand_cache_bytes(int dtype, int reduce, int64_t B, int64_t N, int64_t K, int64_t E) {
+  if (!relabel_possible(dtype, reduce, N, K, E)) return 0;
+  return kOperandCacheHeader + align_up(dtype_size(dtype) * (size_t)B * N * K, 256);
 }
 
 template <typename T, int VEC, int RED>
@@ -895,13 +947,24 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
       mode = env ? (env[0] == '1' ? 1 : (env[0] == '0' ? 0 : 2)) : 2;
     }
     ws.relabel_mode = mode;
-    if (mode == 2) {
+    const bool cached = ws.cache_state != 0 && mode != 0;
+    if (mode == 2 && !(cached && ws.cache_state == 2)) {  // (a reused cache keeps the verdict of its first call)
       TSAMD_HIP_TRY(hipMemsetAsync(ws.relabel_flag, 0, 4 * sizeof(int), stream));
       hipLaunchKernelGGL(spmm_probe_kernel, dim3(kProbeBlocks), dim3(256), 0, stream, col, E,
                          ws.relabel_flag);
       TSAMD_LAUNCH_CHECK();
     }
     if (mode != 0) {
+      if (cached) {
+        hipLaunchKernelGGL(spmm_fingerprint_kernel, dim3(kFingerprintWords), dim3(256), 0, stream,
+                           reinterpret_cast<const uint4 *>(mat), (uint64_t)(B * N * K) * sizeof(T) / 16,
+                           ws.cache_fp + kFingerprintWords);
+        TSAMD_LAUNCH_CHECK();
+        if (ws.cache_state == 2) {
+          ws.fp_stored = ws.cache_fp;
+          ws.fp_new = ws.cache_fp + kFingerprintWords;
+        }
+      }
       // the copy always moves 16-byte packets, whatever packet size the reduction kernel uses
       constexpr int kPV = 16 / (int)sizeof(T);
       const uint32_t pslots = (uint32_t)(K / kPV);
@@ -910,6 +973,9 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
       hipLaunchKernelGGL((spmm_permute_rows_kernel<T, kPV>), dim3(8192), dim3(256), 0, stream, mat,
                          reinterpret_cast<T *>(ws.xperm), B * N, (uint32_t)N, (uint32_t)K, lgL, ws);
       TSAMD_LAUNCH_CHECK();
+      if (cached)
+        TSAMD_HIP_TRY(hipMemcpyAsync(ws.cache_fp, ws.cache_fp + kFingerprintWords,
+                                     sizeof(unsigned long long) * kFingerprintWords, hipMemcpyDeviceToDevice, stream));
     }
   }
   hipLaunchKernelGGL(spmm_partition_kernel, dim3((unsigned int)ceil_div(ws.P + 1, 256)), dim3(256),
@@ -1003,7 +1069,8 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
                       int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
                       size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev,
                       bool relabelled = false, const int64_t *perm = nullptr,
-                      const uint32_t *wmask = nullptr) {
+                      const uint32_t *wmask = nullptr, void *cache = nullptr, size_t cache_bytes = 0,
+                      int cache_valid = 0) {
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
@@ -1013,11 +1080,23 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   if (B * M * K == 0) return TSAMD_OK;  // nothing to write
   if (!rowptr || !out || (E > 0 && (!col || !mat)) || (minmax && !arg_out))
     return TSAMD_ERR_INVALID;
-  const size_t need = carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr, relabelled);
+  // operand cache: the relabelled copy and the probe verdict live in the caller's buffer, not in the workspace
+  const size_t cache_need = operand_cache_bytes(dtype, reduce, B, N, K, E);
+  const bool use_cache = cache != nullptr && !relabelled && cache_need > 0 && cache_bytes >= cache_need &&
+                         ((uintptr_t)cache % 256) == 0 && ((uintptr_t)mat % 16) == 0;
+  const bool no_xperm_in_ws = relabelled || use_cache;
+  const size_t need = carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr, no_xperm_in_ws);
   if (!workspace || workspace_bytes_given < need) return TSAMD_ERR_WORKSPACE;
   if ((uintptr_t)workspace % 256 != 0) return TSAMD_ERR_WORKSPACE;
   Workspace ws;
-  carve(workspace, dtype, reduce, B, M, N, K, E, &ws, relabelled);
+  carve(workspace, dtype, reduce, B, M, N, K, E, &ws, no_xperm_in_ws);
+  if (use_cache) {
+    char *cb = reinterpret_cast<char *>(cache);
+    ws.relabel_flag = reinterpret_cast<int *>(cb);
+    ws.cache_fp = reinterpret_cast<unsigned long long *>(cb + 256);
+    ws.xperm = cb + kOperandCacheHeader;
+    ws.cache_state = cache_valid ? 2 : 1;
+  }
   if (relabelled) {
     if (M >= (int64_t)1 << 32) return TSAMD_ERR_UNSUPPORTED;
     ws.out_relabel = 1;
@@ -1048,6 +1127,32 @@ extern "C" int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const in
                           size_t workspace_bytes_given, void *stream_) {
   return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, workspace,
                     workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// operand cache: see include/tsamd.h
+// ---------------------------------------------------------------------------
+extern "C" size_t tsamd_spmm_operand_cache_bytes(int dtype, int reduce, int64_t B, int64_t M, int64_t N,
+                                                 int64_t K, int64_t E) {
+  (void)M;
+  if (dtype_size(dtype) == 0 || B < 0 || N < 0 || K < 0 || E < 0) return 0;
+  return operand_cache_bytes(dtype, reduce, B, N, K, E);
+}
+
+extern "C" size_t tsamd_spmm_cached_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M, int64_t N,
+                                                    int64_t K, int64_t E) {
+  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
+  return carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr, operand_cache_bytes(dtype, reduce, B, N, K, E) > 0);
+}
+
+extern "C" int tsamd_spmm_cached(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
+                                 const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
+                                 int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
+                                 size_t workspace_bytes_given, void *cache, size_t cache_bytes, int cache_valid,
+                                 void *stream_) {
+  return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, workspace,
+                    workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, false, nullptr, nullptr,
+                    cache, cache_bytes, cache_valid);
 }
 
 // ---------------------------------------------------------------------------

@@ -310,13 +310,22 @@ class PipelinedHaloSpMM(object):
                                       input_split_sizes=piece['send_counts'], group=self.group,
                                       async_op=True), send
 
-    def __call__(self, x_local: Tensor, reduce: str = 'sum') -> Tensor:
+    def __call__(self, x_local: Tensor, reduce: str = 'sum', differentiable: Optional[bool] = None) -> Tensor:
+        """`differentiable`: take the autograd-recording path (its backward issues collectives, so EVERY rank
+        must take the same path).  None (default) = any rank needs a gradient: the local verdict (grad mode,
+        requires_grad of X / the values) is agreed on with one all_reduce per call, so that a rank whose inputs
+        happen not to require grad, or that runs under no_grad, cannot leave its peers waiting in a backward
+        collective.  Pass True / False (the same on every rank) to skip that round trip."""
         if self.world == 1:
             p = self.pieces[0]
             return self.spmm_fn(p['rowptr'], p['col'], p['value'], x_local, reduce)
-        needs_grad = torch.is_grad_enabled() and (
-            x_local.requires_grad or any(p['value'] is not None and p['value'].requires_grad for p in self.pieces))
-        if needs_grad:
+        if differentiable is None:
+            needs_grad = torch.is_grad_enabled() and (
+                x_local.requires_grad or any(p['value'] is not None and p['value'].requires_grad for p in self.pieces))
+            flag = torch.tensor([1 if needs_grad else 0], dtype=torch.int32, device=x_local.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            differentiable = bool(int(flag))
+        if differentiable:
             return self._differentiable(x_local, reduce)
         buf = x_local.new_empty((self.n_needed, ) + tuple(x_local.shape[1:]))
         # one result buffer for the whole row block: every piece writes its rows in place
@@ -412,8 +421,9 @@ EXCHANGES = {'allgather': RowShardedSpMM, 'halo': HaloShardedSpMM, 'pipelined': 
 def build_with_fallback(rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
                         x_local: Tensor, reduce: str, spmm_fn: Callable, requested: str, chunks: int = 8,
                         group=None, sync: Optional[Callable] = None):
-    """Plan the requested exchange and run one trial step; if that raises (an unsupported collective,
-    an allocation that does not fit ...) the ranks agree through an all_reduce and fall back together:
+    """Plan the requested exchange and run one trial step; if that raises a RuntimeError (an unsupported
+    collective, an allocation that does not fit ... -- the exception class goes into the reason; other
+    exception types are bugs and propagate) the ranks agree through an all_reduce and fall back together:
     requested -> halo -> allgather.  Meant for failures every rank hits at the same point; a rank that
     dies in the middle of a collective sequence leaves its peers waiting, nothing recovers from that.
     -> (sharded operator, mode actually used, None or the reason of the first fall-back)."""
@@ -429,8 +439,8 @@ def build_with_fallback(rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_
             with torch.no_grad():
                 sharded(x_local, reduce)
             sync()
-        except Exception as exc:  # noqa: BLE001
-            err = '%s: %s' % (type(exc).__name__, str(exc)[:200])
+        except RuntimeError as exc:  # incl. torch.cuda.OutOfMemoryError and the c10 / RCCL errors; anything else
+            err = '%s: %s' % (type(exc).__name__, str(exc)[:200])  # (TypeError, AssertionError: a bug) propagates
         failed = torch.tensor([0 if err is None else 1], device=x_local.device)
         if world > 1:
             dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=group)

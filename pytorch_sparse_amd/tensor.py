@@ -71,11 +71,11 @@ class SparseTensor(object):
     # ---- constructors ------------------------------------------------------------------------
     @classmethod
     def from_storage(self, storage: SparseStorage):
-        # TorchScript classes have no __new__: build a (cheap, already sorted) instance, then swap
-        # the storage in so that its caches and its pending-sort state come along
-        out = SparseTensor(row=None, rowptr=torch.zeros(1, dtype=torch.long, device=storage._col.device),
-                           col=torch.zeros(0, dtype=torch.long, device=storage._col.device), value=None,
-                           sparse_sizes=(0, 0), is_sorted=True, trust_data=True)
+        # TorchScript classes have no __new__: build an instance on the storage's OWN tensors (no new
+        # allocations, no launches -- is_sorted / trust_data skip every check that reads the device), then swap
+        # the storage in so that its caches and its pending-sort state come along (reference tensor.py:36-47)
+        out = SparseTensor(row=storage._row, rowptr=storage._rowptr, col=storage._col, value=storage._value,
+                           sparse_sizes=storage._sparse_sizes, is_sorted=True, trust_data=True)
         out.storage = storage
         return out
 

@@ -88,7 +88,14 @@ if hasattr(nat, 'spmm_minmax_bw_csc'):
     run('c3_max_bw_pull_bf16_F128', lambda: nat.spmm_minmax_bw_csc(rp, c, None, xb, gb, arg, colptr, perm, row,
                                                                     want_value=False, want_mat=True),
         edges=E, algorithmic_bytes=n * 128 * (8 + 2 * 2) + 2 * n * 128 * 2)
-    del A, colptr, perm
+    vb = synth.values(E, dtype=torch.bfloat16, device=dev)
+    _, argv = nat.spmm(rp, c, vb, xb, 'max')
+    run('c3_max_bw_pull_val_bf16_F128', lambda: nat.spmm_minmax_bw_csc(rp, c, vb, xb, gb, argv, colptr, perm, row,
+                                                                        want_value=True, want_mat=True),
+        edges=E, algorithmic_bytes=n * 128 * (8 + 2 * 2) + 2 * n * 128 * 2)
+    run('c3_value_bw_plain_bf16_F128', lambda: nat.spmm_value_bw(row, rp, c, xb, gb, 'sum'), edges=E,
+        algorithmic_bytes=E * (16 + 128 * 2 + 2) + n * 128 * 2)
+    del A, colptr, perm, vb, argv
 del rp, c, row, x, g, xb, gb, arg
 torch.cuda.empty_cache()
 

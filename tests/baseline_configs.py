@@ -49,6 +49,20 @@ def gpu_ms(fn, iters=10, warm=2):
     return ts[len(ts) // 2]
 
 
+class operand_cache(object):
+    """with operand_cache(False): every product copies its dense operand again (tsamd_spmm), so that a timing loop
+    over the same X measures ALL the work of a call; the ops' default (cache on) is restored on exit."""
+
+    def __init__(self, enabled):
+        self.enabled = enabled
+
+    def __enter__(self):
+        torch.ops.tsamd.operand_cache(self.enabled)
+
+    def __exit__(self, *exc):
+        torch.ops.tsamd.operand_cache(True)
+
+
 def _ref_ops():
     try:
         from oracle import ref
@@ -153,11 +167,13 @@ def run_c2(dev, cpu=True, iters=20):
     v = synth.values(E, device=dev)
     x = synth.features(n, K, device=dev)
     op = torch.ops.torch_sparse.spmm_sum
-    ms = gpu_ms(lambda: op(None, rp, c, v, None, None, x), iters=iters)
+    with operand_cache(False):  # all the work of a call in every timed iteration
+        ms = gpu_ms(lambda: op(None, rp, c, v, None, None, x), iters=iters)
     out = op(None, rp, c, v, None, None, x)
+    ms_rep = gpu_ms(lambda: op(None, rp, c, v, None, None, x), iters=iters)  # operand cache on (default): same X again
     ba = b_alg(E, n, K, 4, True, False)
     res = dict(config='c2', workload='configs[1]: CSR SpMM-sum 2^20 x 2^20 R-MAT (E=%d), F=64 fp32' % E,
-               dtype='f32', ms=round(ms, 4), gedges_per_s=round(E / ms / 1e6, 3),
+               dtype='f32', ms=round(ms, 4), gedges_per_s=round(E / ms / 1e6, 3), ms_repeated_operand=round(ms_rep, 4),
                roofline=dict(bound='hbm', algorithmic_bytes=ba, b_min=b_min(E, n, n, K, 4, True, False),
                              achieved=round(ba / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                              frac=round(ba / ms / 1e6 / HBM_PEAK_GBS, 4), scope='whole op (all kernels of the call)'))
@@ -206,7 +222,8 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     x = synth.features(n, K, dtype=dtype, device=dev)
     g = synth.features(n, K, seed=3, dtype=dtype, device=dev)
     op = torch.ops.torch_sparse.spmm_max
-    fw_ms = gpu_ms(lambda: op(rp, c, v, x), iters=iters)
+    with operand_cache(False):
+        fw_ms = gpu_ms(lambda: op(rp, c, v, x), iters=iters)
     out, arg = op(rp, c, v, x)
     # backward, both routes: the pull over the cached CSC arrays (what adj.matmul(x, 'max').backward() runs,
     # tsamd_spmm_minmax_bw_csc) and the scatter with packed atomics behind the bare 4-argument op
@@ -225,7 +242,11 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     # autograd wiring of the drop-in front-end: adj.matmul(x, 'max').backward(g) takes the pull route
     xr = x.clone().requires_grad_()
     o2 = A.matmul(xr, 'max')
-    o2.backward(g)
+    torch.use_deterministic_algorithms(has_value)  # grad_value too: the pull only on request (torch_ops.cpp), else the fused scatter
+    try:
+        o2.backward(g)
+    finally:
+        torch.use_deterministic_algorithms(False)
     same_as_op = bool(torch.equal(xr.grad.view(torch.int16), gmat.view(torch.int16)))
     # ... and the bare reference op (no CSC arrays) the scatter route
     xr2 = x.clone().requires_grad_()
@@ -627,7 +648,8 @@ def run_c2_backward(dev, cpu=True, iters=10):
         out = A.matmul(xr, 'sum')
         out.backward(g)
         return out
-    fb_ms = gpu_ms(fwbw, iters=iters)
+    with operand_cache(False):
+        fb_ms = gpu_ms(fwbw, iters=iters)
     out = fwbw()
     gval, gmat = A.storage.value().grad, xr.grad
     b_vb = E * (16 + K * s + s) + n * K * s          # SURVEY 8d "value-grad SDDMM"

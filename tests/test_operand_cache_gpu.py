@@ -1,0 +1,109 @@
+"""The operand cache behind torch.ops.torch_sparse.spmm_* (tsamd_spmm_cached): repeated products with the same
+dense operand skip the relabelled copy of X; anything that changes X (or the pattern) is noticed."""
+import pytest
+import torch
+
+from pytorch_sparse_amd import synth
+from tests.util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import pytorch_sparse_amd  # noqa: F401
+    return torch.ops
+
+
+def _graph(dev, scale=17, ef=16):
+    rp, c = synth.rmat_csr(scale, ef, seed=0, device=dev)  # E >= 2^20, E >= 8 N, hub columns camp: the copy is made
+    return rp, c, 1 << scale
+
+
+def _stats(ops):
+    was, hits, fills = ops.tsamd.operand_cache(True)  # (re-enabling drops the entry and returns the counters so far)
+    return hits, fills
+
+
+def test_repeated_calls_hit_and_stay_bit_identical(dev, ops):
+    rp, c, n = _graph(dev)
+    v = synth.values(c.numel(), device=dev)
+    x = synth.features(n, 128, device=dev)
+    ops.tsamd.operand_cache(False)
+    ref = ops.torch_sparse.spmm_sum(None, rp, c, v, None, None, x)  # cache off: plain tsamd_spmm
+    ops.tsamd.operand_cache(True)
+    h0, f0 = _stats(ops)
+    outs = [ops.torch_sparse.spmm_sum(None, rp, c, v, None, None, x) for _ in range(4)]
+    h1, f1 = _stats(ops)
+    assert (f1 - f0, h1 - h0) == (1, 3), (h0, f0, h1, f1)
+    for o in outs:
+        assert bits_equal(o, ref)
+    # min / max of an fp32 operand use the copy as well (its own entry: another reduction class)
+    ops.tsamd.operand_cache(False)
+    mref, aref = ops.torch_sparse.spmm_max(rp, c, v, x)
+    ops.tsamd.operand_cache(True)
+    for _ in range(3):
+        mo, ao = ops.torch_sparse.spmm_max(rp, c, v, x)
+        assert bits_equal(mo, mref) and torch.equal(ao, aref)
+
+
+def test_updates_of_x_are_seen(dev, ops):
+    rp, c, n = _graph(dev)
+    v = synth.values(c.numel(), device=dev)
+    x = synth.features(n, 128, device=dev)
+    spmm = lambda xx: ops.torch_sparse.spmm_sum(None, rp, c, v, None, None, xx)  # noqa: E731
+    ops.tsamd.operand_cache(True)
+    a = spmm(x)
+    assert bits_equal(spmm(x), a)
+    # 1. in-place update through torch: the version counter moves -> refill
+    x.mul_(2.0)
+    b = spmm(x)
+    assert bits_equal(b, a * 2.0)
+    # 2. a write that bypasses the version counter (x.data): the device-side fingerprint notices a dense update
+    spmm(x)
+    x.data.add_(1.0)
+    ops.tsamd.operand_cache(False)
+    want = spmm(x)
+    ops.tsamd.operand_cache(True)
+    spmm(x)  # fill with the current contents
+    x.data.mul_(0.5)
+    got = spmm(x)  # host-side key unchanged (same version): the fingerprint check redoes the copy
+    ops.tsamd.operand_cache(False)
+    want2 = spmm(x)
+    ops.tsamd.operand_cache(True)
+    assert bits_equal(got, want2) and not bits_equal(got, want)
+    # 3. a new tensor at (possibly) the same address: different storage object -> refill, correct result
+    del x
+    y = synth.features(n, 128, seed=9, device=dev)
+    got = spmm(y)
+    ops.tsamd.operand_cache(False)
+    assert bits_equal(got, spmm(y))
+    ops.tsamd.operand_cache(True)
+    # 4. another pattern with the same operand
+    rp2, c2 = synth.rmat_csr(17, 16, seed=3, device=dev)
+    v2 = synth.values(c2.numel(), seed=4, device=dev)
+    got = ops.torch_sparse.spmm_sum(None, rp2, c2, v2, None, None, y)
+    ops.tsamd.operand_cache(False)
+    assert bits_equal(got, ops.torch_sparse.spmm_sum(None, rp2, c2, v2, None, None, y))
+    ops.tsamd.operand_cache(True)
+
+
+
+def test_autograd_and_matmul_through_the_cache(dev, ops):
+    import pytorch_sparse_amd as ts
+    rp, c, n = _graph(dev)
+    v = synth.values(c.numel(), device=dev).requires_grad_()
+    x = synth.features(n, 64, device=dev).requires_grad_()
+    g = synth.features(n, 64, seed=3, device=dev)
+    A = ts.SparseTensor(rowptr=rp, col=c, value=v, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    res = []
+    for enabled in (False, True, True):
+        ops.tsamd.operand_cache(enabled) if not enabled else None
+        v.grad = x.grad = None
+        out = A.matmul(x, 'sum')
+        out.backward(g)
+        res.append((out.detach().clone(), v.grad.clone(), x.grad.clone()))
+        ops.tsamd.operand_cache(True) if not enabled else None
+    for r in res[1:]:
+        for a, b in zip(r, res[0]):
+            assert bits_equal(a, b)

@@ -200,6 +200,12 @@ def _orchestration_worker(rank, world, port, q):
         v = synth.values(c.numel(), seed=1 + rank)
         x_local = synth.features(m, 6, seed=2 + rank)
         res = {}
+        # 0. what a plain `bench.py --gpus N` runs: BASELINE.json configs[4]'s per-GPU share with the all-gather
+        #    of X as the headline exchange (north-star wording)
+        res['defaults'] = (bench.default_workload(1), bench.default_workload(world), bench.WORKLOADS['c5']['F'],
+                           bench.WORKLOADS['c5']['edge_factor'], bench.WORKLOADS['c5']['scale'])
+        sharded0, mode0, reason0 = build_with_fallback(rp, c, v, [m] * world, x_local, 'sum', oracle_spmm, 'allgather')
+        res['default_exchange'] = (mode0, reason0, type(sharded0).__name__)
         # 1. the requested mode works: it is the one used, no fall-back reason
         sharded, mode, reason = build_with_fallback(rp, c, v, [m] * world, x_local, 'sum', oracle_spmm, 'pipelined',
                                                     chunks=3)
@@ -254,6 +260,8 @@ def test_bench_orchestration_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, res in results.items():
+        assert res['defaults'] == ('ns', 'c5', 256, 32, 21), res['defaults']
+        assert res['default_exchange'] == ('allgather', None, 'RowShardedSpMM'), res['default_exchange']
         assert res['plain'] == ('pipelined', None, 'PipelinedHaloSpMM'), res['plain']
         assert res['pipelined_equals_allgather']
         info = res['info']
@@ -268,3 +276,21 @@ def test_bench_orchestration_gloo_world2():
     assert results[0]['info']['max_rows_in_per_rank'] == results[1]['info']['max_rows_in_per_rank']
     assert results[0]['info']['max_rows_in_per_rank'] == max(r['rows_in_expected'] for r in results.values())
     assert all('injected failure' in r['fallback'][1] for r in results.values())
+
+
+def test_build_with_fallback_only_swallows_runtime_errors():
+    """A TypeError / AssertionError in the planning or the trial step is a bug, not a reason to change the
+    exchange: it propagates (VERDICT r2 weak #7); a RuntimeError at world 1 is re-raised with its class name."""
+    from pytorch_sparse_amd.parallel import build_with_fallback
+    rp, c = synth.rmat_csr(6, 4, seed=0)
+    x = synth.features(64, 3)
+
+    def bug(rowptr, col, value, x, reduce):
+        raise TypeError('a bug')
+
+    def oom(rowptr, col, value, x, reduce):
+        raise RuntimeError('out of memory')
+    with pytest.raises(TypeError):
+        build_with_fallback(rp, c, None, [64], x, 'sum', bug, 'allgather')
+    with pytest.raises(RuntimeError, match='RuntimeError: out of memory'):
+        build_with_fallback(rp, c, None, [64], x, 'sum', oom, 'allgather')

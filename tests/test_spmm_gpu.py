@@ -262,9 +262,11 @@ def test_minmax_bw_csc_pull(dev, dtype, reduce):
         acc_u = 2.0 ** -53 if dtype == torch.float64 else 2.0 ** -24
         bound = u * l1 * 1.01 + u * np.abs(egm) * 1.01 + (cnt + 1) * acc_u * l1 + floor
         assert (err <= bound).all(), (K, batch, float((err / (bound + 1e-300)).max()))
-        if has_value:
-            gv_ref, _ = nat.spmm_minmax_bw(*args[:6], want_value=True, want_mat=False)
-            assert bits_equal(gv, gv_ref)
+        if has_value:  # masked SDDMM over the records (16-byte rows) or the row-parallel LDS kernel: fp32 sums, one rounding
+            assert bits_equal(gv, gv2), 'grad_value is not deterministic'
+            tol = {torch.float32: 1e-5, torch.float64: 1e-12, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
+            scale = max(1.0, float(np.abs(egv).max()))
+            assert np.allclose(gv.cpu().double().numpy(), egv, rtol=tol, atol=tol * scale), K
         # through autograd: the front-end hands the CSC arrays over when `mat` needs a gradient
         if batch == ():
             import pytorch_sparse_amd as ts
@@ -273,7 +275,13 @@ def test_minmax_bw_csc_pull(dev, dtype, reduce):
             A = ts.SparseTensor(rowptr=rp.to(dev), col=c.to(dev), value=vr, sparse_sizes=(n, n), is_sorted=True,
                                 trust_data=True)
             o = A.matmul(xr, reduce)
-            o.backward(gout.to(dev))
+            # grad_mat alone always takes the pull; with grad_value as well only when reproducible gradients are asked for
+            # (the scatter kernel gets grad_value fused: torch_ops.cpp)
+            torch.use_deterministic_algorithms(has_value)
+            try:
+                o.backward(gout.to(dev))
+            finally:
+                torch.use_deterministic_algorithms(False)
             assert bits_equal(xr.grad, gm), 'autograd path differs from the C-ABI call'
             assert A.storage.has_csr2csc() and A.storage.has_colptr()
             if has_value:
