@@ -286,6 +286,17 @@ int tsamd_segment_reduce_balanced(int dtype, int reduce, const void *value, cons
  * ------------------------------------------------------------------------ */
 int tsamd_coo_order(const int64_t *row, const int64_t *col, int64_t E, int64_t N,
                     int64_t *counts_out, void *stream);
+/* The same probe plus the range check of the constructor (storage.py:113-129: `row.max() < M`, `col.max() < N`)
+ * in one pass: counts_out[0..3] = (#descents, #adjacent duplicates, max row id, max col id) -- one transfer
+ * instead of three.  The order is taken lexicographically on (row, col), so the number of columns need not be
+ * known yet (the constructor may still have to infer it from max col id). */
+int tsamd_coo_check(const int64_t *row, const int64_t *col, int64_t E, int64_t *counts_out, void *stream);
+/* tsamd_sort_coo decided ON THE DEVICE (no host sync): probes the order into counts_out[0..1] as
+ * tsamd_coo_order does; when the input has no descent the radix passes return at once and the outputs are
+ * (row, col, identity), otherwise they are those of tsamd_sort_coo.  Same workspace. */
+int tsamd_sort_coo_auto(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                        int64_t *row_out, int64_t *col_out, int64_t *perm_out, int64_t *counts_out,
+                        void *workspace, size_t workspace_bytes, void *stream);
 size_t tsamd_sort_coo_workspace_bytes(int64_t E);
 int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
                    int64_t N, int64_t *row_out, int64_t *col_out, int64_t *perm_out,

@@ -57,6 +57,57 @@ __global__ __launch_bounds__(256) void order_probe_kernel(const int64_t *__restr
   }
 }
 
+// order probe + range check in one pass: counts[0..1] as above, counts[2] = max row id, counts[3] = max col id
+// (counts[2..3] start at 0; ids are assumed non-negative)
+__global__ __launch_bounds__(256) void order_check_kernel(const int64_t *__restrict__ row,
+                                                         const int64_t *__restrict__ col, int64_t n,
+                                                         unsigned long long *counts) {
+  unsigned int desc = 0, dup = 0;
+  int64_t mr = 0, mc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = row[i], c = col[i];
+    mr = r > mr ? r : mr;
+    mc = c > mc ? c : mc;
+    if (i > 0) {  // lexicographic (row, col): the same order as row * ncols + col, without knowing ncols
+      const int64_t pr = row[i - 1], pc = col[i - 1];
+      desc += (r < pr) || (r == pr && c < pc);
+      dup += (r == pr) && (c == pc);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    desc += lane_xor(desc, off);
+    dup += lane_xor(dup, off);
+    const int64_t orr = lane_xor(mr, off), oc = lane_xor(mc, off);
+    mr = orr > mr ? orr : mr;
+    mc = oc > mc ? oc : mc;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (desc) atomicAdd(&counts[0], (unsigned long long)desc);
+    if (dup) atomicAdd(&counts[1], (unsigned long long)dup);
+    atomicMax(&counts[2], (unsigned long long)mr);
+    atomicMax(&counts[3], (unsigned long long)mc);
+  }
+}
+
+// the outputs of a device-decided sort when the input turned out to be sorted: a copy and the identity
+__global__ void sort_auto_finish_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
+                                        const int64_t *__restrict__ keys_sorted, int64_t n, int64_t ncols,
+                                        const int64_t *__restrict__ todo, int64_t *__restrict__ row_out,
+                                        int64_t *__restrict__ col_out, int64_t *__restrict__ perm_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (*todo == 0) {
+    if (row_out) row_out[i] = row[i];
+    if (col_out) col_out[i] = col[i];
+    perm_out[i] = i;
+  } else {
+    const int64_t k = keys_sorted[i];
+    const int64_t r = k / ncols;
+    if (row_out) row_out[i] = r;
+    if (col_out) col_out[i] = k - r * ncols;
+  }
+}
+
 __device__ inline bool is_head(const int64_t *row, const int64_t *col, int64_t i) {
   return i == 0 || row[i] != row[i - 1] || col[i] != col[i - 1];
 }
@@ -160,6 +211,52 @@ extern "C" int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E,
                        (const int64_t *)keys_sorted, E, N, row_out, col_out);
     TSAMD_LAUNCH_CHECK();
   }
+  return TSAMD_OK;
+}
+
+// sort_coo decided on the device: counts_out[0..1] = (#descents, #adjacent duplicates) of the INPUT; when
+// there is no descent the radix passes return at once and the outputs are a copy + the identity.
+extern "C" int tsamd_sort_coo_auto(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                                   int64_t *row_out, int64_t *col_out, int64_t *perm_out,
+                                   int64_t *counts_out, void *workspace, size_t workspace_bytes,
+                                   void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (E < 0 || M < 0 || N < 0 || !counts_out) return TSAMD_ERR_INVALID;
+  int st = tsamd_coo_order(row, col, E, N, counts_out, stream_);
+  if (st != TSAMD_OK || E == 0) return st;
+  if (!row || !col || !perm_out) return TSAMD_ERR_INVALID;
+  if ((unsigned __int128)M * (unsigned __int128)N >= ((unsigned __int128)1 << 63))
+    return TSAMD_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < tsamd_sort_coo_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
+  char *p = reinterpret_cast<char *>(workspace);
+  int64_t *keys = reinterpret_cast<int64_t *>(p);
+  p += align_up(sizeof(int64_t) * (size_t)E, 256);
+  int64_t *keys_sorted = reinterpret_cast<int64_t *>(p);
+  p += align_up(sizeof(int64_t) * (size_t)E, 256);
+  const unsigned int blocks = (unsigned int)ceil_div(E, 256);
+  hipLaunchKernelGGL(make_keys_kernel, dim3(blocks), dim3(256), 0, stream, row, col, E, N, keys);
+  TSAMD_LAUNCH_CHECK();
+  st = sort_pairs(keys, nullptr, keys_sorted, perm_out, E, key_bits_for(M, N), p, stream, counts_out);
+  if (st != TSAMD_OK) return st;
+  hipLaunchKernelGGL(sort_auto_finish_kernel, dim3(blocks), dim3(256), 0, stream, row, col,
+                     (const int64_t *)keys_sorted, E, N, (const int64_t *)counts_out, row_out, col_out, perm_out);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+// counts_out[0..3] = (#descents, #adjacent duplicates, max row id, max col id): everything the
+// SparseStorage constructor has to read back, in one pass and one transfer
+extern "C" int tsamd_coo_check(const int64_t *row, const int64_t *col, int64_t E, int64_t *counts_out,
+                               void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (E < 0 || !counts_out) return TSAMD_ERR_INVALID;
+  TSAMD_HIP_TRY(hipMemsetAsync(counts_out, 0, 4 * sizeof(int64_t), stream));
+  if (E == 0) return TSAMD_OK;
+  if (!row || !col) return TSAMD_ERR_INVALID;
+  const int64_t nblk = ceil_div(E, 256);
+  hipLaunchKernelGGL(order_check_kernel, dim3((unsigned int)(nblk < 2048 ? nblk : 2048)), dim3(256), 0,
+                     stream, row, col, E, reinterpret_cast<unsigned long long *>(counts_out));
+  TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }
 

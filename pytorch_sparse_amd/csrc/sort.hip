@@ -28,10 +28,13 @@ constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 pairs per workgrou
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 
+// `todo` (may be NULL): device word that says whether there is anything to sort -- the number of descents
+// of the key sequence (tsamd_sort_coo_auto).  Zero = already sorted: the pass kernels return at once.
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const int64_t *__restrict__ keys,
                                                                  int64_t n, int shift,
                                                                  int64_t *__restrict__ hist,
-                                                                 int64_t nb) {
+                                                                 int64_t nb, const int64_t *__restrict__ todo) {
+  if (todo != nullptr && *todo == 0) return;
   __shared__ uint32_t cnt[kRadix];
   cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -48,7 +51,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const int64_t 
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const int64_t *__restrict__ keys_in, const int64_t *__restrict__ vals_in,
     int64_t *__restrict__ keys_out, int64_t *__restrict__ vals_out, int64_t n, int shift,
-    const int64_t *__restrict__ hist_scanned, int64_t nb) {
+    const int64_t *__restrict__ hist_scanned, int64_t nb, const int64_t *__restrict__ todo) {
+  if (todo != nullptr && *todo == 0) return;
   // gfx950 only: the tile lives in LDS (160 KB per CU there, 64 KB on older parts)
   static_assert(sizeof(int64_t) * 2 * kSortTile + sizeof(uint32_t) * 5 * kRadix + sizeof(int64_t) * (kRadix + 8) <=
                     160 * 1024,
@@ -161,7 +165,8 @@ size_t sort_pairs_workspace_bytes(int64_t n) {
 }
 
 int sort_pairs(const int64_t *keys_in, const int64_t *vals_in, int64_t *keys_out,
-               int64_t *vals_out, int64_t n, int key_bits, void *workspace, hipStream_t stream) {
+               int64_t *vals_out, int64_t n, int key_bits, void *workspace, hipStream_t stream,
+               const int64_t *todo) {
   if (n <= 0) return TSAMD_OK;
   if (key_bits < 0) key_bits = 0;
   if (key_bits > 63) key_bits = 63;
@@ -189,12 +194,12 @@ int sort_pairs(const int64_t *keys_in, const int64_t *vals_in, int64_t *keys_out
     int64_t *dst_v = to_out ? vals_out : tvals;
     const int shift = pass * kRadixBits;
     hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned int)nb), dim3(kSortThreads), 0, stream,
-                       src_k, n, shift, hist, nb);
+                       src_k, n, shift, hist, nb, todo);
     TSAMD_LAUNCH_CHECK();
     int st = exclusive_scan_i64(hist, hist, kRadix * nb, nullptr, scan_ws, stream);
     if (st != TSAMD_OK) return st;
     hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned int)nb), dim3(kSortThreads), 0, stream,
-                       src_k, src_v, dst_k, dst_v, n, shift, (const int64_t *)hist, nb);
+                       src_k, src_v, dst_k, dst_v, n, shift, (const int64_t *)hist, nb, todo);
     TSAMD_LAUNCH_CHECK();
     src_k = dst_k;
     src_v = dst_v;

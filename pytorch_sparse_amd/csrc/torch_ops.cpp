@@ -680,6 +680,40 @@ Tensor coo_order(Tensor row, Tensor col, int64_t N) {
   return counts;
 }
 
+// -> int64[4] on the device: {#descents, #adjacent duplicates, max row id, max col id}
+Tensor coo_check(Tensor row, Tensor col) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  Tensor counts = torch::empty({4}, row.options());
+  check_status(tsamd_coo_check(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), row.numel(),
+                               counts.data_ptr<int64_t>(), current_stream(row)),
+               "tsamd_coo_check");
+  return counts;
+}
+
+// sort_coo decided on the device, no host sync: -> (row_sorted, col_sorted, perm, counts[2] on the device)
+std::tuple<Tensor, Tensor, Tensor, Tensor> sort_coo_auto(Tensor row, Tensor col, int64_t M, int64_t N) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  Tensor perm = torch::empty({E}, row.options()), row_s = torch::empty({E}, row.options()),
+         col_s = torch::empty({E}, row.options()), counts = torch::empty({2}, row.options());
+  Tensor ws = workspace(tsamd_sort_coo_workspace_bytes(E), row);
+  check_status(tsamd_sort_coo_auto(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N,
+                                   row_s.data_ptr<int64_t>(), col_s.data_ptr<int64_t>(), perm.data_ptr<int64_t>(),
+                                   counts.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), current_stream(row)),
+               "tsamd_sort_coo_auto");
+  return std::make_tuple(row_s, col_s, perm, counts);
+}
+
 // stable sort by row * N + col -> (row_sorted, col_sorted, perm); with index=false only perm
 std::tuple<Tensor, Tensor, Tensor> sort_coo(Tensor row, Tensor col, int64_t M, int64_t N,
                                             bool index) {
@@ -1363,6 +1397,8 @@ static auto registry = torch::RegisterOperators()
                            .op("tsamd::operand_cache", &operand_cache_ctl)
                            .op("tsamd::coo_order", &coo_order)
                            .op("tsamd::sort_coo", &sort_coo)
+                           .op("tsamd::coo_check", &coo_check)
+                           .op("tsamd::sort_coo_auto", &sort_coo_auto)
                            .op("tsamd::coalesce_index", &coalesce_index)
                            .op("tsamd::segment_reduce", &segment_reduce)
                            .op("tsamd::spspmm", &spspmm)

@@ -3,8 +3,10 @@
 Same role and method names as ``torch_sparse/storage.py`` of the reference; the work is done by
 fused HIP ops instead of Python/ATen/torch_scatter compositions:
 
-  * sort-on-construct (reference storage.py:149-162)  -> one ``tsamd::coo_order`` probe (the single
-    host sync) + one ``tsamd::sort_coo`` radix sort that emits sorted row/col and the permutation;
+  * sort-on-construct (reference storage.py:149-162)  -> ``tsamd::coo_check`` (order probe + range check /
+    size inference in one pass, the single host sync) + one ``tsamd::sort_coo`` radix sort that emits sorted
+    row/col and the permutation; with ``trust_data=True`` and both sizes given NO host sync at all: the sort
+    is decided on the device (``tsamd::sort_coo_auto``);
   * ``csr2csc`` (storage.py:407-416)                   -> ``tsamd::sort_coo`` on (col, row);
   * ``coalesce`` (storage.py:436-466)                  -> ``tsamd::coalesce_index`` +
     ``tsamd::segment_reduce`` (values are read through the permutation, duplicates reduced in
@@ -94,29 +96,45 @@ class SparseStorage(object):
         col = col.contiguous()
         nnz = col.numel()
 
-        # sizes: given, or inferred (inference reads a maximum back from the device)
+        # sizes: given, or inferred.  On the GPU everything the constructor may have to read back -- the order
+        # probe of sort-on-construct and the two maxima of the range check / size inference -- comes from ONE
+        # fused pass and ONE transfer (tsamd::coo_check); with trust_data=True and both sizes given nothing
+        # is read back at all (the sort is then decided on the device, tsamd::sort_coo_auto).
         M: int = 0
         given_m: Optional[int] = None
         given_n: Optional[int] = None
         if sparse_sizes is not None:
             given_m, given_n = sparse_sizes
+        need_row_max = rowptr is None and nnz > 0 and (given_m is None or not trust_data)
+        need_col_max = nnz > 0 and (given_n is None or not trust_data)
+        max_row: int = -1
+        max_col: int = -1
+        descents: int = -1  # unknown
+        if col.is_cuda and row is not None and (need_row_max or need_col_max):
+            counts: List[int] = torch.ops.tsamd.coo_check(row.contiguous(), col).tolist()  # the one host sync
+            descents, max_row, max_col = counts[0], counts[2], counts[3]
+        else:
+            if need_row_max and row is not None:
+                max_row = int(row.max())
+            if need_col_max:
+                max_col = int(col.max())
         if given_m is not None:
             M = given_m
             if rowptr is not None:
                 assert rowptr.numel() - 1 == M
-            elif row is not None and row.numel() > 0 and not trust_data:
-                assert int(row.max()) < M
+            elif need_row_max:
+                assert max_row < M
         elif rowptr is not None:
             M = rowptr.numel() - 1
         elif row is not None and row.numel() > 0:
-            M = int(row.max()) + 1
+            M = max_row + 1
         N: int = 0
         if given_n is not None:
             N = given_n
-            if nnz > 0 and not trust_data:
-                assert int(col.max()) < N
+            if need_col_max:
+                assert max_col < N
         elif nnz > 0:
-            N = int(col.max()) + 1
+            N = max_col + 1
         self._sparse_sizes = (M, N)
 
         self._row = _checked(row, col, nnz)
@@ -139,8 +157,20 @@ class SparseStorage(object):
         self._pending_sort = (not is_sorted) and nnz > 1 and not col.is_cuda
         if (not is_sorted) and nnz > 1 and col.is_cuda:
             r = self.row()
-            descents = int(torch.ops.tsamd.coo_order(r, col, N)[0])  # the one host sync
-            if descents > 0:
+            keep_caches = rowptr is not None or csr2csc is not None or csc2csr is not None
+            if descents < 0 and keep_caches:
+                # caller-supplied views of the pattern survive when the input turns out to be sorted (as in the
+                # reference, storage.py:149-162): that needs the verdict on the host
+                descents = int(torch.ops.tsamd.coo_order(r, col, N)[0])
+            if descents < 0:
+                # nothing was read back: sort decided on the device (a sorted input costs the probe, a few
+                # kernels that return at once and one copy) -- no host sync in this constructor
+                rs, cs, perm, _ = torch.ops.tsamd.sort_coo_auto(r, col, M, N)
+                self._row = rs
+                self._col = cs
+                if value is not None:
+                    self._value = value[perm]
+            elif descents > 0:
                 rs, cs, perm = torch.ops.tsamd.sort_coo(r, col, M, N, True)
                 self._row = rs
                 self._col = cs

@@ -561,3 +561,50 @@ def test_row_shards_as_logical_ranks_on_one_gpu(ts, dev, P):
         else:
             assert torch.allclose(torch.cat(direct), full, rtol=1e-5, atol=1e-5), reduce
             assert torch.equal(torch.cat(halo), torch.cat(direct)), reduce  # same blocks, relabelled columns
+
+
+# ---- construction without host syncs ---------------------------------------------
+@pytest.mark.parametrize('presorted', [False, True])
+def test_constructor_is_sync_free_with_trusted_data(dev, ts, presorted):
+    """SparseTensor(row, col, value, sparse_sizes, trust_data=True) on device tensors reads nothing back: the sort
+    is decided on the device (tsamd::sort_coo_auto).  torch's sync debug mode turns any synchronising call
+    (.item(), .tolist(), .cpu(), nonzero ...) into an error; the result equals the synchronising constructor's."""
+    from pytorch_sparse_amd import synth
+    m, n, nnz = 3000, 2500, 200000
+    row, col = synth.uniform_edges(m, n, nnz, seed=3, device=dev)
+    val = synth.values(nnz, device=dev)
+    if presorted:
+        perm = torch.argsort(row * n + col, stable=True)
+        row, col, val = row[perm], col[perm], val[perm]
+    ref = ts.SparseTensor(row=row, col=col, value=val, sparse_sizes=(m, n))  # one sync (range check + order probe)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        with pytest.raises(RuntimeError):  # the detector works on this build: a read-back raises
+            int(row[0])
+        A = ts.SparseTensor(row=row, col=col, value=val, sparse_sizes=(m, n), trust_data=True)
+        rowptr = A.storage.rowptr()
+        out = A.matmul(synth.features(n, 8, device=dev))  # and the product right behind it, still no sync
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    r0, c0, v0 = ref.coo()
+    r1, c1, v1 = A.coo()
+    assert torch.equal(r0, r1) and torch.equal(c0, c1) and torch.equal(v0, v1)
+    assert torch.equal(rowptr, ref.storage.rowptr())
+    assert torch.equal(out, ref.matmul(synth.features(n, 8, device=dev)))
+
+
+def test_constructor_single_sync_checks_and_infers(dev, ts):
+    """Without trust_data the range check, the size inference and the order probe share one read-back
+    (tsamd::coo_check); out-of-range ids still raise, sizes are still inferred."""
+    row = torch.tensor([3, 0, 2, 0], device=dev)
+    col = torch.tensor([1, 5, 0, 2], device=dev)
+    A = ts.SparseTensor(row=row, col=col)
+    assert A.sparse_sizes() == (4, 6)
+    assert A.storage.row().tolist() == [0, 0, 2, 3] and A.storage.col().tolist() == [2, 5, 0, 1]
+    with pytest.raises(Exception):
+        ts.SparseTensor(row=row, col=col, sparse_sizes=(3, 6))
+    with pytest.raises(Exception):
+        ts.SparseTensor(row=row, col=col, sparse_sizes=(4, 5))
+    counts = torch.ops.tsamd.coo_check(row, col).tolist()
+    assert counts == [2, 0, 3, 5]
