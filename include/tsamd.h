@@ -329,7 +329,8 @@ int tsamd_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t
  *        it references); bins[2*M] = ids of the rows with more than 512 products by size class
  *        (medium <= 4096 | large, M slots each; rows of <= 512 products are not listed, their
  *        kernels run over all rows in natural order); stats (DEVICE int64[8]): [2]=#medium
- *        [3]=#large  [4]=products in large rows.  colB32 [nnz(B)] = the column ids of B as 32-bit
+ *        [3]=#large  [4]=products in large rows  [5]=products of the largest row (must be < 2^31: the
+ *        per-(row, column range) counters of stage 2 are 32-bit; the caller rejects bigger rows).  colB32 [nnz(B)] = the column ids of B as 32-bit
  *        words (caller-allocated): stages 2 and 4 gather short B rows from all over the array and read
  *        this copy (half the lines per row).
  *        --> host reads stats (sync 1: grid sizes and the workspace of the large rows).

@@ -1,8 +1,9 @@
 """Functional coalesce on raw COO tensors (API of torch_sparse/coalesce.py:5-25).
 
 Runs straight on the fused ops, without building a SparseStorage: one order probe, at most one
-radix sort, one head-flag/scan/compaction pass, and a segmented reduction that reads the values
-through the sort permutation (the permuted value tensor is never materialised).
+radix sort (decided on the device), one head-flag/scan/compaction pass, ONE host sync (the output size),
+and a segmented reduction that reads the values through the sort permutation (the permuted value tensor
+is never materialised).
 """
 from typing import Optional, Tuple
 
@@ -21,18 +22,18 @@ def sorted_unique(row: Tensor, col: Tensor, m: int, n: int):
     nnz = col.numel()
     if nnz <= 1:
         return row, col, None, None, nnz
-    descents, dups = torch.ops.tsamd.coo_order(row, col, n).tolist()  # host sync
-    perm = None
-    if descents > 0:
-        row, col, perm = torch.ops.tsamd.sort_coo(row, col, m, n, True)
-        dups = -1  # adjacent duplicates of the unsorted order say nothing; count after the sort
-    if dups == 0:
-        return row, col, perm, None, nnz
-    row_u, col_u, seg_ptr, n_dev = torch.ops.tsamd.coalesce_index(row, col)
-    n_u = nnz - dups if dups > 0 else int(n_dev)  # second sync only on the sorted path
+    # everything is enqueued without looking at the data -- order probe, a radix sort that returns at once when
+    # the probe finds no descent (tsamd::sort_coo_auto), head flags + scan + compaction -- and ONE transfer brings
+    # back what the output size depends on: (#descents of the input, #distinct pairs)
+    row_s, col_s, perm, counts = torch.ops.tsamd.sort_coo_auto(row, col, m, n)
+    row_u, col_u, seg_ptr, n_dev = torch.ops.tsamd.coalesce_index(row_s, col_s)
+    descents, n_u = torch.cat([counts[:1], n_dev]).tolist()  # the one host sync
+    perm_opt: Optional[Tensor] = perm if descents > 0 else None
+    if descents == 0:
+        row_s, col_s = row, col  # already in order: hand the caller's own tensors back (as the reference does)
     if n_u == nnz:
-        return row, col, perm, None, nnz
-    return row_u[:n_u], col_u[:n_u], perm, seg_ptr, n_u
+        return row_s, col_s, perm_opt, None, nnz
+    return row_u[:n_u], col_u[:n_u], perm_opt, seg_ptr, n_u
 
 
 def coalesce(index: Tensor, value: Optional[Tensor], m: int, n: int,

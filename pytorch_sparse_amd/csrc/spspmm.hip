@@ -38,7 +38,7 @@ constexpr int kSmallCap = 512;    // products handled by one wave (LDS radix sor
 constexpr int kMediumCap = 4096;  // products handled by one 256-thread workgroup
 
 // stats layout (device int64[8])
-enum { ST_NMEDIUM = 2, ST_NLARGE = 3, ST_PLARGE = 4 };
+enum { ST_NMEDIUM = 2, ST_NLARGE = 3, ST_PLARGE = 4, ST_PMAX = 5 };
 
 // products(i) = sum over the entries k of row i of A of |B_k|.  8 lanes per row (32 rows per
 // 256-thread workgroup): rows of a few dozen entries keep most lanes busy, hub rows just loop.
@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256) void spspmm_bin_kernel(const int64_t *__restri
     base = (unsigned long long)lane_read((int64_t)base, 0);
     if (b == bin) bins[(int64_t)bin * M + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = i;
   }
-  if (b == 1) atomicAdd(&stats[ST_PLARGE], (unsigned long long)p);  // few rows: per-row atomics are fine
+  if (b == 1) {  // few rows: per-row atomics are fine
+    atomicAdd(&stats[ST_PLARGE], (unsigned long long)p);
+    atomicMax(&stats[ST_PMAX], (unsigned long long)p);  // largest row: the (row, range) counters are 32-bit
+  }
 }
 
 template <int NW>

@@ -840,6 +840,9 @@ std::tuple<Tensor, Tensor, Tensor> spspmm(Tensor rowptrA, Tensor colA, OptTensor
   Tensor h = stats.cpu();  // sync 1: grid sizes, workspace of the rows beyond the LDS capacity
   const int64_t *hs = h.data_ptr<int64_t>();
   const int64_t n_medium = hs[2], n_large = hs[3], P_large = hs[4];
+  // the large-row path counts the products of a (row, column range) bin in 32-bit LDS words
+  TORCH_CHECK(hs[5] < ((int64_t)1 << 31), "spspmm: a row of the product has ", hs[5],
+              " intermediate products; rows of 2^31 or more are not supported");
 
   const size_t ws_bytes = tsamd_spspmm_workspace_bytes(dt, n_large, P_large, N);
   if (n_large > 0) {  // data dependent scratch: refuse politely instead of an allocator OOM

@@ -1,8 +1,8 @@
 """Legacy functional SpMM ``spmm(index, value, m, n, matrix)`` (reference: torch_sparse/spmm.py).
 
 The reference gathers ``matrix[col] * value`` into an ``[nnz, F]`` temporary and scatter-adds it.
-Here the COO is ordered once (stable radix sort, duplicates kept -- they add up, as in the
-reference) and the CSR SpMM kernel does the rest; autograd w.r.t. ``value`` and ``matrix`` comes
+Here the COO is ordered once (stable radix sort decided on the device, duplicates kept -- they add up,
+as in the reference) and the CSR SpMM kernel does the rest, without a host sync; autograd w.r.t. ``value`` and ``matrix`` comes
 from the op's own backward kernels.
 """
 import torch
@@ -15,10 +15,11 @@ def spmm(index: Tensor, value: Tensor, m: int, n: int, matrix: Tensor) -> Tensor
     matrix = matrix if matrix.dim() > 1 else matrix.unsqueeze(-1)
     value = value.to(matrix.dtype) if value.dtype != matrix.dtype else value
     nnz = col.numel()
-    perm = None
-    if nnz > 1 and int(torch.ops.tsamd.coo_order(row, col, n)[0]) > 0:
-        row, col, perm = torch.ops.tsamd.sort_coo(row, col, m, n, True)
-        value = value[perm]  # differentiable gather
+    if nnz > 1:
+        # ordered on the device without asking the host (tsamd::sort_coo_auto: a sorted input only pays the
+        # probe and a copy): the whole call enqueues kernels and returns -- no sync
+        row, col, perm, _ = torch.ops.tsamd.sort_coo_auto(row.contiguous(), col.contiguous(), m, n)
+        value = value[perm]  # differentiable gather (the identity when the input was in order)
     rowptr = torch.ops.torch_sparse.ind2ptr(row, m)
     need_csc = matrix.requires_grad
     colptr = csr2csc = None

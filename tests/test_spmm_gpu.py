@@ -522,3 +522,42 @@ def test_spmm_permuted_equals_materialised_view(dev, reduce):
         assert bits_equal(out, want)
         if arg is not None:
             assert torch.equal(arg, warg)
+
+
+def test_small_int_mean_with_wrapped_divisor_is_pinned(dev):
+    """Documented divergence (csrc/common.h mean_of): the reference divides the wrapped sum by the row length
+    CAST TO THE ELEMENT TYPE (reducer.h:74), which is 0 -- a SIGFPE there -- for a uint8 / int8 row of 256
+    entries or an int16 row of 65536.  Here such a row gives 0; lengths that wrap to a non-zero divisor follow
+    the reference's arithmetic exactly (300 entries of uint8: divisor 300 & 255 = 44)."""
+    for dtype, wrap in ((torch.uint8, 256), (torch.int8, 256), (torch.int16, 65536)):
+        for deg in (wrap, 2 * wrap, wrap + 44):
+            rp = torch.tensor([0, deg, deg + 3])
+            c = torch.cat([torch.arange(deg) % 7, torch.tensor([0, 1, 2])])
+            x = torch.arange(1, 8, dtype=torch.int64).view(7, 1).repeat(1, 4).to(dtype)
+            out, _ = nat.spmm(rp.to(dev), c.to(dev), None, x.to(dev), 'mean')
+            s = int(x[c[:deg], 0].to(torch.int64).sum())
+            info = torch.iinfo(dtype)
+            span = info.max - info.min + 1
+            wrapped_sum = (s - info.min) % span + info.min
+            div = (deg - info.min) % span + info.min if dtype != torch.uint8 else deg % 256
+            if dtype != torch.uint8:
+                div = (deg + (1 << (info.bits - 1))) % span - (1 << (info.bits - 1))
+            want0 = 0 if div == 0 else int(wrapped_sum / div)  # C++ integer division truncates toward zero
+            assert out[0].cpu().tolist() == [want0] * 4, (dtype, deg, out[0].cpu().tolist(), want0)
+            assert out[1].cpu().tolist() == [2] * 4  # (1 + 2 + 3) / 3: the short row next to it is untouched
+
+
+def test_minmax_all_init_value_reports_no_winner(dev):
+    """A row whose every candidate equals the reducer's init value (or is NaN) has no strict winner
+    (reducer.h:63-67): out = the init value as the reference writes it, arg = E here (the reference leaves
+    a stale index -- the one documented divergence of arg_out, masked in tests/test_oracle.py)."""
+    big = torch.finfo(torch.float32).max
+    rp = torch.tensor([0, 2, 4])
+    c = torch.tensor([0, 1, 0, 1])
+    x = torch.tensor([[big, float('nan')], [big, float('nan')]])
+    out, arg = nat.spmm(rp.to(dev), c.to(dev), None, x.to(dev), 'min')
+    assert arg.cpu().tolist() == [[4, 4], [4, 4]]
+    assert out.cpu()[:, 0].tolist() == [big, big]
+    lo = torch.tensor([[-big, float('nan')], [-big, float('nan')]])
+    out, arg = nat.spmm(rp.to(dev), c.to(dev), None, lo.to(dev), 'max')
+    assert arg.cpu().tolist() == [[4, 4], [4, 4]] and out.cpu()[:, 0].tolist() == [-big, -big]
