@@ -439,8 +439,16 @@ __device__ __forceinline__ void write_carry(void *cval, int64_t *carg, uint64_t 
 // ---------------------------------------------------------------------------
 // SHORT: instantiate the "short rows side by side" path (launched for rows of <= 128 bytes only: its
 // registers would cost the wide-row instantiation two waves per SIMD)
+// The min / max instantiations for wide rows need 61-63 VGPRs but 106 SGPRs, one granule more than fits
+// 8 waves per SIMD; asking for 8 makes the allocator fit (experiment knob: -DTSAMD_MINMAX_WAVES=0 turns it off).
+#ifndef TSAMD_MINMAX_WAVES
+#define TSAMD_MINMAX_WAVES 8
+#endif
+template <int RED, bool SHORT, bool MASKED>
+constexpr int kMinWavesPerEU = (RED != RED_ADD && !SHORT && !MASKED) ? TSAMD_MINMAX_WAVES : 0;
+
 template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false>
-__global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_merge_kernel(
+__global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, MASKED>)) void spmm_merge_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
     const T *__restrict__ value, const T *__restrict__ mat, T *__restrict__ out,
     int64_t *__restrict__ arg_out, int64_t M, int64_t N, uint32_t K, int64_t E,

@@ -49,6 +49,32 @@ def gpu_ms(fn, iters=10, warm=2):
     return ts[len(ts) // 2]
 
 
+_PMC = None
+
+
+def pmc_traffic(workload, kernel_substr):
+    """Counter-measured fabric bytes per call of one kernel (FETCH_SIZE x 2 + WRITE_SIZE, calibrated in
+    profiles/traffic_ns.json) from the committed builder-run profile profiles/r03_pmc.json -- NOT measured in this
+    run (PMC passes need rocprofv3).  -> dict for a roofline's `traffic` fields, or {} when the file is absent."""
+    global _PMC
+    if _PMC is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r03_pmc.json')
+        try:
+            import json
+            _PMC = json.load(open(path))
+        except Exception:
+            _PMC = {}
+    w = _PMC.get('workloads', {}).get(workload)
+    if not w:
+        return {}
+    for k, v in w['kernels'].items():
+        if kernel_substr in k and 'fabric_bytes_per_call_x2_rule' in v:
+            return dict(traffic=v['fabric_bytes_per_call_x2_rule'], traffic_kernel=k, traffic_kernel_us=round(v['us_per_call'], 1),
+                        traffic_tb_per_s=v.get('fabric_tb_per_s_x2_rule'),
+                        traffic_source='profiles/r03_pmc.json (%s), rocprofv3 --pmc builder run, NOT measured in this run' % workload)
+    return {}
+
+
 class operand_cache(object):
     """with operand_cache(False): every product copies its dense operand again (tsamd_spmm), so that a timing loop
     over the same X measures ALL the work of a call; the ops' default (cache on) is restored on exit."""
@@ -260,7 +286,7 @@ def run_c3(dev, has_value, cpu=True, iters=10):
                dtype='bf16', fw_ms=round(fw_ms, 4), bw_ms=round(bw_ms, 4), gedges_per_s_fw=round(E / fw_ms / 1e6, 3),
                roofline=dict(bound='hbm', algorithmic_bytes=ba_fw, achieved=round(ba_fw / fw_ms / 1e6, 1),
                              peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ba_fw / fw_ms / 1e6 / HBM_PEAK_GBS, 4),
-                             scope='forward, whole op'),
+                             scope='forward, whole op', **pmc_traffic('c3_max_fw_bf16_F128', 'spmm_merge_kernel')),
                bw_atomic_ms=round(bw_atomic_ms, 4),
                roofline_bw=dict(bound='hbm', algorithmic_bytes=ba_bw, achieved=round(ba_bw / bw_ms / 1e6, 1),
                                 peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ba_bw / bw_ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -270,6 +296,9 @@ def run_c3(dev, has_value, cpu=True, iters=10):
                                 bytes_pull_model=int(E * (16 + K * 2 + K // 8) + n * K * 8 + n * K * 2),
                                 frac_pull_model=round((E * (16 + K * 2 + K // 8) + n * K * 8 + n * K * 2) / bw_ms / 1e6 / HBM_PEAK_GBS, 4),
                                 atomic_route_frac=round(ba_bw / bw_atomic_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                traffic_pull=dict(masked_merge=pmc_traffic('c3_max_bw_pull_bf16_F128', 'spmm_merge_kernel'),
+                                                  winner_records=pmc_traffic('c3_max_bw_pull_bf16_F128', 'minmax_winrec_kernel')),
+                                traffic_atomic=pmc_traffic('c3_max_bw_atomic_bf16_F128', 'spmm_minmax_bw_kernel'),
                                 note='bw_atomic_ms = tsamd_spmm_minmax_bw (bare spmm_min/max op): bounded by the device-scope '
                                      'atomic rate (20 G 64-byte segments/s, profiles/r02_ubench_atomics.csv), not by bytes'))
     par = dict()
@@ -562,6 +591,7 @@ def run_construct(dev, cpu=True, iters=5):
                roofline={k: _roof(nbytes[k], ms[k], 'whole call incl. host syncs; bytes = E(16+s) in + E\'(16+s) out '
                                   '(SURVEY 8d; the radix passes are implementation cost)') for k in ms})
     res['ms_total'] = round(sum(ms.values()), 4)
+    res['roofline']['construct'].update(pmc_traffic('sort_coo_7m5', 'radix_scatter_kernel'))
     # ---- parity: every index output bit-exact against the numpy restatement, on the host ----
     rn, cn, vn = row.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
     rs, cs, perm = npo.sort_coo(rn, cn, m, n)
@@ -660,7 +690,8 @@ def run_c2_backward(dev, cpu=True, iters=10):
                         'grad_mat through adj.matmul(x).backward(g)' % E,
                value_bw_ms=round(vb_ms, 4), fw_bw_ms=round(fb_ms, 4), gedges_per_s_value_bw=round(E / vb_ms / 1e6, 3),
                gedges_per_s_fw_bw=round(E / fb_ms / 1e6, 3),
-               roofline=_roof(b_vb, vb_ms, 'spmm_value_bw_kernel; bytes = E(16 + F s + s) + M F s (SURVEY 8d)'),
+               roofline=dict(_roof(b_vb, vb_ms, 'spmm_value_bw_kernel; bytes = E(16 + F s + s) + M F s (SURVEY 8d)'),
+                             **pmc_traffic('c2_value_bw_f32_F64', 'spmm_value_bw_kernel')),
                roofline_fw_bw=_roof(b_fw + b_vb + b_gm, fb_ms, 'three kernels families of one training step: forward B_alg + '
                                     'value-grad bytes + B_alg of A^T G (+8 E for csr2csc)'))
     # independent fp64 yardsticks with ATen on the device (chunked gathers), none of the kernels under test
