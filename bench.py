@@ -443,6 +443,13 @@ def main():
                     roofline=roofline)
         if exchange_info is not None:
             line['exchange'] = exchange_info
+            # the N = 1 default of this script is ANOTHER workload (ns); the single-GPU rate of THIS workload -- the
+            # reference point of a weak-scaling efficiency -- is the local SpMM without the exchange:
+            line['weak_scaling_reference'] = dict(
+                gedges_per_s_per_gpu=round(E / exchange_info['spmm_only_ms'] / 1e6, 3),
+                note='one rank\'s block of this workload multiplied without any exchange (spmm_only_ms); compare '
+                     'value / n_gpus with this, not with the N = 1 default run (workload ns); `python bench.py --gpus 1 '
+                     '--workload c5` measures the same thing stand-alone')
         if variants is not None:
             line['exchange_variants_ms_per_step'] = variants
             line['exchange_variants_gedges_per_s'] = {k: (None if v is None else round(total_edges / v / 1e6, 3))

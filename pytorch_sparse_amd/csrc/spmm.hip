@@ -279,6 +279,42 @@ __device__ __forceinline__ void accumulate_window(
       x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
       if constexpr (MASKED) mb[u] = maskk[(uint64_t)lane_read(e_l, src) * mask_words];
     }
+    if constexpr (RED == RED_ADD && MASKED) {
+      // the masked sum is bound by instruction issue as much as by its gathers (twice the instructions of the
+      // plain sum per row): the packet's predicate bits become all-ones / all-zero words (v_bfe_i32) that are
+      // ANDed onto the addend, and the value-less case skips the multiply and the rounding altogether
+      auto add_masked = [&](auto with_value) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const uint32_t bits = idx[u] < hi ? (mb[u] >> mask_shift) : 0u;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const A xv = Traits<T>::to_acc(x[u].v[j]);
+            A p = xv;
+            if constexpr (decltype(with_value)::value) p = Traits<T>::round_acc(w[u] * xv);
+            const int32_t m = __builtin_amdgcn_sbfe((int32_t)bits, j, 1);  // 0 or -1
+            if constexpr (sizeof(A) == 4) {
+              uint32_t pb;
+              __builtin_memcpy(&pb, &p, 4);
+              pb &= (uint32_t)m;
+              A pm;
+              __builtin_memcpy(&pm, &pb, 4);
+              val[j] += pm;
+            } else {
+              uint64_t pb;
+              __builtin_memcpy(&pb, &p, 8);
+              pb &= (uint64_t)(int64_t)m;
+              A pm;
+              __builtin_memcpy(&pm, &pb, 8);
+              val[j] += pm;
+            }
+          }
+        }
+      };
+      if (has_value) add_masked(std::true_type{});  // wave-uniform
+      else add_masked(std::false_type{});
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const bool ok = idx[u] < hi;
