@@ -25,7 +25,7 @@ ARCH = 'gfx950'
 
 HIP_SOURCES = ['api.hip', 'spmm.hip', 'spmm_bw.hip', 'convert.hip', 'scan.hip', 'sort.hip',
                'coalesce.hip', 'spspmm.hip', 'select.hip', 'sample.hip', 'segreduce.hip']
-OPS_SOURCES = ['torch_ops.cpp']
+OPS_SOURCES = ['ops_spmm.cpp', 'ops_storage.cpp', 'ops_sample.cpp']
 
 
 def _hipcc():
@@ -118,10 +118,11 @@ def build_ops(verbose=True, force=False):
             jobs.append(['g++'] + flags + ['-I' + i for i in inc] + ['-c', s, '-o', o])
     if jobs and verbose:
         print('[build] g++: torch operator glue (%d TU)' % len(jobs), flush=True)
-    for j in jobs:
-        out = _run(j)
-        if out.strip() and verbose:
-            print(out)
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            for out in ex.map(_run, jobs):
+                if out.strip() and verbose:
+                    print(out)
     if force or _newer(lib, objs + [os.path.join(LIBDIR, 'libtsamd.so')]):
         _run(['g++', '-shared', '-fPIC', '-o', lib] + objs +
              ['-L' + LIBDIR, '-ltsamd', '-L' + tlib, '-ltorch', '-ltorch_cpu', '-lc10',

@@ -146,7 +146,7 @@ constexpr int kProbeBlocks = 64;
 // Fingerprint of a dense operand for the operand cache: 64 x 256 sixteen-byte packets spread evenly over
 // the matrix, mixed with their sample index and summed per block (wrap-around, order independent).  Any
 // dense update (x += ..., a new epoch's activations) changes it with certainty for all practical purposes;
-// it is the second line of defence behind the tensor's version counter (torch_ops.cpp), for writes that
+// it is the second line of defence behind the tensor's version counter (ops_spmm.cpp), for writes that
 // bypass it.
 constexpr int kFingerprintWords = 64;
 __global__ __launch_bounds__(256) void spmm_fingerprint_kernel(const uint4 *__restrict__ mat, uint64_t npackets,

@@ -268,7 +268,7 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     # autograd wiring of the drop-in front-end: adj.matmul(x, 'max').backward(g) takes the pull route
     xr = x.clone().requires_grad_()
     o2 = A.matmul(xr, 'max')
-    torch.use_deterministic_algorithms(has_value)  # grad_value too: the pull only on request (torch_ops.cpp), else the fused scatter
+    torch.use_deterministic_algorithms(has_value)  # grad_value too: the pull only on request (ops_spmm.cpp), else the fused scatter
     try:
         o2.backward(g)
     finally:

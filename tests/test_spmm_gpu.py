@@ -276,7 +276,7 @@ def test_minmax_bw_csc_pull(dev, dtype, reduce):
                                 trust_data=True)
             o = A.matmul(xr, reduce)
             # grad_mat alone always takes the pull; with grad_value as well only when reproducible gradients are asked for
-            # (the scatter kernel gets grad_value fused: torch_ops.cpp)
+            # (the scatter kernel gets grad_value fused: ops_spmm.cpp)
             torch.use_deterministic_algorithms(has_value)
             try:
                 o.backward(gout.to(dev))
