@@ -188,7 +188,10 @@ std::tuple<Tensor, OptTensor> spmm_fw_cached(const Tensor &rowptr, const Tensor 
     valid = locked && locked.get() == simpl;
   }
   if (!valid) {
-    if (!oc.buf.defined() || (size_t)oc.buf.numel() < cache_bytes || oc.buf.get_device() != mat_in.get_device()) {
+    // a buffer is only ever touched on the stream it was allocated under (the caching allocator's reuse is
+    // stream-ordered on that stream): another stream gets a fresh one instead of racing with pending work
+    if (!oc.buf.defined() || (size_t)oc.buf.numel() < cache_bytes || oc.buf.get_device() != mat_in.get_device() ||
+        oc.stream != stream) {
       oc.buf = Tensor();  // release before the new allocation
       oc.buf = workspace(cache_bytes, mat_in);
     }
