@@ -176,6 +176,161 @@ int key_bits_for(int64_t rows, int64_t cols) {
   return bits;
 }
 
+// ---------------------------------------------------------------------------
+// Small inputs: the whole sort_coo in ONE launch.  A COO set of a few thousand entries (a mini-batch
+// sub-graph, BASELINE config 1) spends its time in ~16 dependent launches of the general path (probe, keys,
+// (histogram, scan, scatter) per digit, decode: ~4 us each on the GPU, a HIP graph replays them no faster).
+// Here one 1024-thread workgroup keeps the (32-bit key, 16-bit index) pairs of up to 8192 entries in LDS and
+// runs every 8-bit LSD pass there: per-wave match ranking (8 ballots per key, stable), per-wave digit counts,
+// one scan over the 256 digits, scatter into the other LDS buffer.  Needs row * N + col < 2^32.
+// counts (nullable): [#descents, #adjacent duplicates] of the input (lexicographic); with `auto_mode` an input
+// without descents skips the passes (outputs = copy + identity), exactly like tsamd_sort_coo_auto.
+// ---------------------------------------------------------------------------
+constexpr int kSmallSortThreads = 1024;
+constexpr int kSmallSortItems = 8;
+constexpr int kSmallSortMax = kSmallSortThreads * kSmallSortItems;  // 8192
+
+__global__ __launch_bounds__(kSmallSortThreads) void small_sort_coo_kernel(
+    const int64_t *__restrict__ row, const int64_t *__restrict__ col, int n, uint32_t ncols, int passes,
+    int64_t *__restrict__ row_out, int64_t *__restrict__ col_out, int64_t *__restrict__ perm_out,
+    unsigned long long *__restrict__ counts, int auto_mode) {
+  __shared__ uint32_t kbuf[2][kSmallSortMax];
+  __shared__ uint16_t vbuf[2][kSmallSortMax];
+  __shared__ uint32_t cnt[kSmallSortThreads / 64][256];
+  __shared__ uint32_t dig_off[256];
+  __shared__ uint32_t wsum[4];
+  __shared__ unsigned int s_order[2];
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < 2) s_order[tid] = 0;
+  __syncthreads();
+  // load, build keys, probe the order
+  unsigned int desc = 0, dup = 0;
+#pragma unroll
+  for (int j = 0; j < kSmallSortItems; ++j) {
+    const int i = w * (64 * kSmallSortItems) + j * 64 + lane;
+    if (i < n) {
+      const int64_t r = row[i], c = col[i];
+      kbuf[0][i] = (uint32_t)((uint64_t)r * ncols + (uint64_t)c);
+      vbuf[0][i] = (uint16_t)i;
+      if (i > 0) {
+        const int64_t pr = row[i - 1], pc = col[i - 1];
+        desc += (r < pr) || (r == pr && c < pc);
+        dup += (r == pr) && (c == pc);
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    desc += lane_xor(desc, off);
+    dup += lane_xor(dup, off);
+  }
+  if (lane == 0) {
+    if (desc) atomicAdd(&s_order[0], desc);
+    if (dup) atomicAdd(&s_order[1], dup);
+  }
+  __syncthreads();
+  if (counts != nullptr && tid < 2) counts[tid] = s_order[tid];
+  const bool skip = auto_mode != 0 && s_order[0] == 0;
+  int cur = 0;
+  for (int pass = 0; pass < passes && !skip; ++pass) {
+    const int shift = pass * 8;
+    const uint32_t *ks = kbuf[cur];
+    const uint16_t *vs = vbuf[cur];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cnt[w][q * 64 + lane] = 0;  // this wave's counters (wave-local: no barrier)
+    uint32_t key[kSmallSortItems], lrank[kSmallSortItems];
+    uint16_t val[kSmallSortItems];
+#pragma unroll
+    for (int j = 0; j < kSmallSortItems; ++j) {
+      const int i = w * (64 * kSmallSortItems) + j * 64 + lane;
+      const bool valid = i < n;
+      key[j] = valid ? ks[i] : 0u;
+      val[j] = valid ? vs[i] : (uint16_t)0;
+      const uint32_t d = (key[j] >> shift) & 255u;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+      }
+      const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+      const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+      uint32_t pre = 0;
+      if (valid && lane == leader) {
+        pre = cnt[w][d];
+        cnt[w][d] = pre + (uint32_t)__popcll(peers);
+      }
+      pre = lane_read(pre, leader);
+      lrank[j] = pre + rank;
+    }
+    __syncthreads();
+    if (tid < 256) {  // thread t owns digit t: exclusive prefix over the waves, then over the digits
+      uint32_t run = 0;
+#pragma unroll
+      for (int ww = 0; ww < kSmallSortThreads / 64; ++ww) {
+        const uint32_t c = cnt[ww][tid];
+        cnt[ww][tid] = run;
+        run += c;
+      }
+      uint32_t inc = run;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = lane_read(inc, lane >= off ? lane - off : lane);
+        if (lane >= off) inc += o;
+      }
+      if (lane == 63) wsum[w] = inc;
+      dig_off[tid] = inc - run;  // exclusive inside the wave; the wave bases are added below
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t base = 0;
+      for (int ww = 0; ww < w; ++ww) base += wsum[ww];
+      dig_off[tid] += base;
+    }
+    __syncthreads();
+    uint32_t *kd = kbuf[cur ^ 1];
+    uint16_t *vd = vbuf[cur ^ 1];
+#pragma unroll
+    for (int j = 0; j < kSmallSortItems; ++j) {
+      const int i = w * (64 * kSmallSortItems) + j * 64 + lane;
+      if (i < n) {
+        const uint32_t d = (key[j] >> shift) & 255u;
+        const uint32_t pos = dig_off[d] + cnt[w][d] + lrank[j];
+        kd[pos] = key[j];
+        vd[pos] = val[j];
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int i = tid; i < n; i += kSmallSortThreads) {
+    if (skip) {
+      if (row_out) row_out[i] = row[i];
+      if (col_out) col_out[i] = col[i];
+      perm_out[i] = i;
+    } else {
+      const uint32_t k = kbuf[cur][i];
+      const uint32_t r = k / ncols;
+      if (row_out) row_out[i] = (int64_t)r;
+      if (col_out) col_out[i] = (int64_t)(k - r * ncols);
+      perm_out[i] = (int64_t)vbuf[cur][i];
+    }
+  }
+}
+
+// true when the one-launch path applies (and was launched)
+bool small_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_out,
+                    int64_t *col_out, int64_t *perm_out, int64_t *counts, bool auto_mode, hipStream_t stream) {
+  if (E > kSmallSortMax || N <= 0 || N >= ((int64_t)1 << 32)) return false;
+  const int bits = key_bits_for(M, N);
+  if (bits > 32) return false;
+  const int passes = E > 1 ? (bits + 7) / 8 : 0;
+  hipLaunchKernelGGL(small_sort_coo_kernel, dim3(1), dim3(kSmallSortThreads), 0, stream, row, col, (int)E,
+                     (uint32_t)N, passes, row_out, col_out, perm_out,
+                     reinterpret_cast<unsigned long long *>(counts), auto_mode ? 1 : 0);
+  return true;
+}
+
 }  // namespace
 }  // namespace tsamd
 
@@ -196,6 +351,10 @@ extern "C" int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E,
   if ((unsigned __int128)M * (unsigned __int128)N >= ((unsigned __int128)1 << 63))
     return TSAMD_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < tsamd_sort_coo_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
+  if (small_sort_coo(row, col, E, M, N, row_out, col_out, perm_out, nullptr, false, stream)) {
+    TSAMD_LAUNCH_CHECK();
+    return TSAMD_OK;
+  }
   char *p = reinterpret_cast<char *>(workspace);
   int64_t *keys = reinterpret_cast<int64_t *>(p);
   p += align_up(sizeof(int64_t) * (size_t)E, 256);
@@ -222,6 +381,12 @@ extern "C" int tsamd_sort_coo_auto(const int64_t *row, const int64_t *col, int64
                                    void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (E < 0 || M < 0 || N < 0 || !counts_out) return TSAMD_ERR_INVALID;
+  if (E > 0 && row && col && perm_out &&
+      (unsigned __int128)M * (unsigned __int128)N < ((unsigned __int128)1 << 63) &&
+      small_sort_coo(row, col, E, M, N, row_out, col_out, perm_out, counts_out, true, stream)) {
+    TSAMD_LAUNCH_CHECK();  // probe, sort and decode in one launch
+    return TSAMD_OK;
+  }
   int st = tsamd_coo_order(row, col, E, N, counts_out, stream_);
   if (st != TSAMD_OK || E == 0) return st;
   if (!row || !col || !perm_out) return TSAMD_ERR_INVALID;
