@@ -35,6 +35,16 @@ namespace tsamd {
 namespace {
 
 constexpr int kSmallCap = 512;    // products handled by one wave (LDS radix sort, no workgroup barriers)
+// Bins of the large-row path that one wave takes through the register sort (kSmallCap for rows stays 512: the
+// config-4 rows of ~240 products want the small LDS footprint).  A persistent 256-thread workgroup spends ~8-10 us
+// of barriers and dependent loads on a bin whatever its size, and 720 k of the 790 k "big" bins of the stress
+// product hold 513..4096 products.  Same-box stress run, cap 512 / 1024 / 2048: the four count + accum kernels
+// take 29.8 / 25.7 / 30.8 ms together (at 2048 the 32-keys-per-lane register sort costs more than the barriers saved).
+#ifndef TSAMD_SPSPMM_SMALLBIN_CAP
+#define TSAMD_SPSPMM_SMALLBIN_CAP 1024
+#endif
+constexpr int kSmallBinCap = TSAMD_SPSPMM_SMALLBIN_CAP;
+constexpr int kBinIdxBits = kSmallBinCap <= 512 ? 9 : (kSmallBinCap <= 1024 ? 10 : 11);
 constexpr int kMediumCap = 4096;  // products handled by one 256-thread workgroup
 
 // stats layout (device int64[8])
@@ -912,7 +922,7 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
   }
 }
 
-// Bins by size: those of at most kSmallCap products go to one WAVE each (many in flight per CU), the
+// Bins by size: those of at most kSmallBinCap products go to one WAVE each (many in flight per CU), the
 // others to the persistent workgroups above.  Most bins of a power-law product are small (a few hundred
 // products), and a persistent workgroup spends ~8 us of barriers, dependent loads and ticket traffic on
 // each regardless of its size.  lists[0 .. ntask) = small bins, lists[ntask .. 2 ntask) = big bins (in no
@@ -928,7 +938,7 @@ __global__ __launch_bounds__(256) void spspmm_large_classify_kernel(const int64_
     n = bin_off[task + 1] - bin_off[task];
     if (n == 0) bin_cnt[task] = 0;
   }
-  const int cls = n == 0 ? -1 : (n <= kSmallCap ? 0 : 1);
+  const int cls = n == 0 ? -1 : (n <= kSmallBinCap ? 0 : 1);
   // one atomic per workgroup and list (the two counters are hot addresses: ~12 ns per atomic, serialised)
   __shared__ int s_cnt[2][4];
   __shared__ unsigned long long s_base[2];
@@ -967,14 +977,14 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_count_kernel(
     const int64_t task = small[t];
     const int64_t b0 = bin_off[task];
     const int n = (int)(bin_off[task + 1] - b0);
-    uint32_t c[kSmallCap / 64];
+    uint32_t c[kSmallBinCap / 64];
 #pragma unroll
-    for (int u = 0; u < kSmallCap / 64; ++u) {
+    for (int u = 0; u < kSmallBinCap / 64; ++u) {
       const int q = u * 64 + lane;
       if (u * 64 < n) c[u] = bcol[b0 + (q < n ? q : n - 1)];  // (wave-uniform) a repeat sets the same bit again
     }
 #pragma unroll
-    for (int u = 0; u < kSmallCap / 64; ++u)
+    for (int u = 0; u < kSmallBinCap / 64; ++u)
       if (u * 64 < n) atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
     __syncthreads();
     int cnt = 0;
@@ -1002,8 +1012,8 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
     const uint32_t *__restrict__ bcol, const T *__restrict__ bval, const int64_t *__restrict__ bin_pref,
     const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC, T *__restrict__ valC) {
   using A = typename Traits<T>::acc_t;
-  __shared__ alignas(16) uint32_t skey[kSmallCap];
-  __shared__ A sval[kSmallCap];
+  __shared__ alignas(16) uint32_t skey[kSmallBinCap];
+  __shared__ A sval[kSmallBinCap];
   __shared__ int sscan[8];
   const int lane = (int)threadIdx.x;
   const int64_t ns = (int64_t)*n_small;
@@ -1011,11 +1021,11 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
     const int64_t task = small[t];
     const int64_t b0 = bin_off[task];
     const int p = (int)(bin_off[task + 1] - b0);
-    const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : 8));
+    const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : (p <= 512 ? 8 : (p <= 1024 ? 16 : 32))));
     for (int q = lane; q < 64 * items; q += 64) {
       uint32_t k = kEmptyKey;
       if (q < p) {
-        k = (bcol[b0 + q] << kIdxBits) | (uint32_t)q;
+        k = (bcol[b0 + q] << kBinIdxBits) | (uint32_t)q;
         if (valC != nullptr) sval[q] = Traits<T>::to_acc(bval[b0 + q]);
       }
       skey[q] = k;
@@ -1024,14 +1034,16 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
     if (items == 1) sort_lds_keys<1>(skey, lane);
     else if (items == 2) sort_lds_keys<2>(skey, lane);
     else if (items == 4) sort_lds_keys<4>(skey, lane);
-    else sort_lds_keys<8>(skey, lane);
+    else if (items == 8) sort_lds_keys<8>(skey, lane);
+    else if (items == 16) sort_lds_keys<16>(skey, lane);
+    else if constexpr (kSmallBinCap > 1024) sort_lds_keys<32>(skey, lane);
     __syncthreads();
     const int64_t r = task / nr, q0 = task - r * nr;
     const int64_t out0 = rowptrC[rows[r]] + (bin_pref[task] - bin_pref[r * nr]);
     const uint32_t col0 = (uint32_t)(q0 << kLgRange<T>);
     compress_and_store<T, 64>(
-        p, out0, colC, valC, sscan, [&](int idx) { return col0 + (skey[idx] >> kIdxBits); },
-        [&](int idx) { return sval[skey[idx] & (uint32_t)(kSmallCap - 1)]; });
+        p, out0, colC, valC, sscan, [&](int idx) { return col0 + (skey[idx] >> kBinIdxBits); },
+        [&](int idx) { return sval[skey[idx] & (uint32_t)(kSmallBinCap - 1)]; });
     __syncthreads();
   }
 }
