@@ -65,6 +65,83 @@ std::vector<int64_t> operand_cache_ctl(bool enable) {
   return r;
 }
 
+// ---- transposed-pattern cache ------------------------------------------------------------------------------
+// grad_mat = A^T * grad_out multiplies by the CSC view (colptr, row[csr2csc], value[csr2csc]).  The reference
+// gathers row[csr2csc] and value[csr2csc] anew in every backward (spmm.cpp:104-106).  The row ids of the CSC
+// order only depend on the PATTERN, which a training loop does not change: they are gathered once and kept
+// (one entry; key = storage objects, data pointers and version counters of `row` and `csr2csc`), so that every
+// later backward reads them sequentially.  TSAMD_PATTERN_CACHE=0 turns it off (then, and for a pattern seen
+// for the first time in a no-reuse setting, the kernel reads (row, value) through csr2csc -- tsamd_spmm_permuted).
+struct PatternCache {
+  std::mutex mu;
+  bool enabled = true;
+  c10::weak_intrusive_ptr<c10::StorageImpl> row_storage{c10::weak_intrusive_ptr<c10::StorageImpl>(
+      c10::make_intrusive<c10::StorageImpl>(c10::StorageImpl::use_byte_size_t(), 0, c10::DataPtr(), nullptr, false))};
+  c10::weak_intrusive_ptr<c10::StorageImpl> perm_storage{c10::weak_intrusive_ptr<c10::StorageImpl>(
+      c10::make_intrusive<c10::StorageImpl>(c10::StorageImpl::use_byte_size_t(), 0, c10::DataPtr(), nullptr, false))};
+  const void *row_ptr = nullptr, *perm_ptr = nullptr;
+  uint32_t row_version = 0, perm_version = 0;
+  int64_t E = -1;
+  int seen = 0;  // calls with this key so far
+  Tensor row_t;
+};
+
+PatternCache &pattern_cache_state() {
+  static PatternCache c;
+  static bool init = [] {
+    const char *env = getenv("TSAMD_PATTERN_CACHE");
+    if (env != nullptr && env[0] == '0') c.enabled = false;
+    return true;
+  }();
+  (void)init;
+  return c;
+}
+
+// torch.ops.tsamd.pattern_cache(enable) -> was enabled; drops the cached row ids
+bool pattern_cache_ctl(bool enable) {
+  PatternCache &c = pattern_cache_state();
+  std::lock_guard<std::mutex> lock(c.mu);
+  const bool was = c.enabled;
+  c.enabled = enable;
+  c.row_t = Tensor();
+  c.row_ptr = nullptr;
+  return was;
+}
+
+// row[csr2csc] from the cache, or an undefined tensor when the caller should read through csr2csc instead
+// (cache off, inference tensors, or the FIRST backward with this pattern: the gather only pays off when the
+// pattern comes back, so it is made on the second sighting)
+Tensor cached_csc_rows(const Tensor &row, const Tensor &csr2csc) {
+  PatternCache &pc = pattern_cache_state();
+  if (!pc.enabled || row.is_inference() || csr2csc.is_inference() || !row.is_contiguous() || !csr2csc.is_contiguous())
+    return Tensor();
+  c10::StorageImpl *rs = row.storage().unsafeGetStorageImpl(), *ps = csr2csc.storage().unsafeGetStorageImpl();
+  const uint32_t rv = row.unsafeGetTensorImpl()->version_counter().current_version();
+  const uint32_t pv = csr2csc.unsafeGetTensorImpl()->version_counter().current_version();
+  std::lock_guard<std::mutex> lock(pc.mu);
+  bool same = pc.row_ptr == row.data_ptr() && pc.perm_ptr == csr2csc.data_ptr() && pc.E == row.numel() &&
+              pc.row_version == rv && pc.perm_version == pv;
+  if (same) {
+    auto a = pc.row_storage.lock(), b = pc.perm_storage.lock();
+    same = a && b && a.get() == rs && b.get() == ps;
+  }
+  if (!same) {
+    pc.row_storage = c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(rs));
+    pc.perm_storage = c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(ps));
+    pc.row_ptr = row.data_ptr();
+    pc.perm_ptr = csr2csc.data_ptr();
+    pc.row_version = rv;
+    pc.perm_version = pv;
+    pc.E = row.numel();
+    pc.seen = 1;
+    pc.row_t = Tensor();
+    return Tensor();
+  }
+  ++pc.seen;
+  if (!pc.row_t.defined()) pc.row_t = row.index_select(0, csr2csc);
+  return pc.row_t;
+}
+
 // Forward launch: mirrors the argument checks of spmm_cpu.cpp:12-24 / spmm_cuda.cu:96-109.
 std::tuple<Tensor, OptTensor> spmm_fw(const Tensor &rowptr, const Tensor &col,
                                       const OptTensor &opt_value, Tensor mat,
@@ -285,10 +362,18 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
       if (!mean) {
         // sum: the kernel reads (row, value) THROUGH csr2csc -- no row.index_select(0, csr2csc) /
         // value.index_select(0, csr2csc) temporaries as in the reference (spmm.cpp:104-106)
-        OptTensor w = has_value ? OptTensor(value.detach()) : std::nullopt;
-        grad_mat = std::get<0>(spmm_fw(colptr, row, w, grad_out, "sum", csr2csc));
+        Tensor row_t = cached_csc_rows(row, csr2csc);
+        if (row_t.defined()) {
+          // the pattern came back: its CSC row ids are at hand, only the values are gathered (one ATen gather)
+          OptTensor w = has_value ? OptTensor(value.detach().index_select(0, csr2csc)) : std::nullopt;
+          grad_mat = std::get<0>(spmm_fw(colptr, row_t, w, grad_out, "sum"));
+        } else {
+          OptTensor w = has_value ? OptTensor(value.detach()) : std::nullopt;
+          grad_mat = std::get<0>(spmm_fw(colptr, row, w, grad_out, "sum", csr2csc));
+        }
       } else {
-        Tensor row_t = row.index_select(0, csr2csc);
+        Tensor row_t = cached_csc_rows(row, csr2csc);
+        if (!row_t.defined()) row_t = row.index_select(0, csr2csc);
         Tensor cnt = rowcount.index_select(0, row_t).to(mat.scalar_type()).clamp_min_(1);
         Tensor w = has_value ? value.detach().index_select(0, csr2csc).div_(cnt) : cnt.reciprocal_();
         grad_mat = std::get<0>(spmm_fw(colptr, row_t, w, grad_out, "sum"));
@@ -610,6 +695,7 @@ static auto registry_spmm = torch::RegisterOperators()
                            .op("torch_sparse::cuda_version", &cuda_version)
                            .op("tsamd::spmm_minmax", &spmm_minmax)
                            .op("tsamd::operand_cache", &operand_cache_ctl)
+                           .op("tsamd::pattern_cache", &pattern_cache_ctl)
                            .op("tsamd::relabel_ids", &relabel_ids)
                            .op("tsamd::gather_rows", &gather_rows)
                            .op("tsamd::spmm_relabelled", &spmm_relabelled);

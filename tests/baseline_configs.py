@@ -679,7 +679,10 @@ def run_c2_backward(dev, cpu=True, iters=10):
         out.backward(g)
         return out
     with operand_cache(False):
-        fb_ms = gpu_ms(fwbw, iters=iters)
+        fb_ms = gpu_ms(fwbw, iters=iters)  # steady state of a training loop: the pattern's CSC row ids are cached
+        torch.ops.tsamd.pattern_cache(False)
+        fb_nocache_ms = gpu_ms(fwbw, iters=iters)  # every backward reads (row, value) through csr2csc
+        torch.ops.tsamd.pattern_cache(True)
     out = fwbw()
     gval, gmat = A.storage.value().grad, xr.grad
     b_vb = E * (16 + K * s + s) + n * K * s          # SURVEY 8d "value-grad SDDMM"
@@ -688,7 +691,8 @@ def run_c2_backward(dev, cpu=True, iters=10):
     res = dict(config='c2_backward', dtype='f32',
                workload='configs[1] graph (2^20 R-MAT, E=%d), F=64 fp32: value gradient alone; sum forward + grad_value + '
                         'grad_mat through adj.matmul(x).backward(g)' % E,
-               value_bw_ms=round(vb_ms, 4), fw_bw_ms=round(fb_ms, 4), gedges_per_s_value_bw=round(E / vb_ms / 1e6, 3),
+               value_bw_ms=round(vb_ms, 4), fw_bw_ms=round(fb_ms, 4), fw_bw_without_pattern_cache_ms=round(fb_nocache_ms, 4),
+               gedges_per_s_value_bw=round(E / vb_ms / 1e6, 3),
                gedges_per_s_fw_bw=round(E / fb_ms / 1e6, 3),
                roofline=dict(_roof(b_vb, vb_ms, 'spmm_value_bw_kernel; bytes = E(16 + F s + s) + M F s (SURVEY 8d)'),
                              **pmc_traffic('c2_value_bw_f32_F64', 'spmm_value_bw_kernel')),

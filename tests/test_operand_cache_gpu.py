@@ -107,3 +107,27 @@ def test_autograd_and_matmul_through_the_cache(dev, ops):
     for r in res[1:]:
         for a, b in zip(r, res[0]):
             assert bits_equal(a, b)
+
+
+@pytest.mark.parametrize('reduce', ['sum', 'mean'])
+def test_pattern_cache_keeps_gradients_identical(dev, ops, reduce):
+    """grad_mat = A^T G through the cached CSC row ids (second and later backwards with one pattern) equals
+    the first backward (entries read through csr2csc) bit for bit; a new pattern is noticed."""
+    import pytorch_sparse_amd as ts
+    grads = []
+    for seed in (0, 3):
+        rp, c = synth.rmat_csr(12, 12, seed=seed, device=dev)
+        n = 1 << 12
+        v = synth.values(c.numel(), device=dev).requires_grad_()
+        x = synth.features(n, 32, device=dev).requires_grad_()
+        g = synth.features(n, 32, seed=5, device=dev)
+        A = ts.SparseTensor(rowptr=rp, col=c, value=v, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+        per_call = []
+        for _ in range(3):
+            v.grad = x.grad = None
+            A.matmul(x, reduce).backward(g)
+            per_call.append((x.grad.clone(), v.grad.clone()))
+        for gx, gv in per_call[1:]:
+            assert bits_equal(gx, per_call[0][0]) and bits_equal(gv, per_call[0][1])
+        grads.append(per_call[0][0])
+    assert not torch.equal(grads[0], grads[1])
