@@ -21,6 +21,14 @@
 namespace tsamd_ops {
 namespace {
 
+// Neither cache may hold on to memory that was allocated while a HIP graph is being captured (it would come
+// from the graph's private pool): a capturing stream bypasses them.
+bool stream_is_capturing(void *stream) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &cs) != hipSuccess ||
+         cs != hipStreamCaptureStatusNone;
+}
+
 // ---- operand cache (include/tsamd.h: tsamd_spmm_cached) ------------------------------------------------
 // One entry: the relabelled copy of the last dense operand that needed one.  A call may reuse it when the
 // operand is provably the same tensor contents as far as torch can tell -- same storage object (held weakly:
@@ -113,7 +121,8 @@ bool pattern_cache_ctl(bool enable) {
 // pattern comes back, so it is made on the second sighting)
 Tensor cached_csc_rows(const Tensor &row, const Tensor &csr2csc) {
   PatternCache &pc = pattern_cache_state();
-  if (!pc.enabled || row.is_inference() || csr2csc.is_inference() || !row.is_contiguous() || !csr2csc.is_contiguous())
+  if (!pc.enabled || row.is_inference() || csr2csc.is_inference() || !row.is_contiguous() || !csr2csc.is_contiguous() ||
+      !row.device().is_cuda() || stream_is_capturing(current_stream(row)))
     return Tensor();
   c10::StorageImpl *rs = row.storage().unsafeGetStorageImpl(), *ps = csr2csc.storage().unsafeGetStorageImpl();
   const uint32_t rv = row.unsafeGetTensorImpl()->version_counter().current_version();
@@ -227,7 +236,8 @@ std::tuple<Tensor, OptTensor> spmm_fw_cached(const Tensor &rowptr, const Tensor 
     B = (N * K) > 0 ? mat_in.numel() / (N * K) : 1;
     cache_bytes = tsamd_spmm_operand_cache_bytes(dt, red, B, M, N, K, E);
   }
-  if (!eligible || cache_bytes == 0) return spmm_fw(rowptr, col, opt_value, mat_in, reduce);
+  if (!eligible || cache_bytes == 0 || stream_is_capturing(current_stream(mat_in)))
+    return spmm_fw(rowptr, col, opt_value, mat_in, reduce);
 
   // same checks as spmm_fw
   check_gpu(col, "col");

@@ -131,3 +131,31 @@ def test_pattern_cache_keeps_gradients_identical(dev, ops, reduce):
             assert bits_equal(gx, per_call[0][0]) and bits_equal(gv, per_call[0][1])
         grads.append(per_call[0][0])
     assert not torch.equal(grads[0], grads[1])
+
+
+def test_graph_capture_bypasses_the_caches(dev, ops):
+    """The sync-free ops can be captured into a HIP graph (torch.cuda.graph); a capturing stream uses neither
+    cache (their buffers would come from the graph's private pool), and the replay follows updates of X."""
+    rp, c, n = _graph(dev)
+    v = synth.values(c.numel(), device=dev)
+    x = synth.features(n, 128, device=dev)
+    spmm = lambda: ops.torch_sparse.spmm_sum(None, rp, c, v, None, None, x)  # noqa: E731
+    ref = spmm()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            spmm()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = spmm()
+    g.replay()
+    torch.cuda.synchronize()
+    assert bits_equal(out, ref)
+    x.mul_(4.0)  # (a power of two: every product and sum scales exactly)
+    g.replay()
+    torch.cuda.synchronize()
+    assert bits_equal(out, ref * 4.0)
+    assert bits_equal(spmm(), ref * 4.0)  # and the eager path (cache refilled for the new version) agrees
