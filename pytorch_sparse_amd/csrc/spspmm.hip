@@ -231,7 +231,10 @@ struct ExpandScratch {
   A av[64];
 };
 
-template <typename T, int BLOCK, bool WITH_VAL, typename Emit>
+// LONG_B: the B rows are expected to be long (the large rows of a power-law product: 733 entries on average in
+// the stress case), so a thread's successive products (BLOCK apart) mostly fall into the same A entry as its
+// previous one: that entry is tried first and the 6-step search only runs on a miss.
+template <typename T, int BLOCK, bool WITH_VAL, bool LONG_B = false, typename Emit>
 __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, const T *__restrict__ valA,
                                           const int64_t *__restrict__ rowptrB,
                                           const uint32_t *__restrict__ colB, const T *__restrict__ valB,
@@ -266,6 +269,7 @@ __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, cons
     }
     __syncthreads();
     const int total = sc.off[64];
+    int lo_prev = 0;
     for (int q0 = tid; q0 < total; q0 += BLOCK * kExpandBatch) {
       int64_t src[kExpandBatch];
       A a[kExpandBatch];
@@ -274,11 +278,19 @@ __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, cons
         const int qq = q0 + u * BLOCK;
         const int q = qq < total ? qq : total - 1;
         int lo = 0, hi = 64;  // last entry whose offset is <= q (zero-length entries are skipped)
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-          const int mid = (lo + hi) >> 1;
-          if (sc.off[mid] <= q) lo = mid; else hi = mid;
+        bool hit = false;
+        if constexpr (LONG_B) {
+          hit = sc.off[lo_prev] <= q && q < sc.off[lo_prev + 1];
+          if (hit) lo = lo_prev;
         }
+        if (!hit) {
+#pragma unroll
+          for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi) >> 1;
+            if (sc.off[mid] <= q) lo = mid; else hi = mid;
+          }
+        }
+        if constexpr (LONG_B) lo_prev = lo;
         src[u] = sc.bs[lo] + (q - sc.off[lo]);
         a[u] = WITH_VAL ? sc.av[lo] : A(1);
       }
@@ -689,20 +701,22 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
   const int64_t i = rows[blockIdx.x];
   for (int q = tid; q < nr; q += kLargeThreads) cnt[q] = 0;
   __syncthreads();
-  // Consecutive products come from one sorted B row, so the 64 lanes of a wave fall into one to three ranges:
-  // one LDS atomic per wave and range instead of one per product (the 2^13-column ranges of a 2^19-column
-  // operand are 64 counters -- per-product atomics serialise on them)
+  // Consecutive products come from one sorted B row, so the 64 lanes of a wave form a few RUNS of equal range:
+  // the head of every run adds the run's length with one LDS atomic (all heads in the same instruction, mostly
+  // different counters) instead of 64 lanes hitting one counter -- the 2^13-column ranges of a 2^19-column
+  // operand are 64 counters, per-product atomics serialise on them.  The active lanes of a step are a prefix of
+  // the wave (q < total cuts a suffix), so "the lane below" is active for every active lane but lane 0.
   const int lane = tid & 63;
-  expand_row<float, kLargeThreads, false>(colA, nullptr, rowptrB, colB, nullptr, rowptrA[i], rowptrA[i + 1], sc,
-                                          [&](int, uint32_t c, float) {
+  expand_row<float, kLargeThreads, false, true>(colA, nullptr, rowptrB, colB, nullptr, rowptrA[i], rowptrA[i + 1], sc,
+                                                [&](int, uint32_t c, float) {
     const int q = (int)(c >> lg_range);
-    for (;;) {
-      const int q0 = __builtin_amdgcn_readfirstlane(q);
-      const unsigned long long m = __ballot(q == q0);
-      if (q == q0) {
-        if (lane == (int)__builtin_ctzll(m)) atomicAdd(&cnt[q0], (int)__popcll(m));
-        break;
-      }
+    const int qprev = lane_read(q, lane > 0 ? lane - 1 : 0);
+    const bool head = lane == 0 || q != qprev;
+    const unsigned long long hm = __ballot(head), act = __ballot(true);
+    if (head) {
+      const unsigned long long above = hm & ~((2ull << lane) - 1ull);
+      const int next = above ? (int)__builtin_ctzll(above) : 64 - (int)__builtin_clzll(act);
+      atomicAdd(&cnt[q], next - lane);
     }
   });
   __syncthreads();
@@ -724,12 +738,26 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
   __syncthreads();
   const int64_t *off = bin_off + (int64_t)blockIdx.x * nr;
   const uint32_t mask = (1u << lg_range) - 1u;
-  expand_row<T, kLargeThreads, WITH_VAL>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
-                                         [&](int, uint32_t c, A v) {
-    // (per-product cursor atomics: grouping the lanes by range as the hist kernel does needs the RETURN of the
-    // leader's atomic before the next group can go -- measured 23 ms instead of 12 ms)
+  const int lane = tid & 63;
+  expand_row<T, kLargeThreads, WITH_VAL, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+                                               [&](int, uint32_t c, A v) {
+    // runs of equal range inside the wave (see the hist kernel): the head of a run reserves the run's slots
+    // with ONE returning atomic -- all heads in the same instruction -- and its lanes take consecutive
+    // positions, so their stores are contiguous.  (Grouping ALL lanes of equal range instead needs one
+    // dependent atomic per group: 11.8 -> 23.3 ms; per-product atomics put 64 lanes on one cursor.)
     const int q = (int)(c >> lg_range);
-    const int64_t pos = off[q] + atomicAdd(&cursor[q], 1);
+    const int qprev = lane_read(q, lane > 0 ? lane - 1 : 0);
+    const bool head = lane == 0 || q != qprev;
+    const unsigned long long hm = __ballot(head), act = __ballot(true);
+    const int leader = 63 - (int)__builtin_clzll(hm & ((2ull << lane) - 1ull));
+    int base = 0;
+    if (head) {
+      const unsigned long long above = hm & ~((2ull << lane) - 1ull);
+      const int next = above ? (int)__builtin_ctzll(above) : 64 - (int)__builtin_clzll(act);
+      base = atomicAdd(&cursor[q], next - lane);
+    }
+    base = lane_read(base, leader);
+    const int64_t pos = off[q] + base + (lane - leader);
     bcol[pos] = c & mask;
     if (WITH_VAL) bval[pos] = Traits<T>::from_acc(v);
   });
