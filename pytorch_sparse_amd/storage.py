@@ -359,6 +359,20 @@ class SparseStorage(object):
         self._csr2csc = perm
         return perm
 
+    def csc_index(self) -> Tuple[Tensor, Tensor, Tensor]:
+        """(col, row, csr2csc) with the entries in column-major order.  When the permutation is not cached
+        yet, the radix sort that produces it also emits the sorted (col, row) pairs -- no gathers through the
+        permutation afterwards (and colptr comes from the sorted columns for free); what `t()` needs."""
+        perm = self._csr2csc
+        if perm is not None:
+            return self._col[perm], self.row()[perm], perm
+        N = self._sparse_sizes[1]
+        cs, rs, perm = torch.ops.tsamd.sort_coo(self._col, self.row(), N, self._sparse_sizes[0], True)
+        self._csr2csc = perm
+        if self._colptr is None and self._colcount is None:
+            self._colptr = torch.ops.torch_sparse.ind2ptr(cs, N)
+        return cs, rs, perm
+
     def has_csc2csr(self) -> bool:
         return self._csc2csr is not None
 
@@ -385,7 +399,16 @@ class SparseStorage(object):
             ptr = self._col.new_zeros(N + 1)
             torch.cumsum(colcount, dim=0, out=ptr[1:])
         else:
-            ptr = torch.ops.torch_sparse.ind2ptr(self._col[self.csr2csc()], N)
+            perm0 = self._csr2csc
+            if perm0 is not None:
+                ptr = torch.ops.torch_sparse.ind2ptr(self._col[perm0], N)
+            else:
+                # a new csr2csc comes with the sorted columns: no gather through the permutation
+                cs, rs, perm = self.csc_index()
+                ptr2 = self._colptr
+                if ptr2 is not None:
+                    return ptr2
+                ptr = torch.ops.torch_sparse.ind2ptr(cs, N)
         self._colptr = ptr
         return ptr
 

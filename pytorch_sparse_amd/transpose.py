@@ -11,10 +11,10 @@ def t(src: SparseTensor) -> SparseTensor:
     over as the CSR-side caches of the result, so ``A.t().t()`` costs nothing more
     (reference transpose.py:7-31)."""
     st = src.storage
-    perm = st.csr2csc()
-    row, col, value = src.coo()
+    col_t, row_t, perm = st.csc_index()  # sorted (col, row) straight from the sort when csr2csc is new
+    value = st.value()
     M, N = st.sparse_sizes()
-    out = SparseStorage(row=col[perm], rowptr=st._colptr, col=row[perm],
+    out = SparseStorage(row=col_t, rowptr=st._colptr, col=row_t,
                         value=None if value is None else value[perm], sparse_sizes=(N, M),
                         rowcount=st._colcount, colptr=st._rowptr, colcount=st._rowcount,
                         csr2csc=st._csc2csr, csc2csr=perm, is_sorted=True, trust_data=True)
