@@ -297,6 +297,12 @@ int tsamd_coo_check(const int64_t *row, const int64_t *col, int64_t E, int64_t *
 int tsamd_sort_coo_auto(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
                         int64_t *row_out, int64_t *col_out, int64_t *perm_out, int64_t *counts_out,
                         void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the order already probed: descents[0] (DEVICE) = #descents of the input, e.g. counts_out[0] of
+ * tsamd_coo_check.  Lets a caller enqueue check, sort and the gathers through the permutation back to back
+ * and read the check's result only once everything is in flight. */
+int tsamd_sort_coo_probed(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                          int64_t *row_out, int64_t *col_out, int64_t *perm_out, const int64_t *descents,
+                          void *workspace, size_t workspace_bytes, void *stream);
 size_t tsamd_sort_coo_workspace_bytes(int64_t E);
 int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
                    int64_t N, int64_t *row_out, int64_t *col_out, int64_t *perm_out,

@@ -48,5 +48,5 @@ def coalesce(index: Tensor, value: Optional[Tensor], m: int, n: int,
             # differentiable, like segment_csr; long runs of duplicates go the entry-balanced way
             value = segment_reduce(value, perm, seg_ptr, n_u, op, balanced=index.size(1) > 8 * max(n_u, 1))
         elif perm is not None:
-            value = value[perm]
+            value = value.index_select(0, perm)
     return torch.stack([row, col], dim=0), value

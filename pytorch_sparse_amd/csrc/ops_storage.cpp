@@ -98,6 +98,27 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sort_coo_auto(Tensor row, Tensor col,
   return std::make_tuple(row_s, col_s, perm, counts);
 }
 
+// sort_coo decided on the device from an EXISTING probe: counts[0] (device) = #descents (tsamd::coo_check)
+std::tuple<Tensor, Tensor, Tensor> sort_coo_probed(Tensor row, Tensor col, int64_t M, int64_t N, Tensor counts) {
+  check_index(row, "row");
+  check_index(col, "col");
+  check_index(counts, "counts");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  TORCH_CHECK(counts.numel() >= 1 && counts.is_contiguous(), "counts must hold the number of descents");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  Tensor perm = torch::empty({E}, row.options()), row_s = torch::empty({E}, row.options()),
+         col_s = torch::empty({E}, row.options());
+  Tensor ws = workspace(tsamd_sort_coo_workspace_bytes(E), row);
+  check_status(tsamd_sort_coo_probed(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N,
+                                     row_s.data_ptr<int64_t>(), col_s.data_ptr<int64_t>(), perm.data_ptr<int64_t>(),
+                                     counts.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), current_stream(row)),
+               "tsamd_sort_coo_probed");
+  return std::make_tuple(row_s, col_s, perm);
+}
+
 // stable sort by row * N + col -> (row_sorted, col_sorted, perm); with index=false only perm
 std::tuple<Tensor, Tensor, Tensor> sort_coo(Tensor row, Tensor col, int64_t M, int64_t N,
                                             bool index) {
@@ -464,6 +485,7 @@ static auto registry_storage = torch::RegisterOperators()
                            .op("tsamd::sort_coo", &sort_coo)
                            .op("tsamd::coo_check", &coo_check)
                            .op("tsamd::sort_coo_auto", &sort_coo_auto)
+                           .op("tsamd::sort_coo_probed", &sort_coo_probed)
                            .op("tsamd::coalesce_index", &coalesce_index)
                            .op("tsamd::segment_reduce", &segment_reduce)
                            .op("tsamd::spspmm", &spspmm)

@@ -19,7 +19,7 @@ def spmm(index: Tensor, value: Tensor, m: int, n: int, matrix: Tensor) -> Tensor
         # ordered on the device without asking the host (tsamd::sort_coo_auto: a sorted input only pays the
         # probe and a copy): the whole call enqueues kernels and returns -- no sync
         row, col, perm, _ = torch.ops.tsamd.sort_coo_auto(row.contiguous(), col.contiguous(), m, n)
-        value = value[perm]  # differentiable gather (the identity when the input was in order)
+        value = value.index_select(0, perm)  # differentiable gather (the identity when the input was in order)
     rowptr = torch.ops.torch_sparse.ind2ptr(row, m)
     need_csc = matrix.requires_grad
     colptr = csr2csc = None

@@ -9,7 +9,7 @@ def _csr(index, value, rows, cols, sort):
     if sort:  # `coalesced=True` in the reference means "sort the inputs first"
         row, col, perm, _, _ = sorted_unique(row, col, rows, cols)
         if perm is not None and value is not None:
-            value = value[perm]
+            value = value.index_select(0, perm)
     return torch.ops.torch_sparse.ind2ptr(row, rows), col, value
 
 

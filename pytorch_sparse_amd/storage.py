@@ -110,7 +110,25 @@ class SparseStorage(object):
         max_row: int = -1
         max_col: int = -1
         descents: int = -1  # unknown
-        if col.is_cuda and row is not None and (need_row_max or need_col_max):
+        # Both sizes given, unsorted COO, no caller caches to preserve: the check, the device-decided sort and the
+        # gather of the values are ENQUEUED back to back and the check's four words are read afterwards -- the one
+        # read-back no longer sits between the probe and the sort (an out-of-range id is still reported, after a
+        # sort whose result is then thrown away; nothing indexes with the unchecked ids before that)
+        presorted_row: Optional[Tensor] = None
+        presorted_col: Optional[Tensor] = None
+        presorted_value: Optional[Tensor] = None
+        did_sort = False
+        if (col.is_cuda and row is not None and rowptr is None and given_m is not None and given_n is not None and
+                not trust_data and not is_sorted and nnz > 1 and csr2csc is None and csc2csr is None):
+            counts_dev = torch.ops.tsamd.coo_check(row.contiguous(), col)
+            presorted_row, presorted_col, perm0 = torch.ops.tsamd.sort_coo_probed(row.contiguous(), col, given_m,
+                                                                                   given_n, counts_dev)
+            if value is not None:
+                presorted_value = value.index_select(0, perm0)
+            counts0: List[int] = counts_dev.tolist()  # the one host sync, with everything already in flight
+            descents, max_row, max_col = counts0[0], counts0[2], counts0[3]
+            did_sort = True
+        elif col.is_cuda and row is not None and (need_row_max or need_col_max):
             counts: List[int] = torch.ops.tsamd.coo_check(row.contiguous(), col).tolist()  # the one host sync
             descents, max_row, max_col = counts[0], counts[2], counts[3]
         else:
@@ -155,7 +173,13 @@ class SparseStorage(object):
         # deferred until the storage is moved to the GPU (`.cuda()` / `.to(device)`); until then every
         # accessor refuses to hand out the (still unsorted) arrays.
         self._pending_sort = (not is_sorted) and nnz > 1 and not col.is_cuda
-        if (not is_sorted) and nnz > 1 and col.is_cuda:
+        if did_sort:
+            # (sorted or not, the outputs of the device-decided sort are what the storage holds)
+            self._row = presorted_row
+            self._col = torch.jit._unwrap_optional(presorted_col)
+            if value is not None:
+                self._value = presorted_value
+        elif (not is_sorted) and nnz > 1 and col.is_cuda:
             r = self.row()
             keep_caches = rowptr is not None or csr2csc is not None or csc2csr is not None
             if descents < 0 and keep_caches:
@@ -169,14 +193,14 @@ class SparseStorage(object):
                 self._row = rs
                 self._col = cs
                 if value is not None:
-                    self._value = value[perm]
+                    self._value = value.index_select(0, perm)
             elif descents > 0:
                 rs, cs, perm = torch.ops.tsamd.sort_coo(r, col, M, N, True)
                 self._row = rs
                 self._col = cs
                 self._rowptr = None
                 if value is not None:
-                    self._value = value[perm]
+                    self._value = value.index_select(0, perm)
                 self._csr2csc = None
                 self._csc2csr = None
 
@@ -365,7 +389,7 @@ class SparseStorage(object):
         permutation afterwards (and colptr comes from the sorted columns for free); what `t()` needs."""
         perm = self._csr2csc
         if perm is not None:
-            return self._col[perm], self.row()[perm], perm
+            return self._col.index_select(0, perm), self.row().index_select(0, perm), perm
         N = self._sparse_sizes[1]
         cs, rs, perm = torch.ops.tsamd.sort_coo(self._col, self.row(), N, self._sparse_sizes[0], True)
         self._csr2csc = perm
@@ -401,7 +425,7 @@ class SparseStorage(object):
         else:
             perm0 = self._csr2csc
             if perm0 is not None:
-                ptr = torch.ops.torch_sparse.ind2ptr(self._col[perm0], N)
+                ptr = torch.ops.torch_sparse.ind2ptr(self._col.index_select(0, perm0), N)
             else:
                 # a new csr2csc comes with the sorted columns: no gather through the permutation
                 cs, rs, perm = self.csc_index()

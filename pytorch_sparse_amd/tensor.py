@@ -155,8 +155,8 @@ class SparseTensor(object):
         perm = self.storage.csr2csc()
         value = self.storage.value()
         if value is not None:
-            value = value[perm]
-        return self.storage.colptr(), self.storage.row()[perm], value
+            value = value.index_select(0, perm)
+        return self.storage.colptr(), self.storage.row().index_select(0, perm), value
 
     def has_value(self) -> bool:
         return self.storage.has_value()

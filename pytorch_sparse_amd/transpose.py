@@ -15,7 +15,7 @@ def t(src: SparseTensor) -> SparseTensor:
     value = st.value()
     M, N = st.sparse_sizes()
     out = SparseStorage(row=col_t, rowptr=st._colptr, col=row_t,
-                        value=None if value is None else value[perm], sparse_sizes=(N, M),
+                        value=None if value is None else value.index_select(0, perm), sparse_sizes=(N, M),
                         rowcount=st._colcount, colptr=st._rowptr, colcount=st._rowcount,
                         csr2csc=st._csc2csr, csc2csr=perm, is_sorted=True, trust_data=True)
     return src.from_storage(out)

@@ -105,6 +105,12 @@ r4, c4 = synth.uniform_edges(m, m, 7500000, seed=0, device=dev)
 v4 = synth.values(7500000, device=dev)
 run('sort_coo_7m5', lambda: torch.ops.tsamd.sort_coo(r4, c4, m, m, True), entries=7500000,
     algorithmic_bytes=7500000 * 16 * 2 + 7500000 * 8)
+def _ctor():
+    B_ = ts.SparseTensor(row=r4, col=c4, value=v4, sparse_sizes=(m, m))
+    B_.storage.rowptr()
+
+
+run('construct_7m5', _ctor, entries=7500000, algorithmic_bytes=7500000 * 20 * 2 + (m + 1) * 8)
 A = ts.SparseTensor(row=r4, col=c4, value=v4, sparse_sizes=(m, m)).coalesce()
 At = A.t()
 rpB = At.storage.rowptr()
