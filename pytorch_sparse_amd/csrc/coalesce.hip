@@ -35,7 +35,7 @@ __global__ void decode_keys_kernel(const int64_t *__restrict__ keys, int64_t n, 
 }
 
 // counts[0] += #{i : key[i] < key[i-1]}, counts[1] += #{i : key[i] == key[i-1]}
-// grid-stride with per-thread counters: one pair of atomics per wave at the very end
+// grid-stride with per-thread counters: one pair of atomics per workgroup at the very end
 __global__ __launch_bounds__(256) void order_probe_kernel(const int64_t *__restrict__ row,
                                                          const int64_t *__restrict__ col, int64_t n,
                                                          int64_t ncols, unsigned long long *counts) {
@@ -51,9 +51,17 @@ __global__ __launch_bounds__(256) void order_probe_kernel(const int64_t *__restr
     desc += lane_xor(desc, off);
     dup += lane_xor(dup, off);
   }
+  // one pair of atomics per WORKGROUP: on unsorted input every wave has descents, and the two result words
+  // are hot addresses (~12 ns per atomic, serialised: 0.12 ms for 7.5 M entries with per-wave atomics)
+  __shared__ unsigned int s_cnt[2][4];
   if ((threadIdx.x & 63) == 0) {
-    if (desc) atomicAdd(&counts[0], (unsigned long long)desc);
-    if (dup) atomicAdd(&counts[1], (unsigned long long)dup);
+    s_cnt[0][threadIdx.x >> 6] = desc;
+    s_cnt[1][threadIdx.x >> 6] = dup;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const unsigned int t = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+    if (t) atomicAdd(&counts[threadIdx.x], (unsigned long long)t);
   }
 }
 
@@ -477,7 +485,7 @@ extern "C" int tsamd_coo_order(const int64_t *row, const int64_t *col, int64_t E
   if (E <= 1) return TSAMD_OK;
   if (!row || !col) return TSAMD_ERR_INVALID;
   const int64_t nblk = ceil_div(E, 256);
-  hipLaunchKernelGGL(order_probe_kernel, dim3((unsigned int)(nblk < 2048 ? nblk : 2048)), dim3(256), 0,
+  hipLaunchKernelGGL(order_probe_kernel, dim3((unsigned int)(nblk < 1024 ? nblk : 1024)), dim3(256), 0,
                      stream, row, col, E, N, reinterpret_cast<unsigned long long *>(counts_out));
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;

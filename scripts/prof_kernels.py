@@ -110,6 +110,8 @@ def _ctor():
     B_.storage.rowptr()
 
 
+_index4 = torch.stack([r4, c4])
+run('coalesce_7m5', lambda: ts.coalesce(_index4, v4, m, m), entries=7500000, algorithmic_bytes=7500000 * 20 * 2)
 run('construct_7m5', _ctor, entries=7500000, algorithmic_bytes=7500000 * 20 * 2 + (m + 1) * 8)
 A = ts.SparseTensor(row=r4, col=c4, value=v4, sparse_sizes=(m, m)).coalesce()
 At = A.t()
