@@ -92,6 +92,13 @@ struct PatternCache {
   int64_t E = -1;
   int seen = 0;  // calls with this key so far
   Tensor row_t;
+  // value[csr2csc] of FIXED edge weights (a value tensor that does not require grad, e.g. GCN's normalised
+  // adjacency): valid while the pattern entry is and the value tensor keeps its storage / pointer / version
+  c10::weak_intrusive_ptr<c10::StorageImpl> val_storage{c10::weak_intrusive_ptr<c10::StorageImpl>(
+      c10::make_intrusive<c10::StorageImpl>(c10::StorageImpl::use_byte_size_t(), 0, c10::DataPtr(), nullptr, false))};
+  const void *val_ptr = nullptr;
+  uint32_t val_version = 0;
+  Tensor value_t;
 };
 
 PatternCache &pattern_cache_state() {
@@ -112,7 +119,9 @@ bool pattern_cache_ctl(bool enable) {
   const bool was = c.enabled;
   c.enabled = enable;
   c.row_t = Tensor();
+  c.value_t = Tensor();
   c.row_ptr = nullptr;
+  c.val_ptr = nullptr;
   return was;
 }
 
@@ -144,11 +153,39 @@ Tensor cached_csc_rows(const Tensor &row, const Tensor &csr2csc) {
     pc.E = row.numel();
     pc.seen = 1;
     pc.row_t = Tensor();
+    pc.value_t = Tensor();
+    pc.val_ptr = nullptr;
     return Tensor();
   }
   ++pc.seen;
   if (!pc.row_t.defined()) pc.row_t = row.index_select(0, csr2csc);
   return pc.row_t;
+}
+
+// value[csr2csc] for the pattern that cached_csc_rows() just confirmed (call right after it returned a defined
+// tensor): kept across backwards when `value` is not trainable, gathered anew otherwise
+Tensor csc_values(const Tensor &value, const Tensor &csr2csc) {
+  Tensor v = value.detach();
+  PatternCache &pc = pattern_cache_state();
+  if (needs_grad(value) || v.is_inference() || !v.is_contiguous() || stream_is_capturing(current_stream(v)))
+    return v.index_select(0, csr2csc);
+  c10::StorageImpl *vs = v.storage().unsafeGetStorageImpl();
+  const uint32_t vv = v.unsafeGetTensorImpl()->version_counter().current_version();
+  std::lock_guard<std::mutex> lock(pc.mu);
+  if (!pc.enabled || pc.perm_ptr != csr2csc.data_ptr() || !pc.row_t.defined()) return v.index_select(0, csr2csc);
+  bool same = pc.value_t.defined() && pc.val_ptr == v.data_ptr() && pc.val_version == vv &&
+              pc.value_t.scalar_type() == v.scalar_type() && pc.value_t.numel() == v.numel();
+  if (same) {
+    auto a = pc.val_storage.lock();
+    same = a && a.get() == vs;
+  }
+  if (!same) {
+    pc.value_t = v.index_select(0, csr2csc);
+    pc.val_storage = c10::weak_intrusive_ptr<c10::StorageImpl>(c10::intrusive_ptr<c10::StorageImpl>::reclaim_copy(vs));
+    pc.val_ptr = v.data_ptr();
+    pc.val_version = vv;
+  }
+  return pc.value_t;
 }
 
 // Forward launch: mirrors the argument checks of spmm_cpu.cpp:12-24 / spmm_cuda.cu:96-109.
@@ -375,7 +412,7 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
         Tensor row_t = cached_csc_rows(row, csr2csc);
         if (row_t.defined()) {
           // the pattern came back: its CSC row ids are at hand, only the values are gathered (one ATen gather)
-          OptTensor w = has_value ? OptTensor(value.detach().index_select(0, csr2csc)) : std::nullopt;
+          OptTensor w = has_value ? OptTensor(csc_values(value, csr2csc)) : std::nullopt;
           grad_mat = std::get<0>(spmm_fw(colptr, row_t, w, grad_out, "sum"));
         } else {
           OptTensor w = has_value ? OptTensor(value.detach()) : std::nullopt;

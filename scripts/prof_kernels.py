@@ -76,6 +76,21 @@ x = synth.features(n, 64, device=dev)
 g = synth.features(n, 64, seed=3, device=dev)
 run('c2_value_bw_f32_F64', lambda: nat.spmm_value_bw(row, rp, c, x, g, 'sum'), edges=E,
     algorithmic_bytes=E * (16 + 64 * 4 + 4) + n * 64 * 4)
+if not which or 'c2_train_step' in which:
+    _v = synth.values(E, device=dev).requires_grad_()
+    _A = ts.SparseTensor(rowptr=rp, col=c, value=_v, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    _A.storage.fill_cache_()
+    _xr = x.clone().requires_grad_()
+
+    def _step():
+        _xr.grad = None
+        _v.grad = None
+        _A.matmul(_xr, 'sum').backward(g)
+    _step()
+    _step()
+    torch.ops.tsamd.operand_cache(False)
+    run('c2_train_step', _step, edges=E, algorithmic_bytes=3 * balg(E, n, 64, 4, True, False))
+    torch.ops.tsamd.operand_cache(True)
 xb = synth.features(n, 128, dtype=torch.bfloat16, device=dev)
 gb = synth.features(n, 128, seed=3, dtype=torch.bfloat16, device=dev)
 run('c3_max_fw_bf16_F128', lambda: nat.spmm(rp, c, None, xb, 'max'), edges=E, algorithmic_bytes=balg(E, n, 128, 2, False, True))

@@ -683,8 +683,20 @@ def run_c2_backward(dev, cpu=True, iters=10):
         torch.ops.tsamd.pattern_cache(False)
         fb_nocache_ms = gpu_ms(fwbw, iters=iters)  # every backward reads (row, value) through csr2csc
         torch.ops.tsamd.pattern_cache(True)
+    # the same step with FIXED edge weights (GCN's normalised adjacency: the values need no gradient): the
+    # backward is A^T G alone and value[csr2csc] is cached next to the pattern's CSC row ids
+    A_fixed = ts.SparseTensor(rowptr=rp, col=c, value=v, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    A_fixed.storage.fill_cache_()
+
+    def fwbw_fixed():
+        xr.grad = None
+        A_fixed.matmul(xr, 'sum').backward(g)
+    with operand_cache(False):
+        fixed_ms = gpu_ms(fwbw_fixed, iters=iters)
+    gmat_fixed = xr.grad.clone()
     out = fwbw()
     gval, gmat = A.storage.value().grad, xr.grad
+    fixed_same = bool(torch.equal(gmat_fixed, gmat))
     b_vb = E * (16 + K * s + s) + n * K * s          # SURVEY 8d "value-grad SDDMM"
     b_fw = b_alg(E, n, K, s, True, False)
     b_gm = b_alg(E, n, K, s, True, False) + E * 8    # A^T G on the CSC view, entries read through csr2csc
@@ -692,6 +704,7 @@ def run_c2_backward(dev, cpu=True, iters=10):
                workload='configs[1] graph (2^20 R-MAT, E=%d), F=64 fp32: value gradient alone; sum forward + grad_value + '
                         'grad_mat through adj.matmul(x).backward(g)' % E,
                value_bw_ms=round(vb_ms, 4), fw_bw_ms=round(fb_ms, 4), fw_bw_without_pattern_cache_ms=round(fb_nocache_ms, 4),
+               fw_bw_fixed_weights_ms=round(fixed_ms, 4), fixed_weights_grad_mat_bit_identical=fixed_same,
                gedges_per_s_value_bw=round(E / vb_ms / 1e6, 3),
                gedges_per_s_fw_bw=round(E / fb_ms / 1e6, 3),
                roofline=dict(_roof(b_vb, vb_ms, 'spmm_value_bw_kernel; bytes = E(16 + F s + s) + M F s (SURVEY 8d)'),

@@ -159,3 +159,26 @@ def test_graph_capture_bypasses_the_caches(dev, ops):
     torch.cuda.synchronize()
     assert bits_equal(out, ref * 4.0)
     assert bits_equal(spmm(), ref * 4.0)  # and the eager path (cache refilled for the new version) agrees
+
+
+def test_fixed_edge_weights_are_gathered_once_and_updates_are_seen(dev, ops):
+    """Non-trainable values (GCN's normalised adjacency): value[csr2csc] is cached with the pattern; an in-place
+    update of the weights (new version) is picked up."""
+    import pytorch_sparse_amd as ts
+    rp, c = synth.rmat_csr(12, 12, seed=1, device=dev)
+    n = 1 << 12
+    v = synth.values(c.numel(), device=dev)
+    x = synth.features(n, 32, device=dev).requires_grad_()
+    g = synth.features(n, 32, seed=5, device=dev)
+    A = ts.SparseTensor(rowptr=rp, col=c, value=v, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    grads = []
+    for _ in range(4):
+        x.grad = None
+        A.matmul(x, 'sum').backward(g)
+        grads.append(x.grad.clone())
+    for gx in grads[1:]:
+        assert bits_equal(gx, grads[0])
+    v.mul_(2.0)
+    x.grad = None
+    A.matmul(x, 'sum').backward(g)
+    assert bits_equal(x.grad, grads[0] * 2.0)
