@@ -138,7 +138,7 @@ def secondary(dev, cpu=True):
     for fn in (lambda: bc.run_c1(dev, cpu=cpu), lambda: bc.run_c2(dev, cpu=cpu), lambda: bc.run_c2_backward(dev, cpu=cpu),
                lambda: bc.run_c3(dev, False, cpu=cpu), lambda: bc.run_c3(dev, True, cpu=cpu),
                lambda: bc.run_construct(dev, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu),
-               lambda: bc.run_spspmm(dev, 'stress', cpu=False, iters=2)):  # SURVEY 8d stress row: property checks
+               lambda: bc.run_spspmm(dev, 'stress', cpu=False, iters=3)):  # SURVEY 8d stress row: property checks
         try:
             res.append(fn())
         except Exception as exc:  # a failing secondary must not take the headline down

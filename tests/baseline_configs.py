@@ -409,7 +409,8 @@ def run_spspmm(dev, kind='c4', cpu=True, iters=5):
     rpB = At.storage.rowptr()
     colA = A.storage.col()
     P = int((rpB[colA + 1] - rpB[colA]).sum())
-    ms = gpu_ms(lambda: A @ At, iters=iters, warm=1)
+    # (two warm-up products: the second still allocates -- the result of the first is alive while it runs)
+    ms = gpu_ms(lambda: A @ At, iters=iters, warm=2)
     C = A @ At
     nnzA, nnzC = A.nnz(), C.nnz()
     comp = nnzA * (8 + 4) + P * (8 + 4) + nnzC * (16 + 4)  # SURVEY 8d compulsory bytes
