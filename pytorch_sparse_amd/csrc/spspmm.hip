@@ -45,7 +45,16 @@ constexpr int kSmallCap = 512;    // products handled by one wave (LDS radix sor
 #endif
 constexpr int kSmallBinCap = TSAMD_SPSPMM_SMALLBIN_CAP;
 constexpr int kBinIdxBits = kSmallBinCap <= 512 ? 9 : (kSmallBinCap <= 1024 ? 10 : 11);
-constexpr int kMediumCap = 4096;  // products handled by one 256-thread workgroup
+// Rows of 513..kMediumCap products are sorted by one 256-thread workgroup in LDS; longer rows take the binned
+// path.  Same-box A/B (scripts/ab_spspmm_medium.py; R-MAT stress product / uniform product with ~1600 products per
+// row): cap 4096: 50.5 / 14.7 ms, 2048: 46.6-47.0 / 11.0-11.1 ms, 1024: 47.0 / 10.1 ms, 512 (no medium class):
+// 49.8 / 10.1-10.2 ms -- the LDS bitonic sort pays a workgroup barrier per stage (78 stages at 4096 keys) and its
+// LDS footprint costs occupancy; the binned path is faster even for uniform rows of a few thousand products.
+#ifndef TSAMD_SPSPMM_MEDIUM_CAP
+#define TSAMD_SPSPMM_MEDIUM_CAP 1024
+#endif
+constexpr int kMediumCap = TSAMD_SPSPMM_MEDIUM_CAP;  // products handled by one 256-thread workgroup
+constexpr int kMediumLogT = kMediumCap <= 1024 ? 11 : (kMediumCap <= 2048 ? 12 : 13);  // hash set of the symbolic stage
 
 // stats layout (device int64[8])
 enum { ST_NMEDIUM = 2, ST_NLARGE = 3, ST_PLARGE = 4, ST_PMAX = 5 };
@@ -1304,7 +1313,7 @@ extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const in
                      colA, rowptrB, colB, prod, bins, nnzC);
   TSAMD_LAUNCH_CHECK();
   if (n_medium > 0) {
-    hipLaunchKernelGGL((spspmm_symbolic_kernel<256, 13>), dim3((unsigned int)n_medium), dim3(256), 0,
+    hipLaunchKernelGGL((spspmm_symbolic_kernel<256, kMediumLogT>), dim3((unsigned int)n_medium), dim3(256), 0,
                        stream, rowptrA, colA, rowptrB, colB, prod, bins, nnzC);
     TSAMD_LAUNCH_CHECK();
   }
