@@ -746,7 +746,6 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
   for (int q = tid; q < nr; q += kLargeThreads) cursor[q] = 0;
   __syncthreads();
   const int64_t *off = bin_off + (int64_t)blockIdx.x * nr;
-  const uint32_t mask = (1u << lg_range) - 1u;
   const int lane = tid & 63;
   expand_row<T, kLargeThreads, WITH_VAL, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
                                                [&](int, uint32_t c, A v) {
@@ -767,7 +766,7 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
     }
     base = lane_read(base, leader);
     const int64_t pos = off[q] + base + (lane - leader);
-    bcol[pos] = c & mask;
+    bcol[pos] = c;  // the FULL column: small bins are merged across ranges (classify), the dense kernels mask
     if (WITH_VAL) bval[pos] = Traits<T>::from_acc(v);
   });
 }
@@ -843,7 +842,7 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
 #pragma unroll
       for (int u = 0; u < kBinBatch; ++u) {
         const int64_t p = p0 + (int64_t)u * kAccumThreads;
-        c[u] = bcol[p < b1 ? p : b1 - 1];  // a repeated entry sets the same bit again
+        c[u] = bcol[p < b1 ? p : b1 - 1] & (uint32_t)(range_words * 32 - 1);  // a repeated entry sets the same bit again
       }
 #pragma unroll
       for (int u = 0; u < kBinBatch; ++u) atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
@@ -903,7 +902,7 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
       for (int u = 0; u < kBinBatch; ++u) {
         const int64_t p = p0 + (int64_t)u * kAccumThreads;
         const bool ok = p < b1;
-        c[u] = bcol[ok ? p : b1 - 1];
+        c[u] = bcol[ok ? p : b1 - 1] & (uint32_t)(kCols - 1);
         v[u] = (ok && valC != nullptr) ? Traits<T>::to_acc(bval[p]) : A(0);  // a repeat adds zero
       }
 #pragma unroll
@@ -959,85 +958,161 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
   }
 }
 
-// Bins by size: those of at most kSmallBinCap products go to one WAVE each (many in flight per CU), the
-// others to the persistent workgroups above.  Most bins of a power-law product are small (a few hundred
-// products), and a persistent workgroup spends ~8 us of barriers, dependent loads and ticket traffic on
-// each regardless of its size.  lists[0 .. ntask) = small bins, lists[ntask .. 2 ntask) = big bins (in no
-// particular order), counts[0] / counts[1] their numbers; empty bins get bin_cnt = 0 here.
+// Bins by size.  Big bins (more than kSmallBinCap products) go to the persistent workgroups above.  The others
+// are taken by one WAVE each (many in flight per CU) -- and CONSECUTIVE small bins of a row are merged into one
+// group of at most kSmallBinCap products first: their products are contiguous in the scratch and the sort-based
+// wave path does not care how many column ranges its keys span.  Most bins of a power-law product hold ~100
+// products and the bins of a uniform product with a few thousand products per row ~60: a wave per such bin runs
+// at 50 % lane utilisation at best and pays its descriptor loads per bin (uniform product: 4.9 M bins -> 0.4 M
+// groups).  lists[0 .. ntask) = small groups, encoded first task | number of merged bins << 40;
+// lists[ntask .. 2 ntask) = big bins; counts[0] / counts[1] their numbers.  bin_cnt of empty bins and of the
+// bins merged into a group behind its first one is set to 0 here (the group's count lands on its first bin).
+// One thread per large row, two passes over its nr bins; one atomic per workgroup and list.
+constexpr int kGroupShift = 40;
+constexpr int kMaxGroupBins = 256;  // (column span of a group) << kBinIdxBits must fit 32 bits: 2^(13+8+10) = 2^31
+
 __global__ __launch_bounds__(256) void spspmm_large_classify_kernel(const int64_t *__restrict__ bin_off,
-                                                                   int64_t ntask, int64_t *__restrict__ lists,
+                                                                   int64_t n_rows, int nr, int64_t ntask,
+                                                                   int64_t *__restrict__ lists,
                                                                    unsigned long long *counts,
                                                                    int64_t *__restrict__ bin_cnt) {
-  const int lane = (int)(threadIdx.x & 63);
-  const int64_t task = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int64_t n = 0;
-  if (task < ntask) {
-    n = bin_off[task + 1] - bin_off[task];
-    if (n == 0) bin_cnt[task] = 0;
+  const int lane = (int)(threadIdx.x & 63), wid = (int)(threadIdx.x >> 6);
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t t0 = r * nr;
+  // pass 1: how many groups / big bins does this row emit
+  int n_small = 0, n_big = 0;
+  if (r < n_rows) {
+    int64_t cur = 0;
+    int span = 0;
+    for (int q = 0; q < nr; ++q) {
+      const int64_t n = bin_off[t0 + q + 1] - bin_off[t0 + q];
+      if (n > kSmallBinCap) {
+        if (cur > 0) ++n_small;
+        cur = 0;
+        span = 0;
+        ++n_big;
+        continue;
+      }
+      if (cur > 0 && (cur + n > kSmallBinCap || span >= kMaxGroupBins)) {
+        ++n_small;
+        cur = 0;
+        span = 0;
+      }
+      if (n > 0 || cur > 0) {
+        cur += n;
+        span += 1;
+      }
+    }
+    if (cur > 0) ++n_small;
   }
-  const int cls = n == 0 ? -1 : (n <= kSmallBinCap ? 0 : 1);
-  // one atomic per workgroup and list (the two counters are hot addresses: ~12 ns per atomic, serialised)
-  __shared__ int s_cnt[2][4];
+  // block-level exclusive positions, one atomic per workgroup and list
+  __shared__ int s_tot[2][4];
   __shared__ unsigned long long s_base[2];
-  const int wid = (int)(threadIdx.x >> 6);
-  unsigned long long m[2];
-  for (int k = 0; k < 2; ++k) {
-    m[k] = __ballot(cls == k);
-    if (lane == 0) s_cnt[k][wid] = __popcll(m[k]);
+  int inc_s = n_small, inc_b = n_big;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int a = lane_read(inc_s, lane >= off ? lane - off : lane), b = lane_read(inc_b, lane >= off ? lane - off : lane);
+    if (lane >= off) {
+      inc_s += a;
+      inc_b += b;
+    }
+  }
+  if (lane == 63) {
+    s_tot[0][wid] = inc_s;
+    s_tot[1][wid] = inc_b;
   }
   __syncthreads();
   if (threadIdx.x < 2) {
-    const int tot = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+    const int tot = s_tot[threadIdx.x][0] + s_tot[threadIdx.x][1] + s_tot[threadIdx.x][2] + s_tot[threadIdx.x][3];
     s_base[threadIdx.x] = tot ? atomicAdd(&counts[threadIdx.x], (unsigned long long)tot) : 0ull;
   }
   __syncthreads();
-  if (cls >= 0) {
-    int before = 0;
-    for (int w = 0; w < wid; ++w) before += s_cnt[cls][w];
-    lists[(int64_t)cls * ntask + (int64_t)s_base[cls] + before + __popcll(m[cls] & ((1ull << lane) - 1ull))] = task;
+  if (r >= n_rows) return;
+  int64_t pos_s = (int64_t)s_base[0] + (inc_s - n_small), pos_b = ntask + (int64_t)s_base[1] + (inc_b - n_big);
+  for (int w = 0; w < wid; ++w) {
+    pos_s += s_tot[0][w];
+    pos_b += s_tot[1][w];
   }
+  // pass 2: the same walk, writing the entries
+  int64_t cur = 0, first = -1;
+  int span = 0;
+  auto flush = [&]() {
+    if (cur > 0) lists[pos_s++] = first | ((int64_t)span << kGroupShift);
+    cur = 0;
+    span = 0;
+    first = -1;
+  };
+  for (int q = 0; q < nr; ++q) {
+    const int64_t t = t0 + q;
+    const int64_t n = bin_off[t + 1] - bin_off[t];
+    if (n > kSmallBinCap) {
+      flush();
+      lists[pos_b++] = t;
+      continue;
+    }
+    bin_cnt[t] = 0;  // empty, or merged behind the first bin of its group (which the count kernel overwrites)
+    if (cur > 0 && (cur + n > kSmallBinCap || span >= kMaxGroupBins)) flush();
+    if (n > 0 || cur > 0) {
+      if (cur == 0) first = t;
+      cur += n;
+      span += 1;
+    }
+  }
+  flush();
 }
 
 constexpr int kSmallBinWaves = 8192;  // resident waves of the small-bin kernels (grid-stride over the list)
 
-// symbolic, small bins: occupancy bitmap of the range in LDS, one wave per bin
+// symbolic, small groups: distinct columns among the group's products -- an LDS hash set (the columns of a
+// merged group span several ranges, a bitmap of them would not fit), one wave per group
+constexpr int kGroupLogT = kSmallBinCap <= 512 ? 10 : (kSmallBinCap <= 1024 ? 11 : 12);
+
 __global__ __launch_bounds__(64) void spspmm_smallbin_count_kernel(
     const int64_t *__restrict__ rows, int nr, const int64_t *__restrict__ small,
     const unsigned long long *__restrict__ n_small, const int64_t *__restrict__ bin_off,
-    const uint32_t *__restrict__ bcol, int range_words, int64_t *__restrict__ bin_cnt,
-    unsigned long long *__restrict__ nnzC) {
-  __shared__ uint32_t bits[(1 << 15) / 32];
+    const uint32_t *__restrict__ bcol, int64_t *__restrict__ bin_cnt, unsigned long long *__restrict__ nnzC) {
+  constexpr int kT = 1 << kGroupLogT;
+  __shared__ uint32_t tab[kT];
   const int lane = (int)threadIdx.x;
-  for (int w = lane; w < range_words; w += 64) bits[w] = 0;
+  for (int w = lane; w < kT; w += 64) tab[w] = kEmptyKey;
   const int64_t ns = (int64_t)*n_small;
   for (int64_t t = blockIdx.x; t < ns; t += gridDim.x) {
-    const int64_t task = small[t];
+    const int64_t entry = small[t];
+    const int64_t task = entry & (((int64_t)1 << kGroupShift) - 1);
+    const int nb = (int)(entry >> kGroupShift);
     const int64_t b0 = bin_off[task];
-    const int n = (int)(bin_off[task + 1] - b0);
-    uint32_t c[kSmallBinCap / 64];
+    const int n = (int)(bin_off[task + nb] - b0);
+    __syncthreads();  // (one wave: orders the table resets of the previous group)
+    int fresh = 0;
+    for (int q0 = 0; q0 < n; q0 += 64 * 4) {
+      uint32_t c[4];
 #pragma unroll
-    for (int u = 0; u < kSmallBinCap / 64; ++u) {
-      const int q = u * 64 + lane;
-      if (u * 64 < n) c[u] = bcol[b0 + (q < n ? q : n - 1)];  // (wave-uniform) a repeat sets the same bit again
-    }
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * 64 + lane;
+        c[u] = q < n ? bcol[b0 + q] : kEmptyKey;
+      }
 #pragma unroll
-    for (int u = 0; u < kSmallBinCap / 64; ++u)
-      if (u * 64 < n) atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
-    __syncthreads();
-    int cnt = 0;
-    for (int w = lane; w < range_words; w += 64) {
-      const uint32_t b = bits[w];
-      if (b) {
-        cnt += __popc(b);
-        bits[w] = 0;
+      for (int u = 0; u < 4; ++u) {
+        if (c[u] == kEmptyKey) continue;
+        uint32_t h = (c[u] * 0x9E3779B1u) >> (32 - kGroupLogT);
+        for (;;) {
+          const uint32_t old = atomicCAS(&tab[h], kEmptyKey, c[u]);
+          if (old == kEmptyKey) {
+            ++fresh;
+            break;
+          }
+          if (old == c[u]) break;
+          h = (h + 1) & (kT - 1);
+        }
       }
     }
-    for (int off = 32; off > 0; off >>= 1) cnt += lane_xor(cnt, off);
-    if (lane == 0) {
-      bin_cnt[task] = cnt;
-      atomicAdd(&nnzC[rows[task / nr]], (unsigned long long)cnt);
-    }
+    for (int off = 32; off > 0; off >>= 1) fresh += lane_xor(fresh, off);
     __syncthreads();
+    for (int w = lane; w < kT; w += 64) tab[w] = kEmptyKey;
+    if (lane == 0) {
+      bin_cnt[task] = fresh;
+      atomicAdd(&nnzC[rows[task / nr]], (unsigned long long)fresh);
+    }
   }
 }
 
@@ -1055,14 +1130,17 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
   const int lane = (int)threadIdx.x;
   const int64_t ns = (int64_t)*n_small;
   for (int64_t t = blockIdx.x; t < ns; t += gridDim.x) {
-    const int64_t task = small[t];
+    const int64_t entry = small[t];
+    const int64_t task = entry & (((int64_t)1 << kGroupShift) - 1);
+    const int nb = (int)(entry >> kGroupShift);
     const int64_t b0 = bin_off[task];
-    const int p = (int)(bin_off[task + 1] - b0);
+    const int p = (int)(bin_off[task + nb] - b0);
+    const uint32_t col_base = (uint32_t)((task % nr) << kLgRange<T>);
     const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : (p <= 512 ? 8 : (p <= 1024 ? 16 : 32))));
     for (int q = lane; q < 64 * items; q += 64) {
       uint32_t k = kEmptyKey;
       if (q < p) {
-        k = (bcol[b0 + q] << kBinIdxBits) | (uint32_t)q;
+        k = ((bcol[b0 + q] - col_base) << kBinIdxBits) | (uint32_t)q;
         if (valC != nullptr) sval[q] = Traits<T>::to_acc(bval[b0 + q]);
       }
       skey[q] = k;
@@ -1075,9 +1153,9 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
     else if (items == 16) sort_lds_keys<16>(skey, lane);
     else if constexpr (kSmallBinCap > 1024) sort_lds_keys<32>(skey, lane);
     __syncthreads();
-    const int64_t r = task / nr, q0 = task - r * nr;
+    const int64_t r = task / nr;
     const int64_t out0 = rowptrC[rows[r]] + (bin_pref[task] - bin_pref[r * nr]);
-    const uint32_t col0 = (uint32_t)(q0 << kLgRange<T>);
+    const uint32_t col0 = col_base;
     compress_and_store<T, 64>(
         p, out0, colC, valC, sscan, [&](int idx) { return col0 + (skey[idx] >> kBinIdxBits); },
         [&](int idx) { return sval[skey[idx] & (uint32_t)(kSmallBinCap - 1)]; });
@@ -1166,13 +1244,13 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const void *valA
   TSAMD_LAUNCH_CHECK();
   TSAMD_HIP_TRY(hipMemsetAsync(w.queue, 0, 64, stream));
   TSAMD_HIP_TRY(hipMemsetAsync(w.counts, 0, 64, stream));
-  hipLaunchKernelGGL(spspmm_large_classify_kernel, dim3((unsigned int)ceil_div(w.ntask, 256)), dim3(256), 0, stream,
-                     (const int64_t *)w.hist, w.ntask, w.lists, w.counts, w.bin_cnt);
+  hipLaunchKernelGGL(spspmm_large_classify_kernel, dim3((unsigned int)ceil_div(n_large, 256)), dim3(256), 0, stream,
+                     (const int64_t *)w.hist, n_large, w.nr, w.ntask, w.lists, w.counts, w.bin_cnt);
   TSAMD_LAUNCH_CHECK();
   const unsigned int small_grid = (unsigned int)(w.ntask < kSmallBinWaves ? w.ntask : kSmallBinWaves);
   hipLaunchKernelGGL(spspmm_smallbin_count_kernel, dim3(small_grid), dim3(64), 0, stream, rows, w.nr,
                      (const int64_t *)w.lists, (const unsigned long long *)w.counts, (const int64_t *)w.hist,
-                     (const uint32_t *)w.bcol, (1 << w.lg_range) / 32, w.bin_cnt,
+                     (const uint32_t *)w.bcol, w.bin_cnt,
                      reinterpret_cast<unsigned long long *>(nnzC));
   TSAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(spspmm_large_count_kernel, dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream, rows,

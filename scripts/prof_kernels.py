@@ -136,6 +136,15 @@ C = A @ At
 run('c4_spspmm', lambda: A @ At, products=P, algorithmic_bytes=A.nnz() * 12 + P * 12 + C.nnz() * 20)
 del A, At, C, r4, c4, v4
 torch.cuda.empty_cache()
+if 'uniform40_spspmm' in which:
+    mu = 200000
+    ru, cu_ = synth.uniform_edges(mu, mu, 40 * mu, seed=0, device=dev)
+    Au = ts.SparseTensor(row=ru, col=cu_, value=synth.values(ru.numel(), device=dev), sparse_sizes=(mu, mu)).coalesce()
+    Atu = Au.t()
+    Pu = int((Atu.storage.rowptr()[Au.storage.col() + 1] - Atu.storage.rowptr()[Au.storage.col()]).sum())
+    nnzCu = (Au @ Atu).nnz()
+    run('uniform40_spspmm', lambda: Au @ Atu, products=Pu, algorithmic_bytes=Au.nnz() * 12 + Pu * 12 + nnzCu * 20)
+    del Au, Atu
 if not which or 'stress_spspmm' in which:
     rp, c = synth.rmat_csr(19, 8, seed=0, device=dev)
     A = ts.SparseTensor(rowptr=rp, col=c, value=synth.values(c.numel(), device=dev), sparse_sizes=(1 << 19, 1 << 19),
