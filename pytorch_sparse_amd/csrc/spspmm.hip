@@ -968,6 +968,14 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
 // lists[ntask .. 2 ntask) = big bins; counts[0] / counts[1] their numbers.  bin_cnt of empty bins and of the
 // bins merged into a group behind its first one is set to 0 here (the group's count lands on its first bin).
 // One thread per large row, two passes over its nr bins; one atomic per workgroup and list.
+// Merging stops at kGroupCap products.  Same-box (R-MAT stress / uniform product): (small-bin cap, group cap) =
+// (1024, 1024): 43.1 / 7.6 ms; (1024, 512): 44.1 / 7.6 ms; (512, 512): 48.0 / 6.6 ms -- the uniform product gains from the
+// smaller LDS footprint of the 512-key kernels, not from shorter sorts; the R-MAT product wants its bins of
+// 513..1024 products off the persistent workgroups.
+#ifndef TSAMD_SPSPMM_GROUP_CAP
+#define TSAMD_SPSPMM_GROUP_CAP 1024
+#endif
+constexpr int kGroupCap = TSAMD_SPSPMM_GROUP_CAP < kSmallBinCap ? TSAMD_SPSPMM_GROUP_CAP : kSmallBinCap;
 constexpr int kGroupShift = 40;
 constexpr int kMaxGroupBins = 256;  // (column span of a group) << kBinIdxBits must fit 32 bits: 2^(13+8+10) = 2^31
 
@@ -993,7 +1001,7 @@ __global__ __launch_bounds__(256) void spspmm_large_classify_kernel(const int64_
         ++n_big;
         continue;
       }
-      if (cur > 0 && (cur + n > kSmallBinCap || span >= kMaxGroupBins)) {
+      if (cur > 0 && (cur + n > kGroupCap || span >= kMaxGroupBins)) {
         ++n_small;
         cur = 0;
         span = 0;
@@ -1051,7 +1059,7 @@ __global__ __launch_bounds__(256) void spspmm_large_classify_kernel(const int64_
       continue;
     }
     bin_cnt[t] = 0;  // empty, or merged behind the first bin of its group (which the count kernel overwrites)
-    if (cur > 0 && (cur + n > kSmallBinCap || span >= kMaxGroupBins)) flush();
+    if (cur > 0 && (cur + n > kGroupCap || span >= kMaxGroupBins)) flush();
     if (n > 0 || cur > 0) {
       if (cur == 0) first = t;
       cur += n;
