@@ -78,7 +78,8 @@ std::vector<int64_t> operand_cache_ctl(bool enable) {
 // gathers row[csr2csc] and value[csr2csc] anew in every backward (spmm.cpp:104-106).  The row ids of the CSC
 // order only depend on the PATTERN, which a training loop does not change: they are gathered once and kept
 // (one entry; key = storage objects, data pointers and version counters of `row` and `csr2csc`), so that every
-// later backward reads them sequentially.  TSAMD_PATTERN_CACHE=0 turns it off (then, and for a pattern seen
+// later backward reads them sequentially; the stream is part of the key (a backward on another stream starts a
+// new entry instead of reading arrays whose producer it is not ordered after).  TSAMD_PATTERN_CACHE=0 turns it off (then, and for a pattern seen
 // for the first time in a no-reuse setting, the kernel reads (row, value) through csr2csc -- tsamd_spmm_permuted).
 struct PatternCache {
   std::mutex mu;
@@ -90,6 +91,7 @@ struct PatternCache {
   const void *row_ptr = nullptr, *perm_ptr = nullptr;
   uint32_t row_version = 0, perm_version = 0;
   int64_t E = -1;
+  void *stream = nullptr;  // the gathered arrays are produced and consumed on one stream only (no cross-stream events)
   int seen = 0;  // calls with this key so far
   Tensor row_t;
   // value[csr2csc] of FIXED edge weights (a value tensor that does not require grad, e.g. GCN's normalised
@@ -136,9 +138,10 @@ Tensor cached_csc_rows(const Tensor &row, const Tensor &csr2csc) {
   c10::StorageImpl *rs = row.storage().unsafeGetStorageImpl(), *ps = csr2csc.storage().unsafeGetStorageImpl();
   const uint32_t rv = row.unsafeGetTensorImpl()->version_counter().current_version();
   const uint32_t pv = csr2csc.unsafeGetTensorImpl()->version_counter().current_version();
+  void *stream = current_stream(row);
   std::lock_guard<std::mutex> lock(pc.mu);
   bool same = pc.row_ptr == row.data_ptr() && pc.perm_ptr == csr2csc.data_ptr() && pc.E == row.numel() &&
-              pc.row_version == rv && pc.perm_version == pv;
+              pc.row_version == rv && pc.perm_version == pv && pc.stream == stream;
   if (same) {
     auto a = pc.row_storage.lock(), b = pc.perm_storage.lock();
     same = a && b && a.get() == rs && b.get() == ps;
@@ -151,6 +154,7 @@ Tensor cached_csc_rows(const Tensor &row, const Tensor &csr2csc) {
     pc.row_version = rv;
     pc.perm_version = pv;
     pc.E = row.numel();
+    pc.stream = stream;
     pc.seen = 1;
     pc.row_t = Tensor();
     pc.value_t = Tensor();
@@ -172,7 +176,8 @@ Tensor csc_values(const Tensor &value, const Tensor &csr2csc) {
   c10::StorageImpl *vs = v.storage().unsafeGetStorageImpl();
   const uint32_t vv = v.unsafeGetTensorImpl()->version_counter().current_version();
   std::lock_guard<std::mutex> lock(pc.mu);
-  if (!pc.enabled || pc.perm_ptr != csr2csc.data_ptr() || !pc.row_t.defined()) return v.index_select(0, csr2csc);
+  if (!pc.enabled || pc.perm_ptr != csr2csc.data_ptr() || !pc.row_t.defined() || pc.stream != current_stream(v))
+    return v.index_select(0, csr2csc);
   bool same = pc.value_t.defined() && pc.val_ptr == v.data_ptr() && pc.val_version == vv &&
               pc.value_t.scalar_type() == v.scalar_type() && pc.value_t.numel() == v.numel();
   if (same) {

@@ -77,10 +77,11 @@ struct Coord {  // a point on the merge path: rows [0,row) done, edges [0,edge) 
 struct Workspace {
   Coord *table;       // [P+1]
   int64_t *tail_row;  // [P]   row id of the unfinished row's partial, or -1
+  int64_t *head_row;  // [P]   row id of the cut row that ends in the partition (its head record is there), or -1
   void *head_val;     // [B][P][K] acc_t : piece of the first row (it started earlier)
   void *tail_val;     // [B][P][K] acc_t : piece of the last row (it continues later)
-  int64_t *head_arg;  // min/max only
-  int64_t *tail_arg;
+  uint32_t *head_arg;  // min/max only: winners as 32-bit offsets from the partition's first edge (table[p].edge),
+  uint32_t *tail_arg;  // kNoArg32 = none -- as the merge kernel holds them; the fix-up kernel widens them
   int64_t P;
   int64_t items;  // (row, edge) items per partition
   // channel-camping avoidance (see "relabel" below)
@@ -475,19 +476,19 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
 }
 
 template <typename T, int VEC, int RED>
-__device__ __forceinline__ void write_carry(void *cval, int64_t *carg, uint64_t off,
+__device__ __forceinline__ void write_carry(void *cval, uint32_t *carg, uint64_t off,
                                             typename Traits<T>::acc_t (&val)[VEC],
-                                            int64_t (&arg)[VEC]) {
+                                            uint32_t (&arg)[VEC]) {
   using A = typename Traits<T>::acc_t;
   Pack<A, VEC> v;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) v.v[j] = val[j];
   *reinterpret_cast<Pack<A, VEC> *>(reinterpret_cast<A *>(cval) + off) = v;
   if constexpr (RED != RED_ADD) {
-    Pack<int64_t, VEC> a;
+    Pack<uint32_t, VEC> a;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) a.v[j] = arg[j];
-    *reinterpret_cast<Pack<int64_t, VEC> *>(carg + off) = a;
+    *reinterpret_cast<Pack<uint32_t, VEC> *>(carg + off) = a;
   }
 }
 
@@ -757,10 +758,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
       // row r ends here
       if (estart < rend) reduce_groups<A, VEC, RED>(lgG, val, arg);
       if (writer) {
-        if constexpr (RED != RED_ADD) widen_args();
         if (incoming && r == r0) {  // head of a cut row: the fix-up kernel finishes it
-          write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg64);
+          write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg);
         } else {
+          if constexpr (RED != RED_ADD) widen_args();
           const uint64_t o = out_b + out_position(ws, r, M) * K;
           write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, rend - estart, mean, E);
         }
@@ -787,17 +788,26 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
   // tail: the piece of the unfinished row r1 that falls into this partition
   if (r1 < M && estart < e1) {
     reduce_groups<A, VEC, RED>(lgG, val, arg);
-    if constexpr (RED != RED_ADD) widen_args();
-    if (writer) write_carry<T, VEC, RED>(ws.tail_val, ws.tail_arg, carry_off, val, arg64);
+    if (writer) write_carry<T, VEC, RED>(ws.tail_val, ws.tail_arg, carry_off, val, arg);
     trow = r1;
   }
-  if (y == 0 && lane == 0) ws.tail_row[p] = trow;
+  if (y == 0 && lane == 0) {
+    ws.tail_row[p] = trow;
+    // a cut first row that ends here (rows [r0, r1) end in this partition): the fix-up kernel finds its id in
+    // head_row[p]
+    ws.head_row[p] = (incoming && r1 > r0) ? r0 : -1;
+  }
 }
 
 // ---------------------------------------------------------------------------
-// 3. fix-up: partition q in which a cut row ends (it has a head record) folds
+// 3. fix-up: partition q in which a cut row ends (the merge kernel left its id in head_row[q]) folds
 //    that row's tail records q-1, q-2, ... and writes the final value.
 //    One wave per (q, b); lanes stride over K.
+//    The kernel is a chain of dependent round trips, not a stream (165 k waves of a few hundred bytes
+//    each): it used to take five of them (table -> rowptr -> tail_row -> records -> store).  Now the
+//    row id comes from one word, and everything else -- the tail ids of the 64 partitions before q, the
+//    row's degree, the head record and the FIRST tail record (a cut row always has one, in q-1) --
+//    is requested at once and waited for once.
 // ---------------------------------------------------------------------------
 template <typename T, int RED>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
@@ -807,78 +817,133 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
   const int lane = (int)(threadIdx.x & 63);
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t q = (int64_t)blockIdx.x * kWavesPerBlock + wib;
-  if (q >= ws.P) return;
+  if (q >= ws.P || q == 0) return;  // partition 0 starts at a row start
   const uint32_t b = blockIdx.y;
-  const Coord c0 = ws.table[q];
-  const Coord c1 = ws.table[q + 1];
-  const int64_t R = c0.row;
-  if (R >= M || c1.row <= R) return;  // no row ends here that started earlier
-  const int64_t rs = rowptr[R];
-  if (c0.edge <= rs) return;  // row R starts in this partition: not cut
-  const int64_t deg = rowptr[R + 1] - rs;
-  // tail records of row R sit in the partitions right before q
-  int64_t run = 0;
-  for (;;) {  // 64 candidates per step: count the leading matches
-    const int64_t idx = q - 1 - run - lane;
-    const bool ok = idx >= 0 && ws.tail_row[idx] == R;
-    const unsigned long long m = __ballot(ok);
-    const int c = m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
-    run += c;
-    if (c < 64) break;
-  }
+  const int64_t R = ws.head_row[q];
+  if (R < 0) return;  // no row ends here that started earlier
 
   const A *head_val = reinterpret_cast<const A *>(ws.head_val);
   const A *tail_val = reinterpret_cast<const A *>(ws.tail_val);
   const uint64_t plane = (uint64_t)b * ws.P;
-  for (uint32_t k = lane; k < K; k += kWave) {
-    A val[1];
-    int64_t arg[1];
-    val[0] = head_val[(plane + q) * K + k];
-    arg[0] = kNoArg;
-    if constexpr (RED != RED_ADD) arg[0] = ws.head_arg[(plane + q) * K + k];
-    // A hub row is cut into hundreds of pieces; folding their fp32 partial sums in fp64 keeps the
-    // error of a long row at that of one piece (costs nothing: a few records per cut row).
-    constexpr bool kWideFold = RED == RED_ADD && std::is_same<A, float>::value;
-    double wide = kWideFold ? (double)val[0] : 0.0;
-    // the records of a hub row (hundreds of pieces) are fetched kFold at a time: the loads of a
-    // batch are independent, only the fold itself is sequential
-    constexpr int kFold = 8;
-    auto fold = [&](A v, int64_t a) {
-      if constexpr (kWideFold) {
-        wide += (double)v;
-      } else if constexpr (RED == RED_ADD) {
-        val[0] += v;
-      } else {
-        const bool better = RED == RED_MIN ? (v < val[0]) : (v > val[0]);
-        if (better || (v == val[0] && a < arg[0])) {
-          val[0] = v;
-          arg[0] = a;
+  const uint64_t hbase = (plane + (uint64_t)q) * K, tbase = (plane + (uint64_t)q - 1) * K;
+  constexpr int kCols = 2;  // feature columns per lane and step
+  A hv[kCols], tv[kCols];
+  int64_t ha[kCols], ta[kCols];
+  // min / max: the records hold the winners as offsets from their partition's first edge
+  auto widen = [](uint32_t a, int64_t first) -> int64_t { return a == kNoArg32 ? kNoArg : first + (int64_t)a; };
+  int64_t e_head = 0, e_tail = 0;
+  if constexpr (RED != RED_ADD) {
+    e_head = ws.table[q].edge;
+    e_tail = ws.table[q - 1].edge;
+  }
+  auto fetch = [&](uint32_t kb) {
+#pragma unroll
+    for (int u = 0; u < kCols; ++u) {
+      const uint32_t k = kb + (uint32_t)(u * kWave + lane);
+      hv[u] = tv[u] = A(0);
+      ha[u] = ta[u] = kNoArg;
+      if (k < K) {
+        hv[u] = head_val[hbase + k];
+        tv[u] = tail_val[tbase + k];
+        if constexpr (RED != RED_ADD) {
+          ha[u] = widen(ws.head_arg[hbase + k], e_head);
+          ta[u] = widen(ws.tail_arg[tbase + k], e_tail);
         }
       }
-    };
-    int64_t i = 0;
-    for (; i + kFold <= run; i += kFold) {  // full batches: only long (hub) rows get here
-      A v[kFold];
-      int64_t a[kFold];
+    }
+  };
+  auto pin = [&]() {  // one wait for the whole batch (and no sinking of the loads behind the run count)
 #pragma unroll
-      for (int u = 0; u < kFold; ++u) {
-        const uint64_t o = (plane + (q - 1 - i - u)) * K + k;
-        v[u] = tail_val[o];
-        a[u] = kNoArg;
-        if constexpr (RED != RED_ADD) a[u] = ws.tail_arg[o];
+    for (int u = 0; u < kCols; ++u) {
+      asm volatile("" : "+v"(hv[u]), "+v"(tv[u]));
+      if constexpr (RED != RED_ADD) asm volatile("" : "+v"(ha[u]), "+v"(ta[u]));
+    }
+  };
+
+  // ---- the one round trip ----
+  const int64_t idx0 = q - 1 - lane;
+  int64_t t_l = idx0 >= 0 ? ws.tail_row[idx0] : -1;
+  const int64_t rs = rowptr[R];
+  const int64_t deg = rowptr[R + 1] - rs;
+  fetch(0);
+  asm volatile("" : "+v"(t_l));
+  pin();
+
+  // tail records of row R sit in the partitions right before q: count the leading matches
+  int64_t run;
+  {
+    const unsigned long long m = __ballot(t_l == R);
+    run = m == ~0ull ? 64 : (int64_t)__builtin_ctzll(~m);
+  }
+  if (run == 64) {  // a hub row cut into more than 64 pieces
+    for (;;) {
+      const int64_t idx = q - 1 - run - lane;
+      const bool ok = idx >= 0 && ws.tail_row[idx] == R;
+      const unsigned long long m = __ballot(ok);
+      const int c = m == ~0ull ? 64 : (int)__builtin_ctzll(~m);
+      run += c;
+      if (c < 64) break;
+    }
+  }
+
+  for (uint32_t kb = 0;;) {
+#pragma unroll
+    for (int u = 0; u < kCols; ++u) {
+      const uint32_t k = kb + (uint32_t)(u * kWave + lane);
+      if (k >= K) continue;
+      A val[1];
+      int64_t arg[1];
+      val[0] = hv[u];
+      arg[0] = ha[u];
+      // A hub row is cut into hundreds of pieces; folding their fp32 partial sums in fp64 keeps the
+      // error of a long row at that of one piece (costs nothing: a few records per cut row).
+      constexpr bool kWideFold = RED == RED_ADD && std::is_same<A, float>::value;
+      double wide = kWideFold ? (double)val[0] : 0.0;
+      auto fold = [&](A v, int64_t a) {
+        if constexpr (kWideFold) {
+          wide += (double)v;
+        } else if constexpr (RED == RED_ADD) {
+          val[0] += v;
+        } else {
+          const bool better = RED == RED_MIN ? (v < val[0]) : (v > val[0]);
+          if (better || (v == val[0] && a < arg[0])) {
+            val[0] = v;
+            arg[0] = a;
+          }
+        }
+      };
+      if (run >= 1) fold(tv[u], ta[u]);
+      // the further records of a hub row are fetched kFold at a time: the loads of a batch are
+      // independent, only the fold itself is sequential
+      constexpr int kFold = 8;
+      int64_t i = 1;
+      for (; i + kFold <= run; i += kFold) {
+        A v[kFold];
+        int64_t a[kFold];
+#pragma unroll
+        for (int f = 0; f < kFold; ++f) {
+          const uint64_t o = (plane + (uint64_t)(q - 1 - i - f)) * K + k;
+          v[f] = tail_val[o];
+          a[f] = kNoArg;
+          if constexpr (RED != RED_ADD) a[f] = widen(ws.tail_arg[o], ws.table[q - 1 - i - f].edge);
+        }
+#pragma unroll
+        for (int f = 0; f < kFold; ++f) fold(v[f], a[f]);
       }
-#pragma unroll
-      for (int u = 0; u < kFold; ++u) fold(v[u], a[u]);
+      for (; i < run; ++i) {
+        const uint64_t o = (plane + (uint64_t)(q - 1 - i)) * K + k;
+        int64_t a = kNoArg;
+        if constexpr (RED != RED_ADD) a = widen(ws.tail_arg[o], ws.table[q - 1 - i].edge);
+        fold(tail_val[o], a);
+      }
+      if constexpr (kWideFold) val[0] = (A)wide;
+      const uint64_t o = ((uint64_t)b * M + out_position(ws, R, M)) * K + k;
+      write_row<T, 1, RED>(out + o, arg_out + o, val, arg, deg, mean, E);
     }
-    for (; i < run; ++i) {
-      const uint64_t o = (plane + (q - 1 - i)) * K + k;
-      int64_t a = kNoArg;
-      if constexpr (RED != RED_ADD) a = ws.tail_arg[o];
-      fold(tail_val[o], a);
-    }
-    if constexpr (kWideFold) val[0] = (A)wide;
-    const uint64_t o = ((uint64_t)b * M + out_position(ws, R, M)) * K + k;
-    write_row<T, 1, RED>(out + o, arg_out + o, val, arg, deg, mean, E);
+    kb += (uint32_t)(kCols * kWave);
+    if (kb >= K) break;
+    fetch(kb);
+    pin();
   }
 }
 
@@ -965,11 +1030,19 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.tail_row = reinterpret_cast<int64_t *>(take(sizeof(int64_t) * P));
   w.head_val = take(acc_size(dtype) * plane);
   w.tail_val = take(acc_size(dtype) * plane);
-  w.head_arg = reinterpret_cast<int64_t *>(minmax ? take(sizeof(int64_t) * plane) : nullptr);
-  w.tail_arg = reinterpret_cast<int64_t *>(minmax ? take(sizeof(int64_t) * plane) : nullptr);
+  w.head_arg = reinterpret_cast<uint32_t *>(minmax ? take(sizeof(uint32_t) * plane) : nullptr);
+  w.tail_arg = reinterpret_cast<uint32_t *>(minmax ? take(sizeof(uint32_t) * plane) : nullptr);
   w.relabel_mode = 0;
   w.relabel_flag = reinterpret_cast<int *>(take(256));
+  if (const char *env = getenv("TSAMD_SPMM_XPERM_PAD")) {  // experiments: shift the copy of X
+    const long v = atol(env);
+    if (v > 0 && v <= (64l << 20)) (void)take((size_t)v);
+  }
   w.xperm = (!relabelled && relabel_possible(dtype, reduce, N, K, E)) ? take(dtype_size(dtype) * (size_t)B * N * K) : nullptr;
+  // (carved behind the copy of X: the position of that copy relative to the start of the workspace decides which
+  // of its hot rows share a memory channel -- 3-5 % of the north-star kernel either way, measured by padding --
+  // and the layout in front of it is the one the round-2/3 numbers were taken with)
+  w.head_row = reinterpret_cast<int64_t *>(take(sizeof(int64_t) * P));
   w.hash_bits = 1;
   while (w.hash_bits < 32 && ((uint64_t)1 << w.hash_bits) < (uint64_t)(N > 1 ? N : 2)) ++w.hash_bits;
   w.hash_mul = 0x9E3779B1u;  // odd (golden-ratio) multiplier
