@@ -82,7 +82,7 @@ L += ['', 'Dominant kernel `spmm_merge_kernel<float, 4, ADD>`: rocprofv3 average
           b['control']['ms'], b['control']['balg_over_peak'], b['cpu_baseline']['cores'], b['cpu_baseline']['ms']),
       '* secondary rows (all `parity.ok` = %s):' % all(s.get('parity', {}).get('ok') for s in b['secondary']), '']
 for s in b['secondary']:
-    keys = [k for k in s if k.endswith('_ms') or k == 'ms']
+    keys = [k for k in s if k.endswith('_ms') or k == 'ms' or k.endswith('_back_to_back')]
     extra = ''
     if s.get('reference_gpu_route', {}).get('ms'):
         extra = '; reference GPU route (hipSPARSE) %.2f ms' % s['reference_gpu_route']['ms']
