@@ -26,10 +26,13 @@
 //        * a row that ends inside the piece is reduced across groups
 //          (bpermute butterfly) and stored once; the pieces of a row that is
 //          cut by a partition boundary go to carry records (accumulator
-//          precision, plus the arg for min/max);
+//          precision, plus the winner's offset in the partition for min/max);
+//          the wave also leaves the ids of its unfinished last row and of a
+//          cut first row that ended in it (tail_row / head_row);
 //   3. spmm_fixup_kernel       the wave of the partition in which a cut row
-//        ends folds that row's carry records (ties -> smaller edge id) and
-//        writes the final value (mean divide / empty handling happen here).
+//        ends (head_row) folds that row's carry records (ties -> smaller edge
+//        id) and writes the final value (mean divide / empty handling happen
+//        here); everything it needs is fetched in one round trip.
 //
 // Deterministic: the partition only depends on rowptr, every combine order is fixed.
 #include "common.h"
