@@ -341,6 +341,33 @@ __device__ __forceinline__ void accumulate_window(
       else add_masked(std::false_type{});
       continue;
     }
+    if constexpr (RED != RED_ADD) {
+      // Slots past `hi` re-read the row's last entry: min / max are idempotent, the duplicate carries the same
+      // (value, edge id) as the original, so nothing has to be masked (strict compares: an equal candidate with
+      // a larger or equal id never replaces).  Without values the candidate is the stored element itself: no
+      // product, no rounding -- as a wave-uniform branch, not a select: the 2-byte instantiations are bound by
+      // VALU issue (84 % of the pipe at config 3, SQ counters), and `has_value ? round(w * x) : x` per element
+      // was a third of their instructions.
+      auto fold = [&](auto with_value) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const A xv = Traits<T>::to_acc(x[u].v[j]);
+            A p = xv;
+            if constexpr (decltype(with_value)::value) p = Traits<T>::round_acc(w[u] * xv);
+            const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
+            val[j] = better ? p : val[j];
+#if !defined(TSAMD_EXP_NO_ARG_TRACK)
+            arg[j] = better ? wrel + (uint32_t)idx[u] : arg[j];
+#endif
+          }
+        }
+      };
+      if (has_value) fold(std::true_type{});  // wave-uniform
+      else fold(std::false_type{});
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const bool ok = idx[u] < hi;
@@ -350,20 +377,9 @@ __device__ __forceinline__ void accumulate_window(
         if constexpr (RED == RED_ADD && MASKED) {
           const A p = Traits<T>::round_acc(w[u] * xv);
           val[j] += (ok && ((mb[u] >> (mask_shift + (uint32_t)j)) & 1u)) ? p : A(0);
-        } else if constexpr (RED == RED_ADD) {
+        } else {
           const A p = w[u] * xv;
           val[j] += ok ? p : A(0);
-        } else {
-          // Slots past `hi` re-read the row's last entry: min / max are idempotent, the duplicate
-          // carries the same (value, edge id) as the original, so nothing has to be masked
-          // (strict compares: an equal candidate with a larger or equal id never replaces).
-          // without values the candidate is the stored element itself (no product to round)
-          const A p = has_value ? Traits<T>::round_acc(w[u] * xv) : xv;
-          const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
-          val[j] = better ? p : val[j];
-#if !defined(TSAMD_EXP_NO_ARG_TRACK)
-          arg[j] = better ? wrel + (uint32_t)idx[u] : arg[j];
-#endif
         }
       }
     }

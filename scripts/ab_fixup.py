@@ -12,15 +12,18 @@ out = {}
 import os
 only = os.environ.get('AB_SHAPES')
 for name, scale, dtype, F, red in (('ns_sum_f32_128', 21, torch.float32, 128, 'sum'), ('c2_sum_f32_64', 20, torch.float32, 64, 'sum'),
-                                   ('c3_max_bf16_128', 20, torch.bfloat16, 128, 'max'), ('c5_sum_f32_256', 20, torch.float32, 256, 'sum')):
+                                   ('c3_max_bf16_128', 20, torch.bfloat16, 128, 'max'), ('c5_sum_f32_256', 20, torch.float32, 256, 'sum'),
+                                   ('c3v_max_bf16_128', 20, torch.bfloat16, 128, 'max'), ('f16_min_f16_64', 20, torch.float16, 64, 'min'),
+                                   ('nsmax_max_f32_128', 21, torch.float32, 128, 'max')):
     if only and name.split('_')[0] not in only.split(','): continue
     rp, c = synth.rmat_csr(scale, 20, seed=0, device=dev); n = 1 << scale
     x = synth.features(n, F, dtype=dtype, device=dev)
-    for _ in range(3): nat.spmm(rp, c, None, x, red)
+    v = synth.values(c.numel(), dtype=dtype, device=dev) if name.startswith('c3v') else None
+    for _ in range(3): nat.spmm(rp, c, v, x, red)
     rows = []
     for _ in range(15):
         prof = []
-        nat.spmm(rp, c, None, x, red, profile=prof)
+        nat.spmm(rp, c, v, x, red, profile=prof)
         rows.append(prof)
     med = [sorted(r[i] for r in rows)[7] for i in range(3)]
     out[name] = [round(m, 4) for m in med] + [round(sum(med), 4)]
