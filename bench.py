@@ -137,6 +137,7 @@ def secondary(dev, cpu=True):
     res = []
     for fn in (lambda: bc.run_c1(dev, cpu=cpu), lambda: bc.run_c2(dev, cpu=cpu), lambda: bc.run_c2_backward(dev, cpu=cpu),
                lambda: bc.run_c3(dev, False, cpu=cpu), lambda: bc.run_c3(dev, True, cpu=cpu),
+               lambda: bc.run_c5_share(dev, cpu=cpu),
                lambda: bc.run_construct(dev, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu),
                lambda: bc.run_spspmm(dev, 'stress', cpu=False, iters=3)):  # SURVEY 8d stress row: property checks
         try:
@@ -190,6 +191,30 @@ def control_graph(m, deg, F, dev, nat):
                 gedges_per_s=round(c.numel() / ms / 1e6, 3), balg_over_peak=round(ba / ms / 1e6 / HBM_PEAK_GBS, 4))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE in the environment): re-run this command under
+    torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 at a free port; rank 0's JSON line is the only
+    thing on stdout.  On a box with fewer than N GPUs the ranks share devices and talk over gloo -- a REHEARSAL of
+    the control flow that the line's `data` field flags as not a measurement (TSAMD_BENCH_BACKEND=gloo, which can
+    also be set by hand)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n)))
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and 'TSAMD_BENCH_BACKEND' not in env:
+        print('[bench] %d GPU(s) visible, %d ranks asked for: rehearsal over gloo, ranks share devices' % (have, n),
+              file=sys.stderr)
+        env['TSAMD_BENCH_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -204,12 +229,15 @@ def main():
     ap.add_argument('--headline-only', action='store_true',
                     help='only the timed north-star steps + the roofline launches (for rocprofv3: every launch of the '
                          'dominant kernel in the trace is then the headline workload)')
-    ap.add_argument('--exchange', default='allgather', choices=['pipelined', 'halo', 'allgather'],
+    ap.add_argument('--exchange', default='allgather', choices=['pipelined', 'halo', 'allgather', 'allgather_serial'],
                     help='N > 1, the exchange of the HEADLINE step: allgather (default: the north star names the RCCL '
-                         'all-gather of X) | halo = all_to_all of the referenced rows only | pipelined = halo exchange in '
-                         'row pieces, overlapped with the SpMM of the previous piece.  The other two are timed beside it '
-                         '(exchange_variants_ms_per_step)')
+                         'all-gather of X; sent in the camping-free row order in --ag-chunks collectives, each overlapped '
+                         'with the partial product of the column block that landed before, SURVEY 8e) | allgather_serial = '
+                         'one all-gather, then the drop-in op | halo = all_to_all of the referenced rows only | pipelined = '
+                         'halo exchange in row pieces, overlapped with the SpMM of the previous piece.  The others are '
+                         'timed beside it (exchange_variants_ms_per_step)')
     ap.add_argument('--chunks', type=int, default=8, help='row pieces of the pipelined exchange')
+    ap.add_argument('--ag-chunks', type=int, default=4, help='collectives (row chunks of every shard) of the overlapped all-gather')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak (default): every rank owns 2**scale rows; strong: the single-GPU matrix is cut '
                          'into N row blocks of equal nnz')
@@ -220,7 +248,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world == 1:
-        sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+        sys.exit(self_launch(args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists)'
     # TSAMD_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
     # (ranks share devices, collectives go through gloo) -- a functional check, never a measurement
@@ -250,8 +278,8 @@ def main():
     value = synth.values(E, seed=1 + rank, device=dev)
     x_local = synth.features(m_local, F, seed=2 + rank, device=dev)
     import pytorch_sparse_amd  # noqa: F401  (registers torch.ops.torch_sparse.*)
-    from pytorch_sparse_amd.parallel import (HaloShardedSpMM, RowShardedSpMM, build_with_fallback,
-                                             exchange_breakdown)
+    from pytorch_sparse_amd.parallel import (HaloShardedSpMM, OverlappedAllGatherSpMM, RowShardedSpMM,
+                                             build_with_fallback, exchange_breakdown)
 
     def op_spmm(rp, c, v, x, reduce):
         # the drop-in path: the reference's own operator names, served by the HIP kernels
@@ -268,14 +296,14 @@ def main():
     requested = args.exchange
     sharded, args.exchange, fallback_reason = build_with_fallback(
         rowptr, col, value, x_sizes, x_local, args.reduce, op_spmm, requested, chunks=args.chunks,
-        sync=torch.cuda.synchronize)
+        sync=torch.cuda.synchronize, ag_chunks=args.ag_chunks)
     comm_rows = getattr(sharded, 'n_needed', n_global) if world > 1 else 0
 
     from pytorch_sparse_amd.parallel import PipelinedHaloSpMM as _Pipelined
 
     def run_op(op):
         # inference steps: the pipelined plan is told so (otherwise it agrees on the path with one all_reduce per call)
-        if isinstance(op, _Pipelined):
+        if isinstance(op, (_Pipelined, OverlappedAllGatherSpMM)):
             return op(x_local, args.reduce, differentiable=False)
         return op(x_local, args.reduce)
 
@@ -284,17 +312,17 @@ def main():
             return run_op(sharded)  # (RCCL exchange of X rows,) then the local SpMM
 
     # operands of ONE local SpMM launch, for the roofline / parity / cpu-baseline legs below
-    if isinstance(sharded, RowShardedSpMM):
-        x_full, col_k = sharded.gather(x_local), sharded.col
+    if isinstance(sharded, (RowShardedSpMM, OverlappedAllGatherSpMM)):
+        x_full, col_k = RowShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm).gather(x_local), col
     elif isinstance(sharded, HaloShardedSpMM):
         x_full, col_k = sharded.exchange(x_local), sharded.col
     else:  # pipelined: reproduce the full block with a one-shot halo plan (setup only)
         ref_plan = HaloShardedSpMM(rowptr, col, value, x_sizes, None, op_spmm)
         x_full, col_k = ref_plan.exchange(x_local), ref_plan.col
 
-    # The headline steps run with the operand cache OFF: every step does all of its work (probe, relabelled copy
-    # of X, partition, merge, fix-up), as if X were new each time.  What a caller sees who multiplies by the SAME X
-    # again (the cache's default-on behaviour) is measured separately below (`repeated_operand`).
+    # The headline steps run with the operand cache OFF (the ops' default: they keep no state between calls): every
+    # step does all of its work (probe, relabelled copy of X, partition, merge, fix-up).  What a caller sees who
+    # OPTS IN to the cache and multiplies by the same X again is measured separately below (`repeated_operand`).
     torch.ops.tsamd.operand_cache(False)
     for _ in range(args.warmup):
         step()
@@ -311,8 +339,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # N = 1: the same steps with the operand cache ON (default behaviour of the ops): the second and later calls
-    # with an unchanged X find its relabelled copy (tsamd_spmm_cached) -- bit-identical output
+    # N = 1: the same steps with the operand cache opted IN (torch.ops.tsamd.operand_cache(True)): the second and
+    # later calls with an unchanged X find its relabelled copy (tsamd_spmm_cached) -- bit-identical output
     repeated = None
     if world == 1:
         torch.ops.tsamd.operand_cache(True)
@@ -330,20 +358,50 @@ def main():
         _, hits, fills = torch.ops.tsamd.operand_cache(True)
         repeated = dict(ms_per_step=round(ms_rep, 4), gedges_per_s=round(E / ms_rep / 1e6, 3), hits=int(hits), fills=int(fills),
                         bit_identical_to_headline=same,
-                        note='operand cache on (the default of torch.ops.torch_sparse.spmm_*): calls after the first with the '
-                             'same X (same storage, version counter, shape, stream, pattern; sampled fingerprint re-checked '
-                             'on the device) skip spmm_probe_kernel and spmm_permute_rows_kernel.  NOT the headline: the '
-                             'headline steps above run with the cache off')
-    torch.ops.tsamd.operand_cache(True)
+                        note='OPT-IN operand cache (torch.ops.tsamd.operand_cache(True); off by default since a sparse write '
+                             'through x.data is invisible to it): calls after the first with the same X (same storage, version '
+                             'counter, shape, stream, pattern; sampled fingerprint re-checked on the device) skip '
+                             'spmm_probe_kernel and spmm_permute_rows_kernel.  NOT the headline: the headline steps above run '
+                             'with the cache off')
+    torch.ops.tsamd.operand_cache(False)
 
     # N > 1: the exchange alone and the local SpMM alone, timed after the headline region, next to the
     # xGMI model of the exchange
     exchange_info = None
     if world > 1:
+        staged = isinstance(sharded, OverlappedAllGatherSpMM)
+        if staged:  # the compute of the overlapped step alone: the column-block stages on buffers that have landed
+            x_pad = sharded.wire_order(x_local)
+            landed = sharded.gather_all(x_local)
+            spmm_alone = lambda: sharded.multiply_landed(x_pad, landed, args.reduce)  # noqa: E731
+        else:
+            spmm_alone = lambda: op_spmm(rowptr, col_k, value, x_full, args.reduce)  # noqa: E731
         exchange_info = exchange_breakdown(
-            sharded, None if isinstance(sharded, (RowShardedSpMM, HaloShardedSpMM)) else ref_plan, x_local,
-            lambda: op_spmm(rowptr, col_k, value, x_full, args.reduce), n_global, F * 4,
-            reps=max(3, min(args.steps, 10)), sync=torch.cuda.synchronize)
+            sharded, None if isinstance(sharded, (RowShardedSpMM, HaloShardedSpMM, OverlappedAllGatherSpMM)) else ref_plan,
+            x_local, spmm_alone, n_global, F * 4, reps=max(3, min(args.steps, 10)), sync=torch.cuda.synchronize)
+        if staged:
+            # parity of the overlapped step against the serial one (one all-gather, then the drop-in op) on this rank
+            serial = op_spmm(rowptr, col, value, x_full, args.reduce)
+            l1 = op_spmm(rowptr, col, value.abs(), x_full.abs(), 'sum') if args.reduce in ('sum', 'mean') else None
+            if l1 is not None:
+                worst = float(((out.double() - serial.double()).abs() / l1.double().clamp(min=1e-30)).max()) / \
+                    (1.0 if args.reduce == 'sum' else 1.0)
+                okp = worst <= 1e-5 if args.reduce == 'sum' else bool(torch.allclose(out, serial, rtol=1e-5, atol=1e-5))
+            else:
+                worst = float((out != serial).sum())
+                okp = worst == 0
+            flag = torch.tensor([0.0 if okp else 1.0, worst], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            exchange_info['overlap'] = dict(
+                chunks=args.ag_chunks, stages=len(sharded.stages), rows_per_chunk=sharded.cs,
+                staged_spmm_only_ms=exchange_info['spmm_only_ms'],
+                parity_vs_serial=dict(ok=bool(float(flag[0]) == 0.0), worst=float(flag[1]),
+                                      criterion='sum: |staged - serial| <= 1e-5 * sum_e|v_e x_e| for every element of every '
+                                                'rank; min / max: bit-identical'),
+                note='all-gather of X in %d collectives of rows in the camping-free wire order; the partial product of '
+                     'the columns a collective delivered runs while the next one is in flight (tsamd_spmm_partial), the '
+                     'rank\'s own column block first; exposed_ms = step - staged_spmm_only_ms' % args.ag_chunks)
+            del serial, l1, landed, x_pad
 
     # N > 1: the same step with each of the three exchanges (the north star names the all-gather; the
     # halo variants move only the referenced rows), a few steps each, max over ranks
@@ -351,12 +409,14 @@ def main():
     if world > 1:
         variants = {}
         from pytorch_sparse_amd.parallel import EXCHANGES, PipelinedHaloSpMM
-        for mode in ('allgather', 'halo', 'pipelined'):
+        for mode in ('allgather', 'allgather_serial', 'halo', 'pipelined'):
             try:
                 if mode == args.exchange:
                     op_v = sharded
                 else:
                     kw = dict(chunks=args.chunks) if EXCHANGES[mode] is PipelinedHaloSpMM else {}
+                    if EXCHANGES[mode] is OverlappedAllGatherSpMM:
+                        kw = dict(chunks=args.ag_chunks)
                     op_v = EXCHANGES[mode](rowptr, col, value, x_sizes, None, op_spmm, **kw)
                 reps = max(3, min(args.steps, 10))
                 with torch.no_grad():
@@ -439,9 +499,10 @@ def main():
                     config=dict(workload=wl['desc'], reduce=args.reduce, rows_per_gpu=m_local,
                                 cols=n_global, edges_per_gpu=E, features=F,
                                 graph='R-MAT(0.57,0.19,0.19,0.05) scale %d edge factor %d, coalesced' % (scale, ef),
-                                parallelism='row-sharded x%d%s' % (world, (', RCCL %s of X rows (%d rows in per rank)' % ({'halo': 'all_to_all', 'pipelined': 'all_to_all in %d overlapped pieces' % args.chunks, 'allgather': 'all_gather'}[args.exchange], comm_rows)) if world > 1 else '')),
+                                parallelism='row-sharded x%d%s' % (world, (', RCCL %s of X rows (%d rows in per rank)' % ({'halo': 'all_to_all', 'pipelined': 'all_to_all in %d overlapped pieces' % args.chunks, 'allgather': 'all_gather in %d chunks overlapped with column-block partial products' % args.ag_chunks, 'allgather_serial': 'all_gather, then SpMM'}[args.exchange], comm_rows)) if world > 1 else '')),
                     roofline=roofline)
         if exchange_info is not None:
+            exchange_info['exposed_ms'] = round(max(0.0, ms_per_step - exchange_info['spmm_only_ms']), 3)
             line['exchange'] = exchange_info
             # the N = 1 default of this script is ANOTHER workload (ns); the single-GPU rate of THIS workload -- the
             # reference point of a weak-scaling efficiency -- is the local SpMM without the exchange:

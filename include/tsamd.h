@@ -101,6 +101,33 @@ int tsamd_spmm_permuted(int dtype, int reduce, const int64_t *rowptr, const int6
                         int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Partial product of ONE COLUMN BLOCK of a matrix, combined into the result of the blocks before it -- the
+ * building block of the overlapped all-gather of the row-sharded SpMM (pytorch_sparse_amd/parallel.py, SURVEY.md
+ * section 8e: "pre-split each rank's CSR into column blocks by owner, run block p's partial SpMM as soon as
+ * shard p lands"; the reference has no distributed code, its slicing primitives are torch_sparse/narrow.py:15-42
+ * and cat.py:60-114).  (rowptr, col, value) is the CSR of the block's entries only (col = positions in `mat`,
+ * the buffer the block's rows of X landed in).  Never copies `mat` (no relabelling), otherwise the kernels of
+ * tsamd_spmm.
+ *   accumulate = 0   first block: out / arg_out are overwritten;
+ *   accumulate = 1   out / arg_out hold the result of the earlier blocks:
+ *       SUM       out += block product (accumulator precision, one rounding per block for f16 / bf16);
+ *       MEAN      out = (out + block product) / max(deg_rowptr[m + 1] - deg_rowptr[m], 1): pass SUM for every block
+ *                 but the last and MEAN with the WHOLE matrix's rowptr (deg_rowptr, required) for the last one;
+ *       MIN/MAX   (out, arg_out) = better of the two, ties to the smaller entry id -- the first occurrence in
+ *                 the whole row, as csrc/cpu/reducer.h:63-67 -- whatever order the blocks come in.
+ *   arg_map  [E] block entry -> entry id of the whole matrix (NULL: identity), reported in arg_out;
+ *   arg_none the whole matrix's "no winner" id (its number of entries): rows without entries so far hold
+ *            (0, arg_none), rows whose entries so far all lost against the init value (NaN only) hold
+ *            (init, arg_none) -- the same final states as tsamd_spmm.
+ * After the last block out / arg_out equal tsamd_spmm on the whole matrix: exactly for MIN / MAX, up to the
+ * association of the partial sums for SUM / MEAN.  Workspace: tsamd_spmm_partial_workspace_bytes. */
+size_t tsamd_spmm_partial_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,
+                                          int64_t E);
+int tsamd_spmm_partial(int dtype, int reduce, const int64_t *rowptr, const int64_t *col, const void *value,
+                       const void *mat, void *out, int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K,
+                       int64_t E, const int64_t *arg_map, int64_t arg_none, int accumulate,
+                       const int64_t *deg_rowptr, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Operand cache.  On Kronecker-like graphs tsamd_spmm copies `mat` to hashed row positions before the
  * gather (channel camping, see below) -- 15 % of a north-star call.  A caller that multiplies by the SAME
  * dense operand again (inference with fixed features, the first layer of every training epoch) can keep

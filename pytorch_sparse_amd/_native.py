@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get('TSAMD_LIB') or os.path.join(_HERE, 'lib', 'libtsamd.s
 SYMBOLS = [
     'tsamd_hip_version', 'tsamd_last_hip_error', 'tsamd_status_string',
     'tsamd_spmm_workspace_bytes', 'tsamd_spmm', 'tsamd_spmm_permuted', 'tsamd_spmm_profiled',
+    'tsamd_spmm_partial_workspace_bytes', 'tsamd_spmm_partial',
     'tsamd_spmm_operand_cache_bytes', 'tsamd_spmm_cached_workspace_bytes', 'tsamd_spmm_cached',
     'tsamd_gather_rows', 'tsamd_relabel_ids', 'tsamd_spmm_relabelled_workspace_bytes', 'tsamd_spmm_relabelled',
     'tsamd_spmm_value_bw',
@@ -62,6 +63,7 @@ def lib():
         L.tsamd_hip_version.restype = ctypes.c_int64
         L.tsamd_status_string.restype = ctypes.c_char_p
         L.tsamd_spmm_workspace_bytes.restype = ctypes.c_size_t
+        L.tsamd_spmm_partial_workspace_bytes.restype = ctypes.c_size_t
         L.tsamd_spmm_minmax_bw_workspace_bytes.restype = ctypes.c_size_t
         L.tsamd_spmm_minmax_bw_csc_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
@@ -144,6 +146,36 @@ def spmm(rowptr, col, value, mat, reduce, out=None, profile=None):
             profile[:] = [float(ms[0]), float(ms[1]), float(ms[2])]
     check(st, 'tsamd_spmm')
     return out, arg
+
+
+def spmm_partial(rowptr, col, value, mat, reduce, out, arg_out=None, arg_map=None, arg_none=0, accumulate=True,
+                 deg_rowptr=None):
+    """C-ABI ``tsamd_spmm_partial``: the product of one column block combined into ``out`` / ``arg_out`` in place
+    (``accumulate=False``: the first block overwrites them).  mat: [N, K] or [B, N, K] contiguous."""
+    require_gpu(rowptr, col, value, mat, out, arg_out, arg_map, deg_rowptr)
+    red = REDUCES[reduce]
+    dt = dtype_code(mat.dtype)
+    if value is not None and value.dtype != mat.dtype:
+        raise TsamdError('expected scalar type %s but found %s' % (mat.dtype, value.dtype))
+    if not (mat.is_contiguous() and out.is_contiguous() and (arg_out is None or arg_out.is_contiguous())):
+        raise TsamdError('tsamd_spmm_partial works in place: mat / out / arg_out must be contiguous')
+    if out.dtype != mat.dtype or (red >= 2 and (arg_out is None or arg_out.dtype != torch.int64)):
+        raise TsamdError('Input mismatch: out / arg_out')
+    M, E = rowptr.numel() - 1, col.numel()
+    N, K = mat.size(-2), mat.size(-1)
+    B = mat.numel() // max(N * K, 1) if N * K > 0 else 1
+    if out.numel() != B * M * K or (arg_out is not None and arg_out.numel() != out.numel()):
+        raise TsamdError('Input mismatch: out must be [B, M, K]')
+    L = lib()
+    nb = L.tsamd_spmm_partial_workspace_bytes(dt, red, _i64(B), _i64(M), _i64(N), _i64(K), _i64(E))
+    ws = workspace(nb, mat.device)
+    with torch.cuda.device(mat.device):
+        st = L.tsamd_spmm_partial(dt, red, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(out), _ptr(arg_out),
+                                  _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(arg_map), _i64(arg_none),
+                                  ctypes.c_int(1 if accumulate else 0), _ptr(deg_rowptr), _ptr(ws),
+                                  ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
+    check(st, 'tsamd_spmm_partial')
+    return out, arg_out
 
 
 def spmm_value_bw(row, rowptr, col, mat, grad, reduce):

@@ -23,9 +23,11 @@ LIBDIR = os.path.join(PKG, 'lib')
 OBJDIR = os.path.join(ROOT, 'build', 'obj')
 ARCH = 'gfx950'
 
-HIP_SOURCES = ['api.hip', 'spmm.hip', 'spmm_bw.hip', 'convert.hip', 'scan.hip', 'sort.hip',
+HIP_SOURCES = ['api.hip', 'spmm.hip', 'spmm_partial.hip', 'spmm_bw.hip', 'convert.hip', 'scan.hip', 'sort.hip',
                'coalesce.hip', 'spspmm.hip', 'select.hip', 'sample.hip', 'segreduce.hip']
 OPS_SOURCES = ['ops_spmm.cpp', 'ops_storage.cpp', 'ops_sample.cpp']
+# translation units that #include another .hip file (rebuilt when that one changes)
+HIP_INCLUDES = {'spmm_partial.hip': ['spmm.hip']}
 
 
 def _hipcc():
@@ -77,7 +79,8 @@ def build_kernels(verbose=True, force=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src + '.o')
         objs.append(o)
-        if force or _newer(o, [s] + headers):
+        deps = [s] + headers + [os.path.join(CSRC, d) for d in HIP_INCLUDES.get(src, [])]
+        if force or _newer(o, deps):
             jobs.append([hipcc] + flags + ['-c', s, '-o', o])
     if jobs:
         if verbose:

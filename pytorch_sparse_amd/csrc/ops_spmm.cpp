@@ -34,15 +34,21 @@ bool stream_is_capturing(void *stream) {
 // operand is provably the same tensor contents as far as torch can tell -- same storage object (held weakly:
 // while it is alive its address cannot be handed to another tensor), same data pointer, same version
 // counter, same shape / dtype / device / stream, same sparse pattern (col pointer and length) and reduction
-// class -- and the kernel side re-checks a sampled fingerprint on the device.  TSAMD_OPERAND_CACHE=0 or
-// torch.ops.tsamd.operand_cache(False) turns it off; inference tensors (no version counter) never use it.
+// class -- and the kernel side re-checks a sampled fingerprint on the device.
+//
+// OPT-IN (off by default): the reference boundary keeps no state between calls (csrc/cuda/spmm_cuda.cu:102,134
+// allocate fresh outputs, nothing else survives), and neither the version counter nor a SAMPLED fingerprint can
+// see a sparse write that bypasses autograd's bookkeeping (`x.data[i] = ...`, a DLPack / raw-pointer writer, a
+// collective landing in a persistent buffer): with the cache on such a write returns a stale product.  A caller
+// that knows its operand is only ever updated through torch (or densely) turns it on with
+// torch.ops.tsamd.operand_cache(True) or TSAMD_OPERAND_CACHE=1; inference tensors (no version counter) never use it.
 struct OperandCache {
   std::mutex mu;
-  bool enabled = true;
+  bool enabled = false;
   c10::weak_intrusive_ptr<c10::StorageImpl> storage{c10::weak_intrusive_ptr<c10::StorageImpl>(
       c10::make_intrusive<c10::StorageImpl>(c10::StorageImpl::use_byte_size_t(), 0, c10::DataPtr(), nullptr, false))};
   const void *ptr = nullptr, *col_ptr = nullptr;
-  uint32_t version = 0;
+  uint32_t version = 0, col_version = 0;
   std::vector<int64_t> sizes;
   int dtype = -1, red_class = -1, device = -1;
   int64_t E = -1;
@@ -55,7 +61,7 @@ OperandCache &operand_cache_state() {
   static OperandCache c;
   static bool init = [] {
     const char *env = getenv("TSAMD_OPERAND_CACHE");
-    if (env != nullptr && env[0] == '0') c.enabled = false;
+    if (env != nullptr) c.enabled = env[0] == '1';
     return true;
   }();
   (void)init;
@@ -81,6 +87,11 @@ std::vector<int64_t> operand_cache_ctl(bool enable) {
 // later backward reads them sequentially; the stream is part of the key (a backward on another stream starts a
 // new entry instead of reading arrays whose producer it is not ordered after).  TSAMD_PATTERN_CACHE=0 turns it off (then, and for a pattern seen
 // for the first time in a no-reuse setting, the kernel reads (row, value) through csr2csc -- tsamd_spmm_permuted).
+//
+// Only the `tsamd::spmm_sum_owned` / `tsamd::spmm_mean_owned` ops consult it -- the ones SparseTensor.matmul
+// calls with arrays that its SparseStorage owns (immutable by the storage's contract, exactly like the
+// reference's own storage-level caches rowcount / colptr / csr2csc).  The bare reference ops
+// `torch_sparse::spmm_sum / spmm_mean` keep NO state between calls.
 struct PatternCache {
   std::mutex mu;
   bool enabled = true;
@@ -305,13 +316,14 @@ std::tuple<Tensor, OptTensor> spmm_fw_cached(const Tensor &rowptr, const Tensor 
   void *stream = current_stream(mat_in);
   c10::StorageImpl *simpl = mat_in.storage().unsafeGetStorageImpl();
   const uint32_t version = mat_in.unsafeGetTensorImpl()->version_counter().current_version();
+  const uint32_t col_version = col.is_inference() ? 0u : col.unsafeGetTensorImpl()->version_counter().current_version();
   const int red_class = (red == TSAMD_MIN || red == TSAMD_MAX) ? 1 : 0;
 
   std::lock_guard<std::mutex> lock(oc.mu);
   bool valid = false;
   if (oc.buf.defined() && oc.ptr == mat_in.data_ptr() && oc.version == version && oc.dtype == dt &&
       oc.red_class == red_class && oc.device == mat_in.get_device() && oc.stream == stream &&
-      oc.col_ptr == col.data_ptr() && oc.E == E && oc.sizes == mat_in.sizes().vec() &&
+      oc.col_ptr == col.data_ptr() && oc.col_version == col_version && oc.E == E && oc.sizes == mat_in.sizes().vec() &&
       (size_t)oc.buf.numel() >= cache_bytes) {
     auto locked = oc.storage.lock();  // the storage the copy was made from is still alive and is this one
     valid = locked && locked.get() == simpl;
@@ -333,6 +345,7 @@ std::tuple<Tensor, OptTensor> spmm_fw_cached(const Tensor &rowptr, const Tensor 
     oc.device = mat_in.get_device();
     oc.stream = stream;
     oc.col_ptr = col.data_ptr();
+    oc.col_version = col_version;
     oc.E = E;
     oc.sizes = mat_in.sizes().vec();
     ++oc.fills;
@@ -378,7 +391,7 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
  public:
   static variable_list forward(AutogradContext *ctx, OptTensor opt_row, Tensor rowptr, Tensor col,
                                Tensor value, OptTensor opt_rowcount, OptTensor opt_colptr,
-                               OptTensor opt_csr2csc, Tensor mat, bool has_value, bool mean) {
+                               OptTensor opt_csr2csc, Tensor mat, bool has_value, bool mean, bool owned) {
     if (has_value && needs_grad(value)) TORCH_CHECK(opt_row.has_value(), "Argument `row` is missing");
     if (needs_grad(mat)) {
       TORCH_CHECK(opt_row.has_value(), "Argument `row` is missing");
@@ -390,6 +403,7 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
     Tensor out = std::get<0>(spmm_fw_cached(rowptr, col, v, mat, mean ? "mean" : "sum"));
     ctx->saved_data["has_value"] = has_value;
     ctx->saved_data["mean"] = mean;
+    ctx->saved_data["owned"] = owned;
     // absent optionals are parked as `col` (any tensor will do; they are never read then)
     ctx->save_for_backward({opt_row.value_or(col), rowptr, col, value, opt_rowcount.value_or(col),
                             opt_colptr.value_or(col), opt_csr2csc.value_or(col), mat});
@@ -399,6 +413,7 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
   static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
     const bool has_value = ctx->saved_data["has_value"].toBool();
     const bool mean = ctx->saved_data["mean"].toBool();
+    const bool owned = ctx->saved_data["owned"].toBool();
     Tensor grad_out = grad_outs[0];
     auto s = ctx->get_saved_variables();
     Tensor row = s[0], rowptr = s[1], col = s[2], value = s[3], rowcount = s[4], colptr = s[5],
@@ -414,7 +429,7 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
       if (!mean) {
         // sum: the kernel reads (row, value) THROUGH csr2csc -- no row.index_select(0, csr2csc) /
         // value.index_select(0, csr2csc) temporaries as in the reference (spmm.cpp:104-106)
-        Tensor row_t = cached_csc_rows(row, csr2csc);
+        Tensor row_t = owned ? cached_csc_rows(row, csr2csc) : Tensor();
         if (row_t.defined()) {
           // the pattern came back: its CSC row ids are at hand, only the values are gathered (one ATen gather)
           OptTensor w = has_value ? OptTensor(csc_values(value, csr2csc)) : std::nullopt;
@@ -424,7 +439,7 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
           grad_mat = std::get<0>(spmm_fw(colptr, row, w, grad_out, "sum", csr2csc));
         }
       } else {
-        Tensor row_t = cached_csc_rows(row, csr2csc);
+        Tensor row_t = owned ? cached_csc_rows(row, csr2csc) : Tensor();
         if (!row_t.defined()) row_t = row.index_select(0, csr2csc);
         Tensor cnt = rowcount.index_select(0, row_t).to(mat.scalar_type()).clamp_min_(1);
         Tensor w = has_value ? value.detach().index_select(0, csr2csc).div_(cnt) : cnt.reciprocal_();
@@ -432,7 +447,7 @@ class SpmmAddFunction : public torch::autograd::Function<SpmmAddFunction> {
       }
     }
     return {Tensor(), Tensor(), Tensor(), grad_value, Tensor(), Tensor(), Tensor(), grad_mat,
-            Tensor(), Tensor()};
+            Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -673,14 +688,30 @@ Tensor spmm_sum(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_valu
                 OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat) {
   Tensor value = opt_value.value_or(col);
   return SpmmAddFunction::apply(opt_row, rowptr, col, value, std::nullopt, opt_colptr, opt_csr2csc,
-                                mat, opt_value.has_value(), false)[0];
+                                mat, opt_value.has_value(), false, false)[0];
 }
 
 Tensor spmm_mean(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_value,
                  OptTensor opt_rowcount, OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat) {
   Tensor value = opt_value.value_or(col);
   return SpmmAddFunction::apply(opt_row, rowptr, col, value, opt_rowcount, opt_colptr, opt_csr2csc,
-                                mat, opt_value.has_value(), true)[0];
+                                mat, opt_value.has_value(), true, false)[0];
+}
+
+// The same two ops for callers whose index arrays belong to a SparseStorage (SparseTensor.matmul): the backward
+// may keep row[csr2csc] (and value[csr2csc] of non-trainable weights) across calls -- see PatternCache.
+Tensor spmm_sum_owned(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_value,
+                      OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat) {
+  Tensor value = opt_value.value_or(col);
+  return SpmmAddFunction::apply(opt_row, rowptr, col, value, std::nullopt, opt_colptr, opt_csr2csc,
+                                mat, opt_value.has_value(), false, true)[0];
+}
+
+Tensor spmm_mean_owned(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor opt_value,
+                       OptTensor opt_rowcount, OptTensor opt_colptr, OptTensor opt_csr2csc, Tensor mat) {
+  Tensor value = opt_value.value_or(col);
+  return SpmmAddFunction::apply(opt_row, rowptr, col, value, opt_rowcount, opt_colptr, opt_csr2csc,
+                                mat, opt_value.has_value(), true, true)[0];
 }
 
 std::tuple<Tensor, Tensor> spmm_min(Tensor rowptr, Tensor col, OptTensor opt_value, Tensor mat) {
@@ -731,6 +762,9 @@ Tensor ptr2ind(Tensor ptr, int64_t E) {
 
 int64_t cuda_version() { return tsamd_hip_version(); }
 
+// torch.are_deterministic_algorithms_enabled() for TorchScript callers (storage_spmm)
+bool deterministic_mode() { return at::globalContext().deterministicAlgorithms(); }
+
 
 }  // namespace
 }  // namespace tsamd_ops
@@ -746,6 +780,9 @@ static auto registry_spmm = torch::RegisterOperators()
                            .op("torch_sparse::ptr2ind", &ptr2ind)
                            .op("torch_sparse::cuda_version", &cuda_version)
                            .op("tsamd::spmm_minmax", &spmm_minmax)
+                           .op("tsamd::deterministic", &deterministic_mode)
+                           .op("tsamd::spmm_sum_owned", &spmm_sum_owned)
+                           .op("tsamd::spmm_mean_owned", &spmm_mean_owned)
                            .op("tsamd::operand_cache", &operand_cache_ctl)
                            .op("tsamd::pattern_cache", &pattern_cache_ctl)
                            .op("tsamd::relabel_ids", &relabel_ids)

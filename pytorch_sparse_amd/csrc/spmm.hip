@@ -44,6 +44,14 @@
 namespace tsamd {
 namespace {
 
+// This file is compiled twice: as itself (every entry point but tsamd_spmm_partial; kPartial = false, the kernels
+// carry no trace of the partial-product mode -- a run-time switch cost the north-star instantiation a wave per SIMD)
+// and through spmm_partial.hip (TSAMD_SPMM_PARTIAL_BUILD = 1: only tsamd_spmm_partial, floating-point types).
+#ifndef TSAMD_SPMM_PARTIAL_BUILD
+#define TSAMD_SPMM_PARTIAL_BUILD 0
+#endif
+constexpr bool kPartial = TSAMD_SPMM_PARTIAL_BUILD != 0;
+
 constexpr int RED_ADD = 0;  // sum and mean
 constexpr int RED_MIN = 1;
 constexpr int RED_MAX = 2;
@@ -110,6 +118,17 @@ struct Workspace {
   const unsigned long long *fp_stored, *fp_new;
   unsigned long long *cache_fp;  // host side: [2][kFingerprintWords] stored | new, inside the cache buffer
   int cache_state;               // host side: 0 no cache, 1 fill it, 2 reuse it if the fingerprint still matches
+  // partial product of one COLUMN BLOCK of a matrix (tsamd_spmm_partial: the stages of the overlapped all-gather,
+  // pytorch_sparse_amd/parallel.py): the CSR holds the block's entries only;
+  //   accumulate   combine with what out / arg_out hold from the earlier blocks instead of overwriting them
+  //   arg_map      min / max: block entry id -> entry id of the whole matrix (what arg_out reports; ties between
+  //                blocks go to the smaller id, i.e. to the first occurrence in the whole row as reducer.h:63-67)
+  //   arg_none     the whole matrix's "no winner" id (its E)
+  //   deg_rowptr   mean: the divisor is the length of the WHOLE row, deg_rowptr[r + 1] - deg_rowptr[r]
+  int partial, accumulate;
+  const int64_t *arg_map;
+  int64_t arg_none;
+  const int64_t *deg_rowptr;
 };
 
 // ---------------------------------------------------------------------------
@@ -438,14 +457,63 @@ __device__ __forceinline__ void nt_store(U *dst, const Pack<U, VEC> &v) {
 }
 
 // Final write of one row (reducer.h:69-83).
+// min / max row of a column-block partial product (Workspace::partial): the candidate (val, arg) of this block
+// against the (value, arg) the earlier blocks left in out / arg_out.  State between blocks: arg == arg_none means
+// "no winner so far", with value 0 (no entry seen yet) or the reduction's init value (entries seen, none beat it).
+template <typename T, int VEC, int RED>
+__device__ __forceinline__ void write_row_partial(T *__restrict__ outk, int64_t *__restrict__ argk,
+                                                  typename Traits<T>::acc_t (&val)[VEC], int64_t (&arg)[VEC],
+                                                  int64_t deg, const Workspace &ws) {
+  using A = typename Traits<T>::acc_t;
+  Pack<T, VEC> o;
+  Pack<int64_t, VEC> a;
+  if (ws.accumulate) {
+    if (deg <= 0) return;  // the block has no entry in this row: the earlier blocks' result stands
+    o = *reinterpret_cast<const Pack<T, VEC> *>(outk);
+    a = *reinterpret_cast<const Pack<int64_t, VEC> *>(argk);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    int64_t ca = arg[j];
+    if (ca == kNoArg) ca = ws.arg_none;
+    else if (ws.arg_map != nullptr) ca = ws.arg_map[ca];
+    if (!ws.accumulate) {
+      o.v[j] = Traits<T>::from_acc(deg > 0 ? val[j] : A(0));
+      a.v[j] = deg > 0 ? ca : ws.arg_none;
+    } else {
+      const A ev = Traits<T>::to_acc(o.v[j]);
+      const int64_t ea = a.v[j];
+      bool take;
+      if (ea == ws.arg_none) take = true;        // nothing won so far: (val, ca) -- or (init, none) -- stands
+      else if (ca == ws.arg_none) take = false;  // this block brought no winner
+      else take = (RED == RED_MIN ? (val[j] < ev) : (val[j] > ev)) || (val[j] == ev && ca < ea);
+      if (take) {
+        o.v[j] = Traits<T>::from_acc(val[j]);
+        a.v[j] = ca;
+      }
+    }
+  }
+  *reinterpret_cast<Pack<T, VEC> *>(outk) = o;  // plain stores: the next block reads them back
+  *reinterpret_cast<Pack<int64_t, VEC> *>(argk) = a;
+}
+
 template <typename T, int VEC, int RED>
 __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restrict__ argk,
                                           typename Traits<T>::acc_t (&val)[VEC],
                                           int64_t (&arg)[VEC], int64_t deg, bool mean,
-                                          int64_t E) {
+                                          int64_t E, const Workspace &ws) {
   using A = typename Traits<T>::acc_t;
   Pack<T, VEC> o;
+  if constexpr (kPartial && RED != RED_ADD) {
+    write_row_partial<T, VEC, RED>(outk, argk, val, arg, deg, ws);
+    return;
+  }
   if constexpr (RED == RED_ADD) {
+    if (kPartial && ws.accumulate) {  // wave-uniform: the earlier column blocks' sum
+      const Pack<T, VEC> ex = *reinterpret_cast<const Pack<T, VEC> *>(outk);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) val[j] += Traits<T>::to_acc(ex.v[j]);
+    }
     if (mean) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) val[j] = mean_of<T>(val[j], deg);
@@ -522,8 +590,10 @@ __device__ __forceinline__ void write_carry(void *cval, uint32_t *carg, uint64_t
 #ifndef TSAMD_MINMAX_WAVES
 #define TSAMD_MINMAX_WAVES 8
 #endif
+// (partial build: the sum's row sink costs 6 SGPRs -- ask for 8 waves there; the min / max sink needs the VGPRs)
 template <int RED, bool SHORT, bool MASKED>
-constexpr int kMinWavesPerEU = (RED != RED_ADD && !SHORT && !MASKED) ? TSAMD_MINMAX_WAVES : 0;
+constexpr int kMinWavesPerEU = kPartial ? ((RED == RED_ADD && !SHORT && !MASKED) ? 8 : 0)
+                                        : ((RED != RED_ADD && !SHORT && !MASKED) ? TSAMD_MINMAX_WAVES : 0);
 
 template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false>
 __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, MASKED>)) void spmm_merge_kernel(
@@ -725,7 +795,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
     if (mine && kok) {
       if constexpr (RED != RED_ADD) widen_args();
       const uint64_t o = out_b + out_position(ws, r + g, M) * K;
-      write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, (int64_t)len, mean, E);
+      int64_t deg_w = (int64_t)len;
+      if constexpr (kPartial && RED == RED_ADD) {
+        if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[r + g + 1] - ws.deg_rowptr[r + g];
+      }
+      write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, deg_w, mean, E, ws);
     }
     init_acc<T, VEC, RED>(val, arg);
     const uint32_t done_rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, j + n - 1);
@@ -782,7 +856,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
         } else {
           if constexpr (RED != RED_ADD) widen_args();
           const uint64_t o = out_b + out_position(ws, r, M) * K;
-          write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, rend - estart, mean, E);
+          int64_t deg_w = rend - estart;
+          if constexpr (kPartial && RED == RED_ADD) {
+            if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[r + 1] - ws.deg_rowptr[r];
+          }
+          write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, deg_w, mean, E, ws);
         }
       }
       init_acc<T, VEC, RED>(val, arg);
@@ -957,7 +1035,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
       }
       if constexpr (kWideFold) val[0] = (A)wide;
       const uint64_t o = ((uint64_t)b * M + out_position(ws, R, M)) * K + k;
-      write_row<T, 1, RED>(out + o, arg_out + o, val, arg, deg, mean, E);
+      int64_t deg_w = deg;
+      if constexpr (kPartial && RED == RED_ADD) {
+        if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[R + 1] - ws.deg_rowptr[R];
+      }
+      write_row<T, 1, RED>(out + o, arg_out + o, val, arg, deg_w, mean, E, ws);
     }
     kb += (uint32_t)(kCols * kWave);
     if (kb >= K) break;
@@ -1073,6 +1155,10 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.fp_stored = w.fp_new = nullptr;
   w.cache_fp = nullptr;
   w.cache_state = 0;
+  w.partial = w.accumulate = 0;
+  w.arg_map = nullptr;
+  w.arg_none = 0;
+  w.deg_rowptr = nullptr;
   w.ohash_bits = 1;
   while (w.ohash_bits < 32 && ((uint64_t)1 << w.ohash_bits) < (uint64_t)(M > 1 ? M : 2)) ++w.ohash_bits;
   w.ohash_shift = w.ohash_bits > 1 ? w.ohash_bits / 2 : 1;
@@ -1216,11 +1302,21 @@ int dispatch_spmm(int reduce, int vec, const int64_t *rowptr, const int64_t *col
 
 using namespace tsamd;
 
+#if !TSAMD_SPMM_PARTIAL_BUILD
 extern "C" size_t tsamd_spmm_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M,
                                              int64_t N, int64_t K, int64_t E) {
   if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
   return carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr);
 }
+
+#endif
+
+struct PartialOpts {  // tsamd_spmm_partial (see Workspace)
+  int accumulate;
+  const int64_t *arg_map;
+  int64_t arg_none;
+  const int64_t *deg_rowptr;
+};
 
 static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
                       const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
@@ -1228,7 +1324,7 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
                       size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev,
                       bool relabelled = false, const int64_t *perm = nullptr,
                       const uint32_t *wmask = nullptr, void *cache = nullptr, size_t cache_bytes = 0,
-                      int cache_valid = 0) {
+                      int cache_valid = 0, const PartialOpts *partial = nullptr) {
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
@@ -1242,7 +1338,7 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   const size_t cache_need = operand_cache_bytes(dtype, reduce, B, N, K, E);
   const bool use_cache = cache != nullptr && !relabelled && cache_need > 0 && cache_bytes >= cache_need &&
                          ((uintptr_t)cache % 256) == 0 && ((uintptr_t)mat % 16) == 0;
-  const bool no_xperm_in_ws = relabelled || use_cache;
+  const bool no_xperm_in_ws = relabelled || use_cache || partial != nullptr;
   const size_t need = carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr, no_xperm_in_ws);
   if (!workspace || workspace_bytes_given < need) return TSAMD_ERR_WORKSPACE;
   if ((uintptr_t)workspace % 256 != 0) return TSAMD_ERR_WORKSPACE;
@@ -1260,6 +1356,14 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
     ws.out_relabel = 1;
   }
   ws.perm = perm;
+  if (partial != nullptr) {
+    if (reduce == TSAMD_MEAN && partial->deg_rowptr == nullptr) return TSAMD_ERR_INVALID;
+    ws.partial = 1;
+    ws.accumulate = partial->accumulate ? 1 : 0;
+    ws.arg_map = partial->arg_map;
+    ws.arg_none = partial->arg_none;
+    ws.deg_rowptr = reduce == TSAMD_MEAN ? partial->deg_rowptr : nullptr;
+  }
   if (wmask != nullptr) {
     if (E >= (int64_t)1 << 32 || reduce != TSAMD_SUM) return TSAMD_ERR_UNSUPPORTED;  // 32-bit entry ids in the windows
     ws.wmask = wmask;
@@ -1273,12 +1377,23 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
                       (!minmax || ((uintptr_t)arg_out % (vec * 8)) == 0)))
     vec >>= 1;
 
+#if TSAMD_SPMM_PARTIAL_BUILD
+  // partial products are the stages of the sharded SpMM over dense FEATURE matrices: floating point only
+  if (dtype != TSAMD_F32 && dtype != TSAMD_F64 && dtype != TSAMD_F16 && dtype != TSAMD_BF16) return TSAMD_ERR_UNSUPPORTED;
+#endif
   return TSAMD_DISPATCH_DTYPE_ALL(dtype, [&]() -> int {
+#if TSAMD_SPMM_PARTIAL_BUILD
+    if constexpr (!(std::is_same<scalar_t, float>::value || std::is_same<scalar_t, double>::value ||
+                    std::is_same<scalar_t, f16_t>::value || std::is_same<scalar_t, bf16_t>::value))
+      return (int)TSAMD_ERR_UNSUPPORTED;
+    else
+#endif
     return dispatch_spmm<scalar_t>(reduce, vec, rowptr, col, value, mat, out, arg_out, B, M, N,
                                    K, E, ws, stream, ev);
   });
 }
 
+#if !TSAMD_SPMM_PARTIAL_BUILD
 extern "C" int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
                           const void *value, const void *mat, void *out, int64_t *arg_out,
                           int64_t B, int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
@@ -1423,6 +1538,29 @@ extern "C" int tsamd_spmm_relabelled(int dtype, int reduce, const int64_t *rowpt
                     workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, true);
 }
 
+#else  // TSAMD_SPMM_PARTIAL_BUILD
+extern "C" size_t tsamd_spmm_partial_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M, int64_t N,
+                                                     int64_t K, int64_t E) {
+  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
+  return carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr, true);
+}
+
+extern "C" int tsamd_spmm_partial(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
+                                  const void *value, const void *mat, void *out, int64_t *arg_out, int64_t B,
+                                  int64_t M, int64_t N, int64_t K, int64_t E, const int64_t *arg_map,
+                                  int64_t arg_none, int accumulate, const int64_t *deg_rowptr, void *workspace,
+                                  size_t workspace_bytes_given, void *stream_) {
+  PartialOpts po{accumulate, arg_map, arg_none, deg_rowptr};
+  // E == 0 with accumulate: nothing to add; without: the "empty so far" state has to be written
+  if (accumulate && E == 0 && reduce != TSAMD_MEAN) return TSAMD_OK;
+  return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, workspace,
+                    workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, false, nullptr, nullptr,
+                    nullptr, 0, 0, &po);
+}
+
+#endif
+
+#if !TSAMD_SPMM_PARTIAL_BUILD
 extern "C" int tsamd_spmm_permuted(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
                                    const void *value, const int64_t *perm, const void *mat, void *out,
                                    int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K,
@@ -1471,3 +1609,4 @@ extern "C" int tsamd_spmm_profiled(int dtype, int reduce, const int64_t *rowptr,
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
   return st;
 }
+#endif  // !TSAMD_SPMM_PARTIAL_BUILD

@@ -4,9 +4,13 @@ The reference has no distributed code; its slicing primitive ``narrow(src, 0, st
 (torch_sparse/narrow.py:15-42) defines what a row shard is: ``rowptr[start:start+length+1] -
 rowptr[start]`` with the matching slices of ``col`` / ``value`` and *global* column ids.
 
-Path per step (BASELINE.json north_star), class ``RowShardedSpMM``:
+Path per step (BASELINE.json north_star), class ``RowShardedSpMM`` (the plain, serial form):
     X_full = all_gather(X_local)           RCCL, the only data-path collective
     out_local = A_local @ X_full           tsamd_spmm on the local row block
+``OverlappedAllGatherSpMM`` is the same all-gather hidden behind the compute: the local row block
+is pre-split into column blocks, X travels in row chunks (already in the channel-camping-free row order, so the
+gathered operand is never copied again), and the partial product of a block starts as soon as its rows landed
+(tsamd_spmm_partial accumulates into the result; the local block needs no exchange and runs first).
 ``HaloShardedSpMM`` is the same computation with the collective reduced to the rows of X the local
 block references (all_to_all_single with uneven splits, planned once per matrix).
 The output stays row-sharded, so there is no reduce step in the forward.  In the backward the
@@ -133,6 +137,234 @@ class RowShardedSpMM(object):
     def __call__(self, x_local: Tensor, reduce: str = 'sum') -> Tensor:
         """out_local [rows of this rank, F] = A_local @ all_gather(x_local)."""
         return self.spmm_fn(self.rowptr, self.col, self.value, self.gather(x_local), reduce)
+
+
+# ---------------------------------------------------------------------------------------------
+# all-gather overlapped with per-column-block partial products (SURVEY.md 8e)
+# ---------------------------------------------------------------------------------------------
+def _default_positions(n: int, device) -> Tensor:
+    """Row order of a shard on the wire: the hashed positions of the relabelled layout (a bijection of [0, n)
+    that spreads the hub rows of Kronecker-like graphs over the memory channels) on the GPU,
+    the identity elsewhere (CPU tests)."""
+    if torch.device(device).type == 'cuda':
+        like = torch.empty(0, dtype=torch.long, device=device)
+        return torch.ops.tsamd.relabel_ids(None, n, like)
+    return torch.arange(n, dtype=torch.long, device=device)
+
+
+def build_column_stages(rowptr: Tensor, col: Tensor, x_sizes: Sequence[int], rank: int, chunks: int,
+                        positions: Optional[Sequence[Tensor]] = None):
+    """Split a local row block (global column ids) into the column blocks of the overlapped all-gather.
+
+    Every owner p stores (and sends) its shard of X in the row order positions[p] (row i at position
+    positions[p][i]; None = identity), padded to chunks * cs rows, cs = ceil(max shard / chunks).  Collective c
+    gathers chunk c -- positions [c cs, (c + 1) cs) -- of every shard into a buffer [world * cs, K] whose row
+    p * cs + j holds position c * cs + j of owner p.
+      stage 0       the entries whose column this rank owns:   col = position in its own shard
+      stage c + 1   the entries of the other owners' chunk c:  col = row of buffer c
+    -> (cs, [dict(rowptr, col, src)]): src = ids of the stage's entries in the block's CSR (ascending: every stage
+    is a sub-sequence of every row, so "first occurrence" ties are decided by src), rowptr over ALL local rows."""
+    dev = col.device
+    world = len(x_sizes)
+    M = rowptr.numel() - 1
+    mx = max(int(v) for v in x_sizes) if world > 0 else 0
+    cs = max(1, -(-mx // max(1, chunks)))
+    bounds = torch.tensor([0] + list(torch.tensor(list(x_sizes)).cumsum(0).tolist()), dtype=torch.long, device=dev)
+    owner = torch.searchsorted(bounds, col, right=True) - 1
+    local = col - bounds[owner]
+    if positions is not None:
+        pos = torch.empty_like(local)
+        for p in range(world):
+            sel = owner == p
+            if positions[p] is not None and bool(sel.any()):
+                pos[sel] = positions[p][local[sel]]
+            else:
+                pos[sel] = local[sel]
+    else:
+        pos = local
+    chunk = torch.div(pos, cs, rounding_mode='floor')
+    row = torch.repeat_interleave(torch.arange(M, dtype=torch.long, device=dev), rowptr[1:] - rowptr[:-1])
+    stage_of = torch.where(owner == rank, torch.zeros_like(chunk), chunk + 1)
+    stage_col = torch.where(owner == rank, pos, owner * cs + (pos - chunk * cs))
+    stages = []
+    for st in range(chunks + 1):
+        src = torch.nonzero(stage_of == st).view(-1)
+        counts = torch.bincount(row[src], minlength=M) if src.numel() > 0 else torch.zeros(M, dtype=torch.long, device=dev)
+        rp = torch.zeros(M + 1, dtype=torch.long, device=dev)
+        torch.cumsum(counts, 0, out=rp[1:])
+        stages.append(dict(rowptr=rp, col=stage_col[src].contiguous(), src=src))
+    return cs, stages
+
+
+def _native_partial(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_none, accumulate, deg_rowptr):
+    from . import _native as nat
+    if value is not None and value.dtype != mat.dtype:
+        value = value.to(mat.dtype)
+    nat.spmm_partial(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_none, accumulate, deg_rowptr)
+
+
+class _ChunkedGather(torch.autograd.Function):
+    """The chunked all-gather of an ``OverlappedAllGatherSpMM`` for the training path: every chunk's collective is
+    enqueued asynchronously (the caller waits per chunk); backward = reduce-scatter of every buffer's gradient."""
+
+    @staticmethod
+    def forward(ctx, x_pad: Tensor, plan):
+        ctx.plan = plan
+        bufs = plan._start_gathers(x_pad)
+        return tuple(bufs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        cs, world, rank = plan.cs, plan.world, plan.rank
+        pieces = []
+        for g in grads:
+            g = g.contiguous()
+            if dist.get_backend(plan.group) != 'gloo':
+                o = g.new_empty((cs, ) + tuple(g.shape[1:]))
+                dist.reduce_scatter_tensor(o, g, group=plan.group)
+            else:  # gloo has no reduce_scatter
+                dist.all_reduce(g, group=plan.group)
+                o = g[rank * cs:(rank + 1) * cs].clone()
+            pieces.append(o)
+        return torch.cat(pieces, 0), None
+
+
+class OverlappedAllGatherSpMM(object):
+    """``RowShardedSpMM`` with the all-gather hidden behind the compute (BASELINE.json north_star:
+    "RCCL all-gather of the dense features over xGMI before SpMM").
+
+    Setup (once per matrix): the local row block is split into ``chunks + 1`` column blocks
+    (``build_column_stages``) and every rank agrees on the row order of the shards on the wire -- the hashed
+    positions of the relabelled layout, so that what lands is ALREADY free of channel camping and the gathered
+    operand (17 GB at configs[4]) is never copied again (the serial path pays that copy on every call).
+    A step:
+        x_h = x_local in wire order (one pass over the LOCAL shard only)
+        enqueue all_gather(chunk c of x_h) for c = 0 .. chunks-1      RCCL stream, back to back, full mesh each
+        out  = A[:, own columns] @ x_h                                 needs no exchange: runs under collective 0
+        out += A[:, chunk c of the other owners] @ buffer c            as soon as collective c has completed
+    On a full xGMI mesh every collective uses all links (each peer's chunk arrives over its own link), which a
+    per-owner schedule of point-to-point steps would not; the column blocks are "by owner AND chunk" instead.
+    sum / mean / min / max; out (and arg_out) equal the serial product -- exactly for min / max (ties between
+    blocks go to the smaller entry id), up to the association of the partial sums for sum / mean.
+    Differentiable for sum / mean (the chunk buffers are autograd nodes whose backward reduce-scatters);
+    min / max under autograd fall back to the serial path.
+
+    ``partial_fn(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_none, accumulate, deg_rowptr)`` is
+    injectable for the CPU (gloo) tests; the product default is tsamd_spmm_partial."""
+
+    def __init__(self, rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
+                 group=None, spmm_fn: Optional[Callable] = None, chunks: int = 4,
+                 partial_fn: Optional[Callable] = None, positions_fn: Optional[Callable] = None):
+        self.group = group
+        self.spmm_fn = spmm_fn or _default_spmm
+        self.partial_fn = partial_fn or _native_partial
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert len(x_sizes) == self.world
+        self.x_sizes = list(x_sizes)
+        self.rowptr, self.col, self.value = rowptr, col, value
+        self.rows = rowptr.numel() - 1
+        self.E = col.numel()
+        self.chunks = max(1, int(chunks))
+        self._works = []
+        if self.world == 1:
+            return
+        positions_fn = positions_fn or _default_positions
+        dev = col.device
+        self.positions = [positions_fn(int(n), dev) for n in self.x_sizes]  # the same on every rank by construction
+        self.cs, self.stages = build_column_stages(rowptr, col, self.x_sizes, self.rank, self.chunks, self.positions)
+        # wire order of the local shard: x_pad[j] = x_local[inv[j]] for j < n_local (rows behind it are padding)
+        mine = self.positions[self.rank]
+        inv = torch.empty_like(mine)
+        inv[mine] = torch.arange(mine.numel(), dtype=torch.long, device=dev)
+        pad = self.chunks * self.cs - mine.numel()
+        self.inv = torch.cat([inv, inv.new_zeros(pad)]) if pad > 0 else inv
+
+    # ---- exchange ----------------------------------------------------------------------------
+    def wire_order(self, x_local: Tensor) -> Tensor:
+        """[chunks * cs, K]: the local shard in the row order it is stored and sent in (padding rows are never read)."""
+        return pack_rows(x_local, self.inv) if not x_local.requires_grad else x_local.index_select(0, self.inv)
+
+    def _start_gathers(self, x_pad: Tensor):
+        cs = self.cs
+        bufs, self._works = [], []
+        for c in range(self.chunks):
+            buf = x_pad.new_empty((self.world * cs, ) + tuple(x_pad.shape[1:]))
+            self._works.append(dist.all_gather_into_tensor(buf, x_pad[c * cs:(c + 1) * cs].detach(), group=self.group,
+                                                           async_op=True))
+            bufs.append(buf)
+        return bufs
+
+    def gather_all(self, x_local: Tensor):
+        """The exchange alone (for timing): all chunk collectives, waited for."""
+        bufs = self._start_gathers(self.wire_order(x_local))
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return bufs
+
+    # ---- the product -------------------------------------------------------------------------
+    def _stage_value(self, st):
+        return None if self.value is None else self.value.detach()[st['src']]
+
+    def multiply_landed(self, x_pad: Tensor, bufs, reduce: str, works=None):
+        """The staged product on buffers that have landed (or land as `works` complete) -> (out, arg_out or None)."""
+        minmax = reduce in ('min', 'max')
+        out = x_pad.new_empty((self.rows, ) + tuple(x_pad.shape[1:]))
+        arg = torch.empty(out.shape, dtype=torch.long, device=out.device) if minmax else None
+        last = len(self.stages) - 1
+        if getattr(self, '_stage_values_of', self) is not self.value:  # fixed weights: gathered once per value tensor
+            self._stage_values = [self._stage_value(st) for st in self.stages]
+            self._stage_values_of = self.value
+        for i, st in enumerate(self.stages):
+            mat = x_pad if i == 0 else bufs[i - 1]
+            if i > 0 and works is not None:
+                works[i - 1].wait()  # the compute stream waits for collective i - 1, the host does not
+            red = reduce
+            if reduce == 'mean' and i < last:
+                red = 'sum'
+            self.partial_fn(st['rowptr'], st['col'], self._stage_values[i], mat, red, out, arg,
+                            st['src'] if minmax else None, self.E, i > 0, self.rowptr if red == 'mean' else None)
+        return out, arg
+
+    def __call__(self, x_local: Tensor, reduce: str = 'sum', differentiable: Optional[bool] = None,
+                 return_arg: bool = False):
+        """`differentiable`: record for autograd (its backward issues collectives, so EVERY rank must take the same
+        path; None = decide from the local grad mode / requires_grad -- pass it explicitly when ranks may differ)."""
+        if reduce == 'add':
+            reduce = 'sum'
+        if self.world == 1:
+            return self.spmm_fn(self.rowptr, self.col, self.value, x_local, reduce)
+        if differentiable is None:
+            differentiable = torch.is_grad_enabled() and (
+                x_local.requires_grad or (self.value is not None and self.value.requires_grad))
+        if differentiable:
+            return self._differentiable(x_local, reduce)
+        x_pad = self.wire_order(x_local.detach())
+        bufs = self._start_gathers(x_pad)
+        works, self._works = self._works, []
+        out, arg = self.multiply_landed(x_pad, bufs, reduce, works)
+        return (out, arg) if return_arg else out
+
+    def _differentiable(self, x_local: Tensor, reduce: str) -> Tensor:
+        if reduce in ('min', 'max'):  # the winner's gradient crosses blocks: serial path
+            return RowShardedSpMM(self.rowptr, self.col, self.value, self.x_sizes, self.group, self.spmm_fn)(x_local, reduce)
+        x_pad = x_local.index_select(0, self.inv)
+        bufs = _ChunkedGather.apply(x_pad, self)
+        works, self._works = self._works, []
+        total = None
+        for i, st in enumerate(self.stages):
+            mat = x_pad if i == 0 else bufs[i - 1]
+            if i > 0:
+                works[i - 1].wait()
+            v = None if self.value is None else self.value[st['src']]
+            part = self.spmm_fn(st['rowptr'], st['col'], v, mat, 'sum')
+            total = part if total is None else total + part
+        if reduce == 'mean':
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).clamp(min=1).to(total.dtype)
+            total = total / deg.view(-1, *([1] * (total.dim() - 1)))
+        return total
 
 
 class _ExchangeRows(torch.autograd.Function):
@@ -393,7 +625,7 @@ class _PipelinedFetch(torch.autograd.Function):
 
 
 def shard_matrix(rowptr: Tensor, col: Tensor, value: Optional[Tensor], n_cols: int, group=None,
-                 balance: str = 'nnz', spmm_fn: Optional[Callable] = None, exchange: str = 'allgather'):
+                 balance: str = 'nnz', spmm_fn: Optional[Callable] = None, exchange: str = 'allgather', **kw):
     """Convenience for a replicated global CSR: every rank cuts out its own row block.  X is
     sharded by the same row ranges when the matrix is square (GNN layers chain that way),
     otherwise in equal blocks of columns."""
@@ -407,37 +639,44 @@ def shard_matrix(rowptr: Tensor, col: Tensor, value: Optional[Tensor], n_cols: i
         x_sizes = [(n_cols * (p + 1)) // world - (n_cols * p) // world for p in range(world)]
     s, e = ranges[rank]
     rp, c, v = narrow_rows(rowptr, col, value, s, e)
-    cls = {'allgather': RowShardedSpMM, 'halo': HaloShardedSpMM, 'pipelined': PipelinedHaloSpMM}[exchange]
-    return cls(rp, c, v, x_sizes, group, spmm_fn), (s, e)
+    cls = EXCHANGES[exchange]
+    return cls(rp, c, v, x_sizes, group, spmm_fn, **kw), (s, e)
 
 
 # ---------------------------------------------------------------------------------------------
 # orchestration helpers of the multi-GPU benchmark (bench.py); backend agnostic so that the control
 # flow is exercised by the gloo tests (tests/test_parallel_cpu.py)
 # ---------------------------------------------------------------------------------------------
-EXCHANGES = {'allgather': RowShardedSpMM, 'halo': HaloShardedSpMM, 'pipelined': PipelinedHaloSpMM}
+EXCHANGES = {'allgather': OverlappedAllGatherSpMM, 'allgather_serial': RowShardedSpMM, 'halo': HaloShardedSpMM,
+             'pipelined': PipelinedHaloSpMM}
 
 
 def build_with_fallback(rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
                         x_local: Tensor, reduce: str, spmm_fn: Callable, requested: str, chunks: int = 8,
-                        group=None, sync: Optional[Callable] = None):
+                        group=None, sync: Optional[Callable] = None, ag_chunks: int = 4,
+                        partial_fn: Optional[Callable] = None):
     """Plan the requested exchange and run one trial step; if that raises a RuntimeError (an unsupported
     collective, an allocation that does not fit ... -- the exception class goes into the reason; other
     exception types are bugs and propagate) the ranks agree through an all_reduce and fall back together:
-    requested -> halo -> allgather.  Meant for failures every rank hits at the same point; a rank that
+    requested -> halo -> allgather (overlapped) -> allgather_serial.  Meant for failures every rank hits at the same point; a rank that
     dies in the middle of a collective sequence leaves its peers waiting, nothing recovers from that.
     -> (sharded operator, mode actually used, None or the reason of the first fall-back)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     sync = sync or (lambda: None)
     reason = None
-    for mode in [requested] + [m for m in ('halo', 'allgather') if m != requested]:
+    for mode in [requested] + [m for m in ('halo', 'allgather', 'allgather_serial') if m != requested]:
         err = None
         try:
             cls = EXCHANGES[mode] if world > 1 else RowShardedSpMM
             kw = dict(chunks=chunks) if cls is PipelinedHaloSpMM else {}
+            if cls is OverlappedAllGatherSpMM:
+                kw = dict(chunks=ag_chunks, partial_fn=partial_fn)
             sharded = cls(rowptr, col, value, x_sizes, group, spmm_fn, **kw)
             with torch.no_grad():
-                sharded(x_local, reduce)
+                if cls in (PipelinedHaloSpMM, OverlappedAllGatherSpMM):
+                    sharded(x_local, reduce, differentiable=False)
+                else:
+                    sharded(x_local, reduce)
             sync()
         except RuntimeError as exc:  # incl. torch.cuda.OutOfMemoryError and the c10 / RCCL errors; anything else
             err = '%s: %s' % (type(exc).__name__, str(exc)[:200])  # (TypeError, AssertionError: a bug) propagates
@@ -463,6 +702,10 @@ def exchange_breakdown(sharded, ref_plan, x_local: Tensor, spmm_call: Callable, 
     sync = sync or (lambda: None)
     if isinstance(sharded, RowShardedSpMM):
         fetch = lambda: sharded.gather(x_local)  # noqa: E731
+        rows_in = n_global - x_local.size(0)
+        mode = 'allgather_serial'
+    elif isinstance(sharded, OverlappedAllGatherSpMM):
+        fetch = lambda: sharded.gather_all(x_local)  # noqa: E731
         rows_in = n_global - x_local.size(0)
         mode = 'allgather'
     else:

@@ -28,7 +28,13 @@ def storage_spmm(st: SparseStorage, other: Tensor, reduce: str) -> Tuple[Tensor,
     if value is not None:
         value = value.to(other.dtype)
     if reduce == 'min' or reduce == 'max':
-        if other.requires_grad:
+        # the CSC arrays (a radix sort on first use) are only built when the pull backward will really run:
+        # a gradient w.r.t. `other` is being recorded, and either the values need none (with grad_value the
+        # backward takes the fused scatter kernel) or deterministic algorithms are asked for
+        pull = other.requires_grad and torch.is_grad_enabled()
+        if pull and value is not None and value.requires_grad:
+            pull = torch.ops.tsamd.deterministic()
+        if pull:
             # training: hand the CSC arrays over (cached in the storage, as for sum) so that grad_mat is
             # pulled column by column instead of scattered with atomics (tsamd_spmm_minmax_bw_csc)
             out, arg = torch.ops.tsamd.spmm_minmax(rowptr, col, value, st.colptr(), st.csr2csc(), st.row(),
@@ -48,9 +54,9 @@ def storage_spmm(st: SparseStorage, other: Tensor, reduce: str) -> Tuple[Tensor,
             rowcount = st.rowcount()
     none: Optional[Tensor] = None
     if reduce == 'sum' or reduce == 'add':
-        return torch.ops.torch_sparse.spmm_sum(row, rowptr, col, value, colptr, csr2csc, other), none
+        return torch.ops.tsamd.spmm_sum_owned(row, rowptr, col, value, colptr, csr2csc, other), none
     if reduce == 'mean':
-        return torch.ops.torch_sparse.spmm_mean(row, rowptr, col, value, rowcount, colptr, csr2csc,
+        return torch.ops.tsamd.spmm_mean_owned(row, rowptr, col, value, rowcount, colptr, csr2csc,
                                                 other), none
     raise ValueError
 

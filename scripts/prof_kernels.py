@@ -90,7 +90,7 @@ if not which or 'c2_train_step' in which:
     _step()
     torch.ops.tsamd.operand_cache(False)
     run('c2_train_step', _step, edges=E, algorithmic_bytes=3 * balg(E, n, 64, 4, True, False))
-    torch.ops.tsamd.operand_cache(True)
+    torch.ops.tsamd.operand_cache(False)
 xb = synth.features(n, 128, dtype=torch.bfloat16, device=dev)
 gb = synth.features(n, 128, seed=3, dtype=torch.bfloat16, device=dev)
 run('c3_max_fw_bf16_F128', lambda: nat.spmm(rp, c, None, xb, 'max'), edges=E, algorithmic_bytes=balg(E, n, 128, 2, False, True))

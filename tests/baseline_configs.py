@@ -93,16 +93,18 @@ def pmc_traffic(workload, kernel_substr):
 
 class operand_cache(object):
     """with operand_cache(False): every product copies its dense operand again (tsamd_spmm), so that a timing loop
-    over the same X measures ALL the work of a call; the ops' default (cache on) is restored on exit."""
+    over the same X measures ALL the work of a call -- the ops' default since round 4 (the cache is opt-in);
+    with operand_cache(True): the opt-in behaviour.  The previous setting is restored on exit."""
 
     def __init__(self, enabled):
         self.enabled = enabled
+        self.was = False
 
     def __enter__(self):
-        torch.ops.tsamd.operand_cache(self.enabled)
+        self.was = bool(torch.ops.tsamd.operand_cache(self.enabled)[0])
 
     def __exit__(self, *exc):
-        torch.ops.tsamd.operand_cache(True)
+        torch.ops.tsamd.operand_cache(self.was)
 
 
 def _ref_ops():
@@ -188,8 +190,21 @@ def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5):
                n_elements_ref_ge_1e_2_l1=int((refd.abs() >= 1e-2 * l1).sum()),
                ref_vs_fp64_frac_rel_gt_1e_5=float((rel_ref64 > 1e-5).double().mean()),
                ours_vs_fp64_over_l1=float(e_ours.max()), ref_vs_fp64_over_l1=float(e_ref.max()))
+    # SURVEY 8(d)'s bound as written: |a - b| <= 1e-5 * max(|b|, 1e-5 * ||row||_1).  It is element-wise relative
+    # down to 1e-5 of the row's L1 mass, i.e. it also bites on cancelled sums -- where ANY fp32 summation order,
+    # the reference's own sequential one included, misses it against the exact (fp64) sum.  So the counts are
+    # reported for the three pairs, and the pass / fail statement is "ours violates it against fp64 no more often
+    # than the reference's own fp32 kernel does".
+    def literal(a_, b_):
+        return int(((a_ - b_).abs() > 1e-5 * torch.maximum(b_.abs(), 1e-5 * l1)).sum())
+    res['survey_8d_literal_bound'] = dict(
+        bound='|a - b| <= 1e-5 * max(|b|, 1e-5 * L1(row))',
+        n_viol_ours_vs_ref=literal(a.double(), refd), n_viol_ours_vs_fp64=literal(a.double(), exact),
+        n_viol_ref_vs_fp64=literal(refd, exact))
+    lb = res['survey_8d_literal_bound']
+    lb['ours_le_ref'] = bool(lb['n_viol_ours_vs_fp64'] <= lb['n_viol_ref_vs_fp64'])
     res['ok'] = bool(res['max_err_over_l1'] <= tol and res['ours_vs_fp64_over_l1'] <= tol and
-                     res['n_rel_gt_1e_5_where_ref_ge_1e_1_l1'] == 0)
+                     res['n_rel_gt_1e_5_where_ref_ge_1e_1_l1'] == 0 and lb['ours_le_ref'])
     return res
 
 
@@ -213,7 +228,8 @@ def run_c2(dev, cpu=True, iters=20):
         ms = gpu_ms(lambda: op(None, rp, c, v, None, None, x), iters=iters)
         ms_b2b = gpu_ms_stream(lambda: op(None, rp, c, v, None, None, x), iters=iters)
     out = op(None, rp, c, v, None, None, x)
-    ms_rep = gpu_ms(lambda: op(None, rp, c, v, None, None, x), iters=iters)  # operand cache on (default): same X again
+    with operand_cache(True):  # opt-in operand cache: same X again
+        ms_rep = gpu_ms(lambda: op(None, rp, c, v, None, None, x), iters=iters)
     ba = b_alg(E, n, K, 4, True, False)
     res = dict(config='c2', workload='configs[1]: CSR SpMM-sum 2^20 x 2^20 R-MAT (E=%d), F=64 fp32' % E,
                dtype='f32', ms=round(ms, 4), gedges_per_s=round(E / ms / 1e6, 3), ms_repeated_operand=round(ms_rep, 4),
@@ -229,6 +245,68 @@ def run_c2(dev, cpu=True, iters=20):
         res['cpu_baseline'] = dict(value=round(E / t / 1e9, 4), unit='GEdges/s', cores=cores, kind=kind,
                                    ms=round(t * 1e3, 2), sample='full workload, best of %d' % runs)
         res['parity'] = sum_parity(out, rpc, cc, vc, xc, ro)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# C5 share: what ONE of the 8 GPUs of configs[4] multiplies -- 2^21 rows, ~32 nnz/row, F = 256 fp32 (1 KB rows: the
+# 1024-item branch of plan_partition) -- plus the row-sharded path with P = 8 logical ranks on this one device
+# ------------------------------------------------------------------------------------------------
+def run_c5_share(dev, cpu=True, iters=10, logical_ranks=8):
+    from pytorch_sparse_amd import synth
+    from pytorch_sparse_amd import _native as nat
+    from pytorch_sparse_amd.parallel import narrow_rows, partition_rows
+    rp, c, n = rmat_graph(21, 32, dev)
+    E, K = c.numel(), 256
+    v = synth.values(E, device=dev)
+    x = synth.features(n, K, device=dev)
+    op = torch.ops.torch_sparse.spmm_sum
+    ms = gpu_ms(lambda: op(None, rp, c, v, None, None, x), iters=iters)
+    ms_b2b = gpu_ms_stream(lambda: op(None, rp, c, v, None, None, x), iters=iters)
+    out = op(None, rp, c, v, None, None, x)
+    ba = b_alg(E, n, K, 4, True, False)
+    res = dict(config='c5_share',
+               workload='configs[4] per-GPU share: CSR SpMM-sum 2^21 x 2^21 R-MAT edge factor 32 (E=%d), F=256 fp32' % E,
+               dtype='f32', ms=round(ms, 4), ms_back_to_back=round(ms_b2b, 4), gedges_per_s=round(E / ms / 1e6, 3),
+               roofline=dict(bound='hbm', algorithmic_bytes=ba, b_min=b_min(E, n, n, K, 4, True, False),
+                             achieved=round(ba / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                             frac=round(ba / ms / 1e6 / HBM_PEAK_GBS, 4), scope='whole op (all kernels of the call)'))
+    # P logical ranks, one after the other on this device (SURVEY 8e validation): every rank multiplies its
+    # nnz-balanced row block (narrow semantics, global column ids) with the full X
+    ranges = partition_rows(rp, logical_ranks, 'nnz')
+    l1 = nat.spmm(rp, c, v.abs(), x.abs(), 'sum')[0]
+    worst, t_blocks = 0.0, []
+    mx_full, ma_full = nat.spmm(rp, c, v, x, 'max')
+    max_equal = True
+    for s_, e_ in ranges:
+        rpl, cl, vl = narrow_rows(rp, c, v, s_, e_)
+        rpl = rpl.contiguous()
+        blk = nat.spmm(rpl, cl, vl, x, 'sum')[0]
+        t_blocks.append(gpu_ms(lambda: nat.spmm(rpl, cl, vl, x, 'sum'), iters=3, warm=1))
+        worst = max(worst, float(((blk.double() - out[s_:e_].double()).abs() / l1[s_:e_].double().clamp(min=1e-30)).max()))
+        bm, bam = nat.spmm(rpl, cl, vl, x, 'max')
+        e0 = int(rp[s_])
+        bam = torch.where(bam == cl.numel(), torch.full_like(bam, E), bam + e0)  # block-local entry ids -> global
+        max_equal = max_equal and bool(torch.equal(bm, mx_full[s_:e_])) and bool(torch.equal(bam, ma_full[s_:e_]))
+        del blk, bm, bam
+    del mx_full, ma_full, l1
+    res['row_sharded'] = dict(logical_ranks=logical_ranks, block_ms=[round(t, 4) for t in t_blocks],
+                              sum_of_blocks_ms=round(sum(t_blocks), 4), max_block_ms=round(max(t_blocks), 4),
+                              sum_max_err_over_l1_vs_unsharded=worst, max_and_arg_bit_identical_to_unsharded=max_equal,
+                              note='sum: a long row is cut by the merge-path partition at other places inside a block, so its '
+                                   'fp32 partial sums associate differently (<= 1e-5 of the L1 mass required); max: exact')
+    par = dict()
+    if cpu:
+        rpc, cc, vc, xc = rp.cpu(), c.cpu(), v.cpu(), x.cpu()
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        t, (ro, _, kind), runs = cpu_time(lambda: ref_spmm_cpu(rpc, cc, vc, xc, 'sum'), budget_s=20.0, max_reps=1)
+        res['cpu_baseline'] = dict(value=round(E / t / 1e9, 4), unit='GEdges/s', cores=cores, kind=kind,
+                                   ms=round(t * 1e3, 2), sample='full workload, best of %d' % runs)
+        par = sum_parity(out, rpc, cc, vc, xc, ro)
+    par['row_sharded_ok'] = bool(worst <= 1e-5 and max_equal)
+    par['ok'] = bool(par.get('ok', True) and par['row_sharded_ok'])
+    res['parity'] = par
     return res
 
 

