@@ -297,7 +297,8 @@ int tsamd_segment_reduce_balanced(int dtype, int reduce, const void *value, cons
  *                        adjacent duplicates, key = row * N + col.  counts_out is
  *                        a DEVICE int64[2]; reading it is the caller's one sync.
  *   tsamd_sort_coo       sort-on-construct (storage.py:149-162, utils.py:14-21):
- *                        stable radix sort by row * N + col; writes the sorted
+ *                        stable one-sweep radix sort by (row, col) -- the order of row * N + col;
+ *                        E < 2^32 and bits(M) + bits(N) <= 64, else TSAMD_ERR_UNSUPPORTED; writes the sorted
  *                        row / col (either may be NULL) and the permutation.
  *                        Called with (col, row, E, N, M, NULL, NULL, perm) it
  *                        yields csr2csc (storage.py:407-416).
@@ -330,6 +331,15 @@ int tsamd_sort_coo_auto(const int64_t *row, const int64_t *col, int64_t E, int64
 int tsamd_sort_coo_probed(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
                           int64_t *row_out, int64_t *col_out, int64_t *perm_out, const int64_t *descents,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* The three sorts above behind one entry, with the entries' values riding along: mode 0 = tsamd_sort_coo, 1 =
+ * tsamd_sort_coo_auto (counts [2] written), 2 = tsamd_sort_coo_probed (counts[0] read).  value / value_out
+ * (both or neither): arrays of E elements of value_bytes = 4 or 8 bytes; value_out[i] = value[perm_out[i]] is
+ * written by the last radix pass (the `value.index_select(0, perm)` of torch_sparse/storage.py:160-161 without a
+ * second pass over the permutation).  E < 2^32, bits(M) + bits(N) <= 64. */
+int tsamd_sort_coo_values(int mode, const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                          int64_t *row_out, int64_t *col_out, int64_t *perm_out, int64_t *counts,
+                          const void *value, void *value_out, int64_t value_bytes, void *workspace,
+                          size_t workspace_bytes, void *stream);
 size_t tsamd_sort_coo_workspace_bytes(int64_t E);
 int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
                    int64_t N, int64_t *row_out, int64_t *col_out, int64_t *perm_out,

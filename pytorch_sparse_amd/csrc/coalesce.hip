@@ -10,29 +10,12 @@
 // permutation, one flag+scan+compaction, one segmented reduction that reads the values
 // through the permutation (no materialised value[perm]).
 #include "common.h"
-#include "scan.h"
 #include "sort.h"
 
 #include <type_traits>
 
 namespace tsamd {
 namespace {
-
-__global__ void make_keys_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
-                                 int64_t n, int64_t ncols, int64_t *__restrict__ keys) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keys[i] = row[i] * ncols + col[i];
-}
-
-__global__ void decode_keys_kernel(const int64_t *__restrict__ keys, int64_t n, int64_t ncols,
-                                   int64_t *__restrict__ row, int64_t *__restrict__ col) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t k = keys[i];
-  const int64_t r = k / ncols;
-  if (row) row[i] = r;
-  if (col) col[i] = k - r * ncols;
-}
 
 // counts[0] += #{i : key[i] < key[i-1]}, counts[1] += #{i : key[i] == key[i-1]}
 // grid-stride with per-thread counters: one pair of atomics per workgroup at the very end
@@ -67,33 +50,53 @@ __global__ __launch_bounds__(256) void order_probe_kernel(const int64_t *__restr
 
 // order probe + range check in one pass: counts[0..1] as above, counts[2] = max row id, counts[3] = max col id
 // (counts[2..3] start at 0; ids are assumed non-negative)
-__global__ __launch_bounds__(256) void order_check_kernel(const int64_t *__restrict__ row,
+constexpr int kCheckThreads = 1024;
+__global__ __launch_bounds__(kCheckThreads) void order_check_kernel(const int64_t *__restrict__ row,
                                                          const int64_t *__restrict__ col, int64_t n,
                                                          unsigned long long *counts) {
   unsigned int desc = 0, dup = 0;
   int64_t mr = 0, mc = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = row[i], c = col[i];
-    mr = r > mr ? r : mr;
-    mc = c > mc ? c : mc;
-    if (i > 0) {  // lexicographic (row, col): the same order as row * ncols + col, without knowing ncols
-      const int64_t pr = row[i - 1], pc = col[i - 1];
-      desc += (r < pr) || (r == pr && c < pc);
-      dup += (r == pr) && (c == pc);
+  const int lane = (int)(threadIdx.x & 63);
+  constexpr int kB = 4;  // entries per thread and step, all loads of a step in flight together
+  for (int64_t base = (int64_t)blockIdx.x * (kCheckThreads * kB); base < n; base += (int64_t)gridDim.x * (kCheckThreads * kB)) {
+    int64_t r[kB], c[kB];
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const int64_t i = base + u * kCheckThreads + threadIdx.x;
+      r[u] = i < n ? row[i] : 0;
+      c[u] = i < n ? col[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const int64_t i = base + u * kCheckThreads + threadIdx.x;
+      // the entry before: the neighbour lane's registers, except for lane 0 (one cached load per wave)
+      int64_t pr = lane_read(r[u], lane > 0 ? lane - 1 : 0), pc = lane_read(c[u], lane > 0 ? lane - 1 : 0);
+      if (i < n) {
+        if (lane == 0 && i > 0) {
+          pr = row[i - 1];
+          pc = col[i - 1];
+        }
+        mr = (uint64_t)r[u] > (uint64_t)mr ? r[u] : mr;  // unsigned: a negative id reads as a huge one and fails the range check
+        mc = (uint64_t)c[u] > (uint64_t)mc ? c[u] : mc;
+        if (i > 0) {  // lexicographic (row, col): the same order as row * ncols + col, without knowing ncols
+          desc += (r[u] < pr) || (r[u] == pr && c[u] < pc);
+          dup += (r[u] == pr) && (c[u] == pc);
+        }
+      }
     }
   }
   for (int off = 32; off > 0; off >>= 1) {
     desc += lane_xor(desc, off);
     dup += lane_xor(dup, off);
     const int64_t orr = lane_xor(mr, off), oc = lane_xor(mc, off);
-    mr = orr > mr ? orr : mr;
-    mc = oc > mc ? oc : mc;
+    mr = (uint64_t)orr > (uint64_t)mr ? orr : mr;
+    mc = (uint64_t)oc > (uint64_t)mc ? oc : mc;
   }
   // one set of atomics per WORKGROUP (the four result words are hot addresses: ~12 ns per atomic, serialised --
   // a first version with one set per wave took 0.30 ms for 7.5 M entries instead of 0.07), and the maxima only
   // when they would change anything
-  __shared__ unsigned int s_desc[4], s_dup[4];
-  __shared__ long long s_mr[4], s_mc[4];
+  __shared__ unsigned int s_desc[kCheckThreads / 64], s_dup[kCheckThreads / 64];
+  __shared__ long long s_mr[kCheckThreads / 64], s_mc[kCheckThreads / 64];
   const int wid = (int)(threadIdx.x >> 6);
   if ((threadIdx.x & 63) == 0) {
     s_desc[wid] = desc;
@@ -105,11 +108,11 @@ __global__ __launch_bounds__(256) void order_check_kernel(const int64_t *__restr
   if (threadIdx.x == 0) {
     unsigned int d = 0, u = 0;
     long long a = 0, b = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kCheckThreads / 64; ++w) {
       d += s_desc[w];
       u += s_dup[w];
-      a = s_mr[w] > a ? s_mr[w] : a;
-      b = s_mc[w] > b ? s_mc[w] : b;
+      a = (unsigned long long)s_mr[w] > (unsigned long long)a ? s_mr[w] : a;
+      b = (unsigned long long)s_mc[w] > (unsigned long long)b ? s_mc[w] : b;
     }
     if (d) atomicAdd(&counts[0], (unsigned long long)d);
     if (u) atomicAdd(&counts[1], (unsigned long long)u);
@@ -118,47 +121,119 @@ __global__ __launch_bounds__(256) void order_check_kernel(const int64_t *__restr
   }
 }
 
-// the outputs of a device-decided sort when the input turned out to be sorted: a copy and the identity
-__global__ void sort_auto_finish_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
-                                        const int64_t *__restrict__ keys_sorted, int64_t n, int64_t ncols,
-                                        const int64_t *__restrict__ todo, int64_t *__restrict__ row_out,
-                                        int64_t *__restrict__ col_out, int64_t *__restrict__ perm_out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (*todo == 0) {
-    if (row_out) row_out[i] = row[i];
-    if (col_out) col_out[i] = col[i];
-    perm_out[i] = i;
-  } else {
-    const int64_t k = keys_sorted[i];
-    const int64_t r = k / ncols;
-    if (row_out) row_out[i] = r;
-    if (col_out) col_out[i] = k - r * ncols;
-  }
-}
-
 __device__ inline bool is_head(const int64_t *row, const int64_t *col, int64_t i) {
   return i == 0 || row[i] != row[i - 1] || col[i] != col[i - 1];
 }
 
-__global__ void head_flags_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
-                                  int64_t n, int64_t *__restrict__ flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flags[i] = is_head(row, col, i) ? 1 : 0;
-}
+// Adjacent-duplicate compaction of a sorted COO list in ONE kernel: head flags, their scan and the compaction.
+// A tile of 2048 entries counts its heads, publishes the count and looks back over the tiles before it
+// (decoupled look-back, one status word per tile: [63:62] 1 = own count, 2 = inclusive prefix; tiles are handed
+// out by a ticket), then writes its heads at their final positions.
+constexpr int kCompactItems = 8;
+constexpr int kCompactTile = 256 * kCompactItems;
 
-__global__ void compact_heads_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col,
-                                     int64_t n, const int64_t *__restrict__ pos,
-                                     const int64_t *__restrict__ nnz, int64_t *__restrict__ row_out,
-                                     int64_t *__restrict__ col_out, int64_t *__restrict__ seg_ptr) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) seg_ptr[*nnz] = n;
-  if (i >= n) return;
-  if (is_head(row, col, i)) {
-    const int64_t p = pos[i];
-    row_out[p] = row[i];
-    col_out[p] = col[i];
-    seg_ptr[p] = i;
+__global__ __launch_bounds__(256) void coalesce_compact_kernel(
+    const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t n, int64_t *__restrict__ row_out,
+    int64_t *__restrict__ col_out, int64_t *__restrict__ seg_ptr, int64_t *__restrict__ nnz_out,
+    unsigned long long *__restrict__ state /* [1] error, [8 + tile] status */) {
+  __shared__ unsigned long long s_base;
+  __shared__ unsigned int s_cnt[kCompactItems][4];
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t tile = (int64_t)blockIdx.x;  // tiles wait for lower tiles only (see sort.hip on the dispatch order)
+  const int64_t ntiles = (n + kCompactTile - 1) / kCompactTile;
+  const int64_t tile0 = tile * kCompactTile;
+  // entry e = tile0 + i * 256 + tid: every load instruction of a wave covers 512 contiguous bytes
+  int64_t r[kCompactItems], c[kCompactItems];
+  unsigned long long hmask[kCompactItems];  // the wave's head flags of step i
+  unsigned int heads = 0;
+#pragma unroll
+  for (int i = 0; i < kCompactItems; ++i) {
+    const int64_t e = tile0 + i * 256 + tid;
+    r[i] = e < n ? row[e] : 0;
+    c[i] = e < n ? col[e] : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < kCompactItems; ++i) {
+    const int64_t e = tile0 + i * 256 + tid;
+    int64_t pr = lane_read(r[i], lane > 0 ? lane - 1 : 0), pc = lane_read(c[i], lane > 0 ? lane - 1 : 0);
+    bool h = false;
+    if (e < n) {
+      if (lane == 0 && e > 0) {
+        pr = row[e - 1];
+        pc = col[e - 1];
+      }
+      h = e == 0 || r[i] != pr || c[i] != pc;
+    }
+    hmask[i] = __ballot(h);
+    heads |= (h ? 1u : 0u) << i;
+    if (lane == 0) s_cnt[i][w] = (unsigned int)__popcll(hmask[i]);
+  }
+  __syncthreads();
+  // heads before (step i, wave w) in entry order: steps first, waves inside a step
+  unsigned int before_step[kCompactItems];
+  unsigned int total = 0;
+#pragma unroll
+  for (int i = 0; i < kCompactItems; ++i) {
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      if (ww == w) before_step[i] = total;
+      total += s_cnt[i][ww];
+    }
+  }
+  constexpr unsigned long long kLocal = 1ull << 62, kPrefix = 2ull << 62, kMask = (1ull << 62) - 1ull;
+  if (w == 0) {  // wave 0 publishes and looks back, 64 tiles per step
+    unsigned long long *mine = state + 8 + tile;
+    if (lane == 0)
+      __hip_atomic_store(mine, (tile == 0 ? kPrefix : kLocal) | (unsigned long long)total, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long before = 0;
+    int64_t t = tile - 1;
+    unsigned int spins = 0;
+    while (t >= 0) {
+      const int64_t mt = t - lane;
+      unsigned long long s = kPrefix;  // lanes past tile 0 read as "prefix 0"
+      if (mt >= 0) s = __hip_atomic_load(state + 8 + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long ready = __ballot((s >> 62) != 0);
+      const unsigned long long pref = __ballot((s >> 62) == 2);
+      // usable lanes: the ready ones up to and including the first prefix, with no gap before it
+      const int first_gap = ~ready ? __builtin_ctzll(~ready) : 64;
+      const int first_pref = pref ? __builtin_ctzll(pref) : 64;
+      const int take = first_pref < first_gap ? first_pref + 1 : first_gap;
+      unsigned long long v = lane < take ? (s & kMask) : 0ull;
+      for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)lane_xor((int64_t)v, off);
+      before += v;
+      if (first_pref < first_gap) break;  // reached an inclusive prefix
+      t -= take;
+      if (take == 0) {
+        if (++spins > (1u << 20)) {
+          if (lane == 0) state[1] = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (lane == 0) {
+      if (tile > 0)
+        __hip_atomic_store(mine, kPrefix | (before + (unsigned long long)total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      s_base = before;
+      if (tile == ntiles - 1) {
+        nnz_out[0] = (int64_t)(before + total);
+        seg_ptr[before + total] = n;
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t base = (int64_t)s_base;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int i = 0; i < kCompactItems; ++i) {
+    if ((heads >> i) & 1u) {
+      const int64_t p = base + before_step[i] + (unsigned int)__popcll(hmask[i] & lt);
+      row_out[p] = r[i];
+      col_out[p] = c[i];
+      seg_ptr[p] = tile0 + i * 256 + tid;
+    }
   }
 }
 
@@ -365,10 +440,7 @@ bool small_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M
 
 using namespace tsamd;
 
-extern "C" size_t tsamd_sort_coo_workspace_bytes(int64_t E) {
-  const size_t n = (size_t)(E > 0 ? E : 1);
-  return 2 * align_up(sizeof(int64_t) * n, 256) + sort_pairs_workspace_bytes(E);
-}
+extern "C" size_t tsamd_sort_coo_workspace_bytes(int64_t E) { return sort_coo_workspace_bytes(E); }
 
 extern "C" int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
                               int64_t N, int64_t *row_out, int64_t *col_out, int64_t *perm_out,
@@ -377,36 +449,38 @@ extern "C" int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E,
   if (E < 0 || M < 0 || N < 0) return TSAMD_ERR_INVALID;
   if (E == 0) return TSAMD_OK;
   if (!row || !col || !perm_out) return TSAMD_ERR_INVALID;
-  if ((unsigned __int128)M * (unsigned __int128)N >= ((unsigned __int128)1 << 63))
-    return TSAMD_ERR_UNSUPPORTED;
+  if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < tsamd_sort_coo_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
   if (small_sort_coo(row, col, E, M, N, row_out, col_out, perm_out, nullptr, false, stream)) {
     TSAMD_LAUNCH_CHECK();
     return TSAMD_OK;
   }
-  char *p = reinterpret_cast<char *>(workspace);
-  int64_t *keys = reinterpret_cast<int64_t *>(p);
-  p += align_up(sizeof(int64_t) * (size_t)E, 256);
-  int64_t *keys_sorted = reinterpret_cast<int64_t *>(p);
-  p += align_up(sizeof(int64_t) * (size_t)E, 256);
-  const unsigned int blocks = (unsigned int)ceil_div(E, 256);
-  hipLaunchKernelGGL(make_keys_kernel, dim3(blocks), dim3(256), 0, stream, row, col, E, N, keys);
-  TSAMD_LAUNCH_CHECK();
-  int st = sort_pairs(keys, nullptr, keys_sorted, perm_out, E, key_bits_for(M, N), p, stream);
-  if (st != TSAMD_OK) return st;
-  if (row_out || col_out) {
-    hipLaunchKernelGGL(decode_keys_kernel, dim3(blocks), dim3(256), 0, stream,
-                       (const int64_t *)keys_sorted, E, N, row_out, col_out);
-    TSAMD_LAUNCH_CHECK();
-  }
-  return TSAMD_OK;
+  return sort_coo_onesweep(row, col, E, M, N, row_out, col_out, perm_out, nullptr, false, nullptr, workspace, stream);
 }
 
 // sort_coo decided on the device: counts_out[0..1] = (#descents, #adjacent duplicates) of the INPUT; when
 // there is no descent the radix passes return at once and the outputs are a copy + the identity.
 static int sort_coo_auto_impl(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
                               int64_t *row_out, int64_t *col_out, int64_t *perm_out, int64_t *counts_out,
-                              bool probe, void *workspace, size_t workspace_bytes, void *stream_);
+                              bool probe, void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (E < 0 || M < 0 || N < 0 || !counts_out) return TSAMD_ERR_INVALID;
+  if (E == 0) {
+    if (probe) TSAMD_HIP_TRY(hipMemsetAsync(counts_out, 0, 2 * sizeof(int64_t), stream));
+    return TSAMD_OK;
+  }
+  if (!row || !col || !perm_out) return TSAMD_ERR_INVALID;
+  if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
+  if (small_sort_coo(row, col, E, M, N, row_out, col_out, perm_out, probe ? counts_out : nullptr, true, stream)) {
+    TSAMD_LAUNCH_CHECK();  // probe, sort and decode in one launch (the small kernel probes for itself)
+    return TSAMD_OK;
+  }
+  if (!workspace || workspace_bytes < tsamd_sort_coo_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
+  // probe = true: the build kernel counts the descents itself (one read of the input serves the probe, the keys and
+  // the digit histograms); probe = false: counts_out[0] already holds them (tsamd_coo_check)
+  return sort_coo_onesweep(row, col, E, M, N, row_out, col_out, perm_out, probe ? nullptr : counts_out, probe,
+                           probe ? counts_out : nullptr, workspace, stream);
+}
 
 extern "C" int tsamd_sort_coo_auto(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
                                    int64_t *row_out, int64_t *col_out, int64_t *perm_out,
@@ -427,38 +501,30 @@ extern "C" int tsamd_sort_coo_probed(const int64_t *row, const int64_t *col, int
                             workspace, workspace_bytes, stream_);
 }
 
-static int sort_coo_auto_impl(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
-                              int64_t *row_out, int64_t *col_out, int64_t *perm_out, int64_t *counts_out,
-                              bool probe, void *workspace, size_t workspace_bytes, void *stream_) {
+// One entry point for the three flavours with the entries' values riding along (include/tsamd.h).
+extern "C" int tsamd_sort_coo_values(int mode, const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                                     int64_t *row_out, int64_t *col_out, int64_t *perm_out, int64_t *counts,
+                                     const void *value, void *value_out, int64_t value_bytes, void *workspace,
+                                     size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (E < 0 || M < 0 || N < 0 || !counts_out) return TSAMD_ERR_INVALID;
-  if (E > 0 && row && col && perm_out &&
-      (unsigned __int128)M * (unsigned __int128)N < ((unsigned __int128)1 << 63) &&
-      small_sort_coo(row, col, E, M, N, row_out, col_out, perm_out, probe ? counts_out : nullptr, true, stream)) {
-    TSAMD_LAUNCH_CHECK();  // probe, sort and decode in one launch (the small kernel probes for itself)
+  if (E < 0 || M < 0 || N < 0 || mode < 0 || mode > 2 || (mode != 0 && !counts)) return TSAMD_ERR_INVALID;
+  if ((value == nullptr) != (value_out == nullptr)) return TSAMD_ERR_INVALID;
+  if (value != nullptr && value_bytes != 4 && value_bytes != 8) return TSAMD_ERR_UNSUPPORTED;
+  if (E == 0) {
+    if (mode == 1) TSAMD_HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), stream));
     return TSAMD_OK;
   }
-  int st = TSAMD_OK;
-  if (probe) st = tsamd_coo_order(row, col, E, N, counts_out, stream_);
-  if (st != TSAMD_OK || E == 0) return st;
   if (!row || !col || !perm_out) return TSAMD_ERR_INVALID;
-  if ((unsigned __int128)M * (unsigned __int128)N >= ((unsigned __int128)1 << 63))
-    return TSAMD_ERR_UNSUPPORTED;
+  if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < tsamd_sort_coo_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
-  char *p = reinterpret_cast<char *>(workspace);
-  int64_t *keys = reinterpret_cast<int64_t *>(p);
-  p += align_up(sizeof(int64_t) * (size_t)E, 256);
-  int64_t *keys_sorted = reinterpret_cast<int64_t *>(p);
-  p += align_up(sizeof(int64_t) * (size_t)E, 256);
-  const unsigned int blocks = (unsigned int)ceil_div(E, 256);
-  hipLaunchKernelGGL(make_keys_kernel, dim3(blocks), dim3(256), 0, stream, row, col, E, N, keys);
-  TSAMD_LAUNCH_CHECK();
-  st = sort_pairs(keys, nullptr, keys_sorted, perm_out, E, key_bits_for(M, N), p, stream, counts_out);
-  if (st != TSAMD_OK) return st;
-  hipLaunchKernelGGL(sort_auto_finish_kernel, dim3(blocks), dim3(256), 0, stream, row, col,
-                     (const int64_t *)keys_sorted, E, N, (const int64_t *)counts_out, row_out, col_out, perm_out);
-  TSAMD_LAUNCH_CHECK();
-  return TSAMD_OK;
+  if (small_sort_coo(row, col, E, M, N, row_out, col_out, perm_out, mode == 1 ? counts : nullptr, mode != 0, stream)) {
+    TSAMD_LAUNCH_CHECK();
+    if (value != nullptr)  // the one-launch path has no payload: a gather through the permutation behind it
+      return tsamd_gather_rows(value, perm_out, value_out, E, E, value_bytes, stream_);
+    return TSAMD_OK;
+  }
+  return sort_coo_onesweep(row, col, E, M, N, row_out, col_out, perm_out, mode == 2 ? counts : nullptr, mode == 1,
+                           mode == 1 ? counts : nullptr, workspace, stream, value, value_out, (int)value_bytes);
 }
 
 // counts_out[0..3] = (#descents, #adjacent duplicates, max row id, max col id): everything the
@@ -470,8 +536,9 @@ extern "C" int tsamd_coo_check(const int64_t *row, const int64_t *col, int64_t E
   TSAMD_HIP_TRY(hipMemsetAsync(counts_out, 0, 4 * sizeof(int64_t), stream));
   if (E == 0) return TSAMD_OK;
   if (!row || !col) return TSAMD_ERR_INVALID;
-  const int64_t nblk = ceil_div(E, 256);
-  hipLaunchKernelGGL(order_check_kernel, dim3((unsigned int)(nblk < 1024 ? nblk : 1024)), dim3(256), 0,
+  // few, big workgroups: the four result words are hot addresses (~12 ns per atomic, serialised)
+  const int64_t nblk = ceil_div(E, kCheckThreads * 4);
+  hipLaunchKernelGGL(order_check_kernel, dim3((unsigned int)(nblk < 512 ? nblk : 512)), dim3(kCheckThreads), 0,
                      stream, row, col, E, reinterpret_cast<unsigned long long *>(counts_out));
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
@@ -492,7 +559,8 @@ extern "C" int tsamd_coo_order(const int64_t *row, const int64_t *col, int64_t E
 }
 
 extern "C" size_t tsamd_coalesce_workspace_bytes(int64_t E) {
-  return align_up(sizeof(int64_t) * (size_t)(E > 0 ? E : 1), 256) + scan_workspace_bytes(E);
+  const size_t ntiles = ((size_t)(E > 0 ? E : 1) + kCompactTile - 1) / kCompactTile;
+  return align_up(sizeof(unsigned long long) * (8 + ntiles), 256);
 }
 
 extern "C" int tsamd_coalesce_index(const int64_t *row, const int64_t *col, int64_t E,
@@ -507,16 +575,12 @@ extern "C" int tsamd_coalesce_index(const int64_t *row, const int64_t *col, int6
     return TSAMD_OK;
   }
   if (!row || !col || !row_out || !col_out) return TSAMD_ERR_INVALID;
-  if (!workspace || workspace_bytes < tsamd_coalesce_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
-  int64_t *pos = reinterpret_cast<int64_t *>(workspace);
-  void *scan_ws = reinterpret_cast<char *>(workspace) + align_up(sizeof(int64_t) * (size_t)E, 256);
-  const unsigned int blocks = (unsigned int)ceil_div(E, 256);
-  hipLaunchKernelGGL(head_flags_kernel, dim3(blocks), dim3(256), 0, stream, row, col, E, pos);
-  TSAMD_LAUNCH_CHECK();
-  int st = exclusive_scan_i64(pos, pos, E, nnz_out, scan_ws, stream);
-  if (st != TSAMD_OK) return st;
-  hipLaunchKernelGGL(compact_heads_kernel, dim3(blocks), dim3(256), 0, stream, row, col, E,
-                     (const int64_t *)pos, (const int64_t *)nnz_out, row_out, col_out, seg_ptr);
+  const size_t need = tsamd_coalesce_workspace_bytes(E);
+  if (!workspace || workspace_bytes < need) return TSAMD_ERR_WORKSPACE;
+  TSAMD_HIP_TRY(hipMemsetAsync(workspace, 0, need, stream));
+  hipLaunchKernelGGL(coalesce_compact_kernel, dim3((unsigned int)ceil_div(E, kCompactTile)), dim3(256), 0, stream,
+                     row, col, E, row_out, col_out, seg_ptr, nnz_out,
+                     reinterpret_cast<unsigned long long *>(workspace));
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }

@@ -119,6 +119,54 @@ std::tuple<Tensor, Tensor, Tensor> sort_coo_probed(Tensor row, Tensor col, int64
   return std::make_tuple(row_s, col_s, perm);
 }
 
+// The three sorts with the entries' values riding along: mode 0 plain | 1 device-decided (probe) | 2 device-decided from
+// counts[0] (tsamd::coo_check) -> (row_sorted, col_sorted, perm, counts, value[perm] or an empty tensor).
+// 1-D values of 4- or 8-byte elements that need no gradient are written by the sort's last pass
+// (tsamd_sort_coo_values); anything else is gathered through the permutation afterwards (differentiable).
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sort_coo_values(Tensor row, Tensor col, int64_t M, int64_t N,
+                                                                 int64_t mode, OptTensor opt_counts, OptTensor opt_value) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  TORCH_CHECK(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  Tensor perm = torch::empty({E}, row.options()), row_s = torch::empty({E}, row.options()),
+         col_s = torch::empty({E}, row.options());
+  Tensor counts;
+  if (mode == 2) {
+    TORCH_CHECK(opt_counts.has_value(), "mode 2 needs the probe's counts");
+    counts = opt_counts.value();
+    check_index(counts, "counts");
+    TORCH_CHECK(counts.numel() >= 1 && counts.is_contiguous(), "counts must hold the number of descents");
+  } else {
+    counts = torch::empty({2}, row.options());
+  }
+  Tensor value, value_s = torch::empty({0}, row.options());
+  bool fused = false;
+  if (opt_value.has_value()) {
+    value = opt_value.value();
+    check_gpu(value, "value");
+    TORCH_CHECK(value.dim() >= 1 && value.size(0) == E, "value must have one entry per (row, col) pair");
+    fused = value.dim() == 1 && (value.element_size() == 4 || value.element_size() == 8) && !needs_grad(value) && E > 0;
+    if (fused) {
+      value = value.contiguous();
+      value_s = torch::empty_like(value);
+    }
+  }
+  Tensor ws = workspace(tsamd_sort_coo_workspace_bytes(E), row);
+  check_status(tsamd_sort_coo_values((int)mode, row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N,
+                                     row_s.data_ptr<int64_t>(), col_s.data_ptr<int64_t>(), perm.data_ptr<int64_t>(),
+                                     mode == 0 ? nullptr : counts.data_ptr<int64_t>(), fused ? value.data_ptr() : nullptr,
+                                     fused ? value_s.data_ptr() : nullptr, fused ? (int64_t)value.element_size() : 0,
+                                     ws.data_ptr(), (size_t)ws.numel(), current_stream(row)),
+               "tsamd_sort_coo_values");
+  if (opt_value.has_value() && !fused) value_s = value.index_select(0, perm);
+  return std::make_tuple(row_s, col_s, perm, counts, value_s);
+}
+
 // stable sort by row * N + col -> (row_sorted, col_sorted, perm); with index=false only perm
 std::tuple<Tensor, Tensor, Tensor> sort_coo(Tensor row, Tensor col, int64_t M, int64_t N,
                                             bool index) {
@@ -484,6 +532,7 @@ static auto registry_storage = torch::RegisterOperators()
                            .op("tsamd::coo_order", &coo_order)
                            .op("tsamd::sort_coo", &sort_coo)
                            .op("tsamd::coo_check", &coo_check)
+                           .op("tsamd::sort_coo_values", &sort_coo_values)
                            .op("tsamd::sort_coo_auto", &sort_coo_auto)
                            .op("tsamd::sort_coo_probed", &sort_coo_probed)
                            .op("tsamd::coalesce_index", &coalesce_index)

@@ -1,12 +1,19 @@
 #pragma once
 #include "common.h"
 namespace tsamd {
-size_t sort_pairs_workspace_bytes(int64_t n);
-// Stable sort of (key, payload) by the low `key_bits` bits of key.  vals_in == nullptr sorts
-// the identity permutation (argsort).  Inputs are not modified; in/out must not alias.
-// todo != nullptr: device word; when it holds 0 at run time the passes do nothing (the outputs are then
-// left untouched -- the caller fills them) -- a sort that is decided on the device, without a host sync.
-int sort_pairs(const int64_t *keys_in, const int64_t *vals_in, int64_t *keys_out,
-               int64_t *vals_out, int64_t n, int key_bits, void *workspace, hipStream_t stream,
-               const int64_t *todo = nullptr);
+// Stable sort of COO entries by (row, col) -- the order of row * N + col -- see sort.hip.
+//   row_out / col_out (nullable): the sorted ids; perm_out: position of every sorted entry in the input.
+//   todo (nullable, device): number of descents of the input known from an earlier probe; 0 at run time = nothing to
+//     sort: every kernel returns at once and the finish kernel writes (copy, identity);
+//   probe: the build kernel counts descents / adjacent duplicates itself (counts_out[0..1], device), and the passes
+//     are decided by that count -- a sort decided on the device without a host sync.
+//   gather_src / gather_dst (nullable): gather_dst[o] = gather_src[perm_out[o]] for arrays of 4- or 8-byte elements,
+//     written by the last pass (the values of the entries ride along instead of a gather through perm_out later).
+// Inputs are not modified; outputs must not alias them.  E < 2^32, bits(M) + bits(N) <= 64.
+size_t sort_coo_workspace_bytes(int64_t E);
+bool sort_coo_supported(int64_t E, int64_t M, int64_t N);
+int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_out,
+                      int64_t *col_out, int64_t *perm_out, const int64_t *todo, bool probe, int64_t *counts_out,
+                      void *workspace, hipStream_t stream, const void *gather_src = nullptr,
+                      void *gather_dst = nullptr, int gather_bytes = 0);
 }  // namespace tsamd

@@ -1,20 +1,33 @@
-// Stable LSD radix sort of (int64 key, int64 payload) pairs on gfx950.
+// Stable one-sweep LSD radix sort of COO entries on gfx950.
 //
-// Replaces the generic device sort the reference calls through `index_sort` /
-// `torch.sort` when a SparseStorage is built from unsorted COO, when csr2csc is
-// computed and inside coalesce/transpose (torch_sparse/utils.py:14-21, called from
-// torch_sparse/storage.py:149-162, 407-429).  Keys are `row * N + col`, so only
-// ceil(log2(M*N)) bits are significant: the number of 8-bit passes is chosen per call.
-// Unlike the reference's default `torch.sort` the order of equal keys is stable.
+// Replaces the generic device sort the reference calls through `index_sort` / `torch.sort` when a
+// SparseStorage is built from unsorted COO, when csr2csc is computed and inside coalesce / transpose
+// (torch_sparse/utils.py:14-21, called from torch_sparse/storage.py:149-162, 407-429), TOGETHER with the key
+// build in front of it and the gathers / divisions behind it.  Unlike the reference's default `torch.sort` the
+// order of equal keys is stable.
 //
-// One pass = three launches:
-//   radix_hist_kernel     per-workgroup digit histogram          -> hist[digit][block]
-//   exclusive_scan_i64    over the digit-major histogram matrix  (scan.hip)
-//   radix_scatter_kernel  wave-level match ranking (8 ballots per key) keeps equal digits in
-//                         input order; the tile is reordered in LDS so that every digit run
-//                         leaves the workgroup as one contiguous, coalesced write.
+// Design (round 4; the round 1-3 version took three launches per digit -- histogram, device scan, scatter --
+// over 16-byte (key, payload) pairs plus a key-build and a decode pass: 1.39 GB of fabric traffic for 300 MB of
+// in + out bytes at 7.5 M entries, ~35 dispatches per coalesce):
+//   * key = (row << col_bits) | col  -- the same order as row * N + col without a multiply in front and a 64-bit
+//     division behind; only row_bits + col_bits bits are sorted, 8 per pass;
+//   * the entry's position rides in the low bits of the SAME 64-bit word when row_bits + col_bits + idx_bits <= 64
+//     (7.5 M entries of a 500 k x 500 k matrix: 38 + 23): a pass moves 8 + 8 bytes per entry instead of 16 + 16;
+//     otherwise a 32-bit payload array travels beside the keys (12 + 12 bytes);
+//   * ONE read of (row, col) builds the words and the digit histograms of EVERY pass (and, for the
+//     device-decided sort, the order probe);
+//   * a pass is ONE kernel: the tile's digit counts are published and the tiles before it are looked back at
+//     (decoupled look-back, one status word per (tile, digit)) -- no histogram kernel, no device scan.  Tile =
+//     workgroup id: a tile only waits for LOWER tiles, and the dispatcher of every XCD hands its share of the
+//     workgroups out in increasing order, so the lowest tile that has not started yet always finds its predecessors
+//     running or done and a free slot on its XCD (an atomic ticket per tile cost 10-16 us per pass at 7.5 M
+//     entries: 1831 serialised atomics on one word; -DTSAMD_SORT_TICKET=1 brings it back).  A look-back that does not
+//     see its predecessor within ~1 s raises an error flag instead of hanging;
+//   * the last pass writes the sorted row / col / permutation themselves (shifts and masks).
+// 2 + passes launches (memset, build, passes), also for the device-decided variants; a value array can ride along in
+// the last pass (dst[o] = src[perm[o]], 4- or 8-byte elements) instead of being gathered through the permutation later.
 #include "common.h"
-#include "scan.h"
+#include "sort.h"
 
 namespace tsamd {
 namespace {
@@ -24,68 +37,237 @@ constexpr int kSortThreads = 256;
 #define TSAMD_SORT_ITEMS 16
 #endif
 constexpr int kSortItems = TSAMD_SORT_ITEMS;
-constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 pairs per workgroup (A/B: 4 / 8 / 12 / 16 items -> 0.83 / 0.61 / 0.58 / 0.56 ms for 7.5 M pairs)
+constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 entries per workgroup
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
+constexpr int kMaxPasses = 8;
+#ifndef TSAMD_SORT_ATOMIC_RANK
+#define TSAMD_SORT_ATOMIC_RANK 1
+#endif
+#ifndef TSAMD_SORT_TICKET
+#define TSAMD_SORT_TICKET 0
+#endif
+#ifndef TSAMD_SORT_LOOK
+#define TSAMD_SORT_LOOK 4
+#endif
 
-// `todo` (may be NULL): device word that says whether there is anything to sort -- the number of descents
-// of the key sequence (tsamd_sort_coo_auto).  Zero = already sorted: the pass kernels return at once.
-__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const int64_t *__restrict__ keys,
-                                                                 int64_t n, int shift,
-                                                                 int64_t *__restrict__ hist,
-                                                                 int64_t nb, const int64_t *__restrict__ todo) {
-  if (todo != nullptr && *todo == 0) return;
-  __shared__ uint32_t cnt[kRadix];
-  cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kSortTile;
-#pragma unroll
-  for (int i = 0; i < kSortItems; ++i) {
-    const int64_t idx = base + i * kSortThreads + threadIdx.x;
-    if (idx < n) atomicAdd(&cnt[(uint32_t)((uint64_t)keys[idx] >> shift) & (kRadix - 1)], 1u);
-  }
-  __syncthreads();
-  hist[(int64_t)threadIdx.x * nb + blockIdx.x] = cnt[threadIdx.x];
+// workspace header (zeroed by the one memset of a sort): 64 words
+constexpr int kHdrDescents = 0, kHdrDups = 1, kHdrError = 2;
+[[maybe_unused]] constexpr int kHdrTicket = 8;  // ticket[kMaxPasses], -DTSAMD_SORT_TICKET=1 only
+constexpr int kHdrWords = 64;
+
+// status word of (tile, digit): [63:62] 1 = the tile's own count, 2 = inclusive prefix over all tiles up to it;
+// [61:56] epoch = pass + 1 (the array is zeroed once per sort, not once per pass); [55:0] count
+constexpr unsigned long long kFlagLocal = 1ull << 62, kFlagPrefix = 2ull << 62;
+constexpr unsigned long long kCountMask = (1ull << 56) - 1ull;
+__device__ __forceinline__ unsigned long long st_load(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_store(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr unsigned int kSpinLimit = 1u << 20;  // a look-back that never sees its predecessor gives up (error flag) instead of hanging
+
+struct KeyLayout {
+  int col_bits, key_bits, idx_bits;
+  bool packed;
+  int passes;
+};
+
+int bits_for(int64_t n) {  // bits needed for ids in [0, n)
+  int b = 0;
+  while (b < 63 && ((int64_t)1 << b) < n) ++b;
+  return b;
 }
 
-__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
-    const int64_t *__restrict__ keys_in, const int64_t *__restrict__ vals_in,
-    int64_t *__restrict__ keys_out, int64_t *__restrict__ vals_out, int64_t n, int shift,
-    const int64_t *__restrict__ hist_scanned, int64_t nb, const int64_t *__restrict__ todo) {
+// ---------------------------------------------------------------------------
+// build: words (or keys) + every pass's digit histogram (+ the order probe) in one read of (row, col)
+// ---------------------------------------------------------------------------
+constexpr int kBuildThreads = 1024;
+__global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
+    const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t n, KeyLayout L,
+    unsigned long long *__restrict__ words, unsigned long long *__restrict__ hist /* [passes][256] */,
+    unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo, int probe) {
   if (todo != nullptr && *todo == 0) return;
-  // gfx950 only: the tile lives in LDS (160 KB per CU there, 64 KB on older parts)
-  static_assert(sizeof(int64_t) * 2 * kSortTile + sizeof(uint32_t) * 5 * kRadix + sizeof(int64_t) * (kRadix + 8) <=
-                    160 * 1024,
-                "radix_scatter_kernel: the tile (TSAMD_SORT_ITEMS) no longer fits the 160 KB LDS of gfx950");
-  __shared__ int64_t skey[kSortTile];
-  __shared__ int64_t sval[kSortTile];
-  __shared__ uint32_t cnt[4][kRadix];
-  __shared__ uint32_t dig_off[kRadix];
-  __shared__ int64_t goff[kRadix];
-  __shared__ int64_t sscan[8];
-
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63;
-  const int w = tid >> 6;
-  const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
-  const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
-
-  int64_t key[kSortItems], val[kSortItems];
-  uint32_t dig[kSortItems], lrank[kSortItems];
-  bool valid[kSortItems];
+  __shared__ unsigned int cnt[kMaxPasses][kRadix];
+  for (int p = 0; p < L.passes; ++p)
+    if (threadIdx.x < kRadix) cnt[p][threadIdx.x] = 0;
+  __syncthreads();
+  unsigned int desc = 0, dup = 0;
+  const int lane = (int)(threadIdx.x & 63);
+  constexpr int kB = 4;  // entries per thread and step: the loads of a step are all in flight together
+  for (int64_t base = (int64_t)blockIdx.x * (kBuildThreads * kB); base < n; base += (int64_t)gridDim.x * (kBuildThreads * kB)) {
+    int64_t r[kB], c[kB];
+    bool ok[kB];
 #pragma unroll
-  for (int i = 0; i < kSortItems; ++i) {
-    const int64_t idx = base + i * 64 + lane;
-    valid[i] = idx < n;
-    key[i] = valid[i] ? keys_in[idx] : 0;
-    val[i] = valid[i] ? (vals_in ? vals_in[idx] : idx) : 0;
-    dig[i] = (uint32_t)((uint64_t)key[i] >> shift) & (kRadix - 1);
+    for (int u = 0; u < kB; ++u) {
+      const int64_t i = base + u * kBuildThreads + threadIdx.x;
+      ok[u] = i < n;
+      r[u] = ok[u] ? row[i] : 0;
+      c[u] = ok[u] ? col[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const int64_t i = base + u * kBuildThreads + threadIdx.x;
+      unsigned long long key = ((unsigned long long)r[u] << L.col_bits) | (unsigned long long)c[u];
+      // the entry before: the neighbour lane's registers (exchanged with every lane active: a disabled source lane
+      // reads as 0), except for lane 0 (one cached load per wave)
+      int64_t pr = 0, pc = 0;
+      if (probe) {
+        pr = lane_read(r[u], lane > 0 ? lane - 1 : 0);
+        pc = lane_read(c[u], lane > 0 ? lane - 1 : 0);
+      }
+      if (ok[u]) {
+        words[i] = L.packed ? ((key << L.idx_bits) | (unsigned long long)i) : key;
+        if (probe && i > 0) {
+          if (lane == 0) {
+            pr = row[i - 1];
+            pc = col[i - 1];
+          }
+          desc += (r[u] < pr) || (r[u] == pr && c[u] < pc);
+          dup += (r[u] == pr) && (c[u] == pc);
+        }
+      }
+      for (int p = 0; p < L.passes; ++p) {
+        const unsigned int d = (unsigned int)(key >> (p * kRadixBits)) & (kRadix - 1);
+        // the high digits of a power-law matrix take a handful of values: one add per wave when all lanes agree
+        const unsigned int d0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)d);
+        const unsigned long long act = __ballot(ok[u]);
+        if (__ballot(ok[u] && d == d0) == act) {
+          if (lane == 0 && act) atomicAdd(&cnt[p][d0], (unsigned int)__popcll(act));
+        } else if (ok[u]) {
+          atomicAdd(&cnt[p][d], 1u);
+        }
+      }
+    }
   }
+  __syncthreads();
+  // (few, big workgroups: every histogram word is a hot address -- ~12 ns per atomic, serialised; 4096 workgroups
+  // spent 50 us queueing on them, 256 spend 3)
+  for (int p = (int)(threadIdx.x >> 8); p < L.passes; p += kBuildThreads / kRadix) {
+    const unsigned int c = cnt[p][threadIdx.x & (kRadix - 1)];
+    if (c) atomicAdd(&hist[p * kRadix + (threadIdx.x & (kRadix - 1))], (unsigned long long)c);
+  }
+  if (probe) {
+    for (int off = 32; off > 0; off >>= 1) {
+      desc += lane_xor(desc, off);
+      dup += lane_xor(dup, off);
+    }
+    __shared__ unsigned int s_cnt[2][kBuildThreads / 64];
+    if (lane == 0) {
+      s_cnt[0][threadIdx.x >> 6] = desc;
+      s_cnt[1][threadIdx.x >> 6] = dup;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {  // one pair of atomics per workgroup: the two words are hot addresses
+      unsigned int t = 0;
+      for (int ww = 0; ww < kBuildThreads / 64; ++ww) t += s_cnt[threadIdx.x][ww];
+      if (t) atomicAdd(&hdr[threadIdx.x == 0 ? kHdrDescents : kHdrDups], (unsigned long long)t);
+    }
+  }
+}
+
+// exclusive scan of one value per thread over a 256-thread block (u64); smem: 4 words
+__device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long *smem) {
+  const int lane = (int)(threadIdx.x & 63), wid = (int)(threadIdx.x >> 6);
+  unsigned long long inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = (unsigned long long)lane_read((int64_t)inc, lane >= off ? lane - off : lane);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) smem[wid] = inc;
+  __syncthreads();
+  unsigned long long base = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (w < wid) base += smem[w];
+  __syncthreads();
+  return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------
+// one pass = one kernel
+// ---------------------------------------------------------------------------
+template <bool PACKED, bool LAST>
+__global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
+    const unsigned long long *__restrict__ in, const unsigned int *__restrict__ idx_in,
+    unsigned long long *__restrict__ out, unsigned int *__restrict__ idx_out, int64_t *__restrict__ row_out,
+    int64_t *__restrict__ col_out, int64_t *__restrict__ perm_out, int64_t n, int shift, KeyLayout L,
+    const unsigned long long *__restrict__ hist, unsigned long long *__restrict__ tile_state,
+    unsigned long long *__restrict__ hdr, unsigned int epoch, const int64_t *__restrict__ todo,
+    const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t *__restrict__ counts_out,
+    const void *__restrict__ gather_src, void *__restrict__ gather_dst, int gather_bytes) {
+  if constexpr (LAST) {  // the probe's counters travel with the last pass (no separate kernel)
+    if (counts_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+      counts_out[0] = (int64_t)hdr[kHdrDescents];
+      counts_out[1] = (int64_t)hdr[kHdrDups];
+    }
+  }
+  if (todo != nullptr && *todo == 0) {
+    // nothing had to be sorted: the last pass writes what a sort of a sorted input returns -- a copy and the identity
+    if constexpr (LAST) {
+      const int64_t t0 = (int64_t)blockIdx.x * kSortTile;
+      for (int k = 0; k < kSortItems; ++k) {
+        const int64_t e = t0 + k * kSortThreads + threadIdx.x;
+        if (e >= n) break;
+        if (row_out) row_out[e] = row[e];
+        if (col_out) col_out[e] = col[e];
+        perm_out[e] = e;
+        if (gather_dst != nullptr) {
+          if (gather_bytes == 4) reinterpret_cast<uint32_t *>(gather_dst)[e] = reinterpret_cast<const uint32_t *>(gather_src)[e];
+          else reinterpret_cast<uint64_t *>(gather_dst)[e] = reinterpret_cast<const uint64_t *>(gather_src)[e];
+        }
+      }
+    }
+    return;
+  }
+  __shared__ unsigned long long sword[kSortTile];
+  __shared__ unsigned int sidx[PACKED ? 1 : kSortTile];
+  __shared__ unsigned int cnt[4][kRadix];
+  __shared__ unsigned int dig_off[kRadix];
+  __shared__ long long goff[kRadix];
+  __shared__ unsigned long long sscan[4];
+  __shared__ unsigned int s_tile;
+
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+#if TSAMD_SORT_TICKET
+  if (tid == 0) s_tile = (unsigned int)atomicAdd(&hdr[kHdrTicket + epoch - 1], 1ull);
+#else
+  if (tid == 0) s_tile = blockIdx.x;
+#endif
 #pragma unroll
   for (int i = 0; i < 4; ++i) cnt[i][tid] = 0;
   __syncthreads();
+  const int64_t tile = (int64_t)s_tile;
+  const int64_t tile0 = tile * kSortTile;
+  const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
 
-  // rank of every key among the equal digits of its wave, in input order
+  unsigned long long word[kSortItems];
+  unsigned int idx[PACKED ? 1 : kSortItems];
+  unsigned int dig[kSortItems], lrank[kSortItems];
+  bool valid[kSortItems];
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    const int64_t e = base + i * 64 + lane;
+    valid[i] = e < n;
+    word[i] = valid[i] ? in[e] : 0ull;
+    if constexpr (!PACKED) idx[i] = valid[i] ? (idx_in ? idx_in[e] : (unsigned int)e) : 0u;
+    dig[i] = (unsigned int)(word[i] >> shift) & (kRadix - 1);
+  }
+  // rank of every entry among the equal digits of its wave, in input order
+#if TSAMD_SORT_ATOMIC_RANK
+  // One returning LDS atomic per entry.  When several lanes of ONE ds_add_rtn hit the same counter the LDS unit
+  // serves them in ascending lane order on gfx950, so the value returned is the stable rank (tests/test_sort_gpu.py
+  // pins the exact stable permutation on inputs made of a few hot keys; -DTSAMD_SORT_ATOMIC_RANK=0 selects the
+  // ballot matching below, which does not depend on that order but issues ~190 instead of ~40 instructions per
+  // entry and pass: 60 vs ~30 us per pass at 7.5 M entries).
+#pragma unroll
+  for (int i = 0; i < kSortItems; ++i) {
+    lrank[i] = 0;
+    if (valid[i]) lrank[i] = atomicAdd(&cnt[w][dig[i]], 1u);
+  }
+#else
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
     unsigned long long peers = __ballot(valid[i]);
@@ -95,114 +277,262 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
       const unsigned long long m = __ballot(valid[i] && bit);
       peers &= bit ? m : ~m;
     }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t rank = (uint32_t)__popcll(peers & lt);
+    const unsigned int rank = (unsigned int)__popcll(peers & ((1ull << lane) - 1ull));
     const int leader = valid[i] ? (__ffsll((long long)peers) - 1) : lane;
-    uint32_t pre = 0;
+    unsigned int pre = 0;
     if (valid[i] && lane == leader) {
       pre = cnt[w][dig[i]];
-      cnt[w][dig[i]] = pre + (uint32_t)__popcll(peers);
+      cnt[w][dig[i]] = pre + (unsigned int)__popcll(peers);
     }
     pre = lane_read(pre, leader);
     lrank[i] = pre + rank;
   }
+#endif
   __syncthreads();
 
-  // thread t owns digit t: exclusive prefix over the 4 waves, then over the digits
-  {
-    uint32_t run = 0;
+  // thread t owns digit t
+  unsigned int mine = 0;
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) {
-      const uint32_t c = cnt[ww][tid];
-      cnt[ww][tid] = run;
-      run += c;
-    }
-    int64_t tot;
-    const int64_t ex = block_exclusive_scan_256((int64_t)run, sscan, &tot);
-    dig_off[tid] = (uint32_t)ex;
-    goff[tid] = hist_scanned[(int64_t)tid * nb + blockIdx.x] - ex;
+  for (int ww = 0; ww < 4; ++ww) {
+    const unsigned int c = cnt[ww][tid];
+    cnt[ww][tid] = mine;
+    mine += c;
   }
+  unsigned long long *my_state = tile_state + (size_t)tile * kRadix + tid;
+  const unsigned long long ep = (unsigned long long)epoch << 56;
+  st_store(my_state, (tile == 0 ? kFlagPrefix : kFlagLocal) | ep | (unsigned long long)mine);
+  const unsigned long long ex = block_excl_scan_u64((unsigned long long)mine, sscan);    // position of the digit's run in the tile
+  const unsigned long long gbase = block_excl_scan_u64(hist[tid], sscan);                // first output slot of the digit
+  dig_off[tid] = (unsigned int)ex;
   __syncthreads();
 
+  // reorder the tile in LDS (needs nothing from the other tiles) ...
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
     if (valid[i]) {
-      const uint32_t pos = dig_off[dig[i]] + cnt[w][dig[i]] + lrank[i];
-      skey[pos] = key[i];
-      sval[pos] = val[i];
+      const unsigned int pos = dig_off[dig[i]] + cnt[w][dig[i]] + lrank[i];
+      sword[pos] = word[i];
+      if constexpr (!PACKED) sidx[pos] = idx[i];
     }
   }
+  // ... then look back: the entries with my digit in the tiles before this one
+  unsigned long long before = 0;
+#if defined(TSAMD_SORT_EXP_NOLOOKBACK)
+  if (false) {
+#else
+  if (tile > 0) {
+#endif
+    int64_t t = tile - 1;
+    unsigned int spins = 0;
+    bool done = false;
+    while (!done) {
+      // the status words of kLook tiles at once (independent loads: one round trip), consumed nearest first
+      constexpr int kLook = TSAMD_SORT_LOOK;
+      unsigned long long sv[kLook];
+#pragma unroll
+      for (int u = 0; u < kLook; ++u) sv[u] = st_load(tile_state + (size_t)(t - u >= 0 ? t - u : 0) * kRadix + tid);
+#pragma unroll
+      for (int u = 0; u < kLook; ++u) {
+        if (done) break;
+        const unsigned long long sw = sv[u];
+        if ((sw & (0x3full << 56)) != ep || (sw >> 62) == 0) {  // not published yet (for this pass): poll again from here
+          if (++spins > kSpinLimit) {
+            hdr[kHdrError] = 1;
+            done = true;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          break;
+        }
+        before += sw & kCountMask;
+        if ((sw >> 62) == 2 || t == 0) done = true;
+        else --t;
+      }
+    }
+    st_store(my_state, kFlagPrefix | ep | (before + (unsigned long long)mine));
+  }
+  goff[tid] = (long long)(gbase + before) - (long long)ex;
   __syncthreads();
 
   const int64_t rem = n - tile0;
   const int count = rem < kSortTile ? (int)rem : kSortTile;
-  for (int j = tid; j < count; j += kSortThreads) {
-    const int64_t k = skey[j];
-    const uint32_t d = (uint32_t)((uint64_t)k >> shift) & (kRadix - 1);
-    const int64_t o = goff[d] + j;
-    keys_out[o] = k;
-    vals_out[o] = sval[j];
+  if constexpr (LAST) {
+    // batches of 8 entries per thread: positions and source ids first, then (values riding along) the 8 random reads
+    // in flight together, then the stores -- one entry at a time the gather's latency was paid 16 times in a row
+    constexpr int kBatch = 8;
+#pragma unroll
+    for (int k0 = 0; k0 < kSortItems; k0 += kBatch) {
+      int64_t o[kBatch];
+      unsigned long long key[kBatch], e[kBatch];
+      bool ok[kBatch];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const int j = (k0 + k) * kSortThreads + tid;
+        ok[k] = j < count;
+        const unsigned long long wd = sword[ok[k] ? j : 0];
+        const unsigned int d = (unsigned int)(wd >> shift) & (kRadix - 1);
+        o[k] = goff[d] + j;
+        if constexpr (PACKED) {
+          key[k] = wd >> L.idx_bits;
+          e[k] = wd & ((1ull << L.idx_bits) - 1ull);
+        } else {
+          key[k] = wd;
+          e[k] = sidx[ok[k] ? j : 0];
+        }
+      }
+      if (gather_dst != nullptr) {
+        if (gather_bytes == 4) {
+          uint32_t v[kBatch];
+#pragma unroll
+          for (int k = 0; k < kBatch; ++k) v[k] = reinterpret_cast<const uint32_t *>(gather_src)[ok[k] ? e[k] : 0];
+#pragma unroll
+          for (int k = 0; k < kBatch; ++k)
+            if (ok[k]) reinterpret_cast<uint32_t *>(gather_dst)[o[k]] = v[k];
+        } else {
+          uint64_t v[kBatch];
+#pragma unroll
+          for (int k = 0; k < kBatch; ++k) v[k] = reinterpret_cast<const uint64_t *>(gather_src)[ok[k] ? e[k] : 0];
+#pragma unroll
+          for (int k = 0; k < kBatch; ++k)
+            if (ok[k]) reinterpret_cast<uint64_t *>(gather_dst)[o[k]] = v[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        if (!ok[k]) continue;
+        if (row_out) row_out[o[k]] = (int64_t)(key[k] >> L.col_bits);
+        if (col_out) col_out[o[k]] = (int64_t)(key[k] & ((1ull << L.col_bits) - 1ull));
+        perm_out[o[k]] = (int64_t)e[k];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+      const int j = k * kSortThreads + tid;
+      if (j >= count) break;
+      const unsigned long long wd = sword[j];
+      const unsigned int d = (unsigned int)(wd >> shift) & (kRadix - 1);
+      const int64_t o = goff[d] + j;
+      out[o] = wd;
+      if constexpr (!PACKED) idx_out[o] = sidx[j];
+    }
   }
 }
 
-__global__ void copy_iota_kernel(const int64_t *__restrict__ keys_in,
-                                 const int64_t *__restrict__ vals_in,
-                                 int64_t *__restrict__ keys_out, int64_t *__restrict__ vals_out,
-                                 int64_t n) {
+// keys of zero bits (a 1 x 1 matrix), or a single entry: the input order is the sorted order
+__global__ void sort_identity_kernel(const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t n,
+                                     int64_t *__restrict__ row_out, int64_t *__restrict__ col_out,
+                                     int64_t *__restrict__ perm_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keys_out[i] = keys_in[i];
-  vals_out[i] = vals_in ? vals_in[i] : i;
+  if (row_out) row_out[i] = row[i];
+  if (col_out) col_out[i] = col[i];
+  perm_out[i] = i;
+}
+
+KeyLayout layout_for(int64_t E, int64_t M, int64_t N) {
+  KeyLayout L;
+  L.col_bits = bits_for(N > 0 ? N : 1);
+  L.key_bits = bits_for(M > 0 ? M : 1) + L.col_bits;
+  L.idx_bits = bits_for(E > 0 ? E : 1);
+  L.packed = L.key_bits + L.idx_bits <= 64;
+  L.passes = (L.key_bits + kRadixBits - 1) / kRadixBits;
+  return L;
+}
+
+struct SortWs {
+  unsigned long long *hdr, *hist, *tile_state, *a, *b;
+  unsigned int *ia, *ib;
+  size_t zero_bytes;  // hdr + hist + tile_state are contiguous: one memset
+};
+
+size_t carve_sort(void *base, int64_t E, SortWs *ws) {
+  const size_t n = (size_t)(E > 0 ? E : 1);
+  const size_t ntiles = (n + kSortTile - 1) / kSortTile;
+  char *p = reinterpret_cast<char *>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) -> void * {
+    void *r = p ? p + off : nullptr;
+    off += align_up(bytes, 256);
+    return r;
+  };
+  SortWs w;
+  w.hdr = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * kHdrWords));
+  w.hist = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * kMaxPasses * kRadix));
+  w.tile_state = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * ntiles * kRadix));
+  w.zero_bytes = off;
+  w.a = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * n));
+  w.b = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * n));
+  w.ia = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * n));
+  w.ib = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * n));
+  if (ws) *ws = w;
+  return off;
 }
 
 }  // namespace
 
-size_t sort_pairs_workspace_bytes(int64_t n) {
-  const int64_t nb = ceil_div(n > 0 ? n : 1, kSortTile);
-  const size_t hist = align_up(sizeof(int64_t) * (size_t)(kRadix * nb), 256);
-  return 2 * align_up(sizeof(int64_t) * (size_t)(n > 0 ? n : 1), 256) + hist +
-         scan_workspace_bytes(kRadix * nb);
+size_t sort_coo_workspace_bytes(int64_t E) { return carve_sort(nullptr, E, nullptr); }
+
+bool sort_coo_supported(int64_t E, int64_t M, int64_t N) {
+  return E < ((int64_t)1 << 32) && bits_for(M > 0 ? M : 1) + bits_for(N > 0 ? N : 1) <= 64 &&
+         (bits_for(M > 0 ? M : 1) + bits_for(N > 0 ? N : 1) + kRadixBits - 1) / kRadixBits <= kMaxPasses;
 }
 
-int sort_pairs(const int64_t *keys_in, const int64_t *vals_in, int64_t *keys_out,
-               int64_t *vals_out, int64_t n, int key_bits, void *workspace, hipStream_t stream,
-               const int64_t *todo) {
-  if (n <= 0) return TSAMD_OK;
-  if (key_bits < 0) key_bits = 0;
-  if (key_bits > 63) key_bits = 63;
-  const int passes = n > 1 ? (key_bits + kRadixBits - 1) / kRadixBits : 0;
-  if (passes == 0) {
-    hipLaunchKernelGGL(copy_iota_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
-                       keys_in, vals_in, keys_out, vals_out, n);
+int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_out,
+                      int64_t *col_out, int64_t *perm_out, const int64_t *todo, bool probe, int64_t *counts_out,
+                      void *workspace, hipStream_t stream, const void *gather_src, void *gather_dst,
+                      int gather_bytes) {
+  if (E <= 0) return TSAMD_OK;
+  if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
+  const KeyLayout L = layout_for(E, M, N);
+  const unsigned int eblocks = (unsigned int)ceil_div(E, 256);
+  if (gather_dst != nullptr && (gather_src == nullptr || (gather_bytes != 4 && gather_bytes != 8))) return TSAMD_ERR_INVALID;
+  SortWs ws;
+  carve_sort(workspace, E, &ws);
+  if (L.passes == 0 || E == 1) {  // nothing to order (a 1 x 1 matrix: every key is equal)
+    if (probe && counts_out != nullptr) {
+      const int64_t c[2] = {0, E - 1};  // no descent, every adjacent pair a duplicate
+      TSAMD_HIP_TRY(hipMemcpyAsync(counts_out, c, sizeof(c), hipMemcpyHostToDevice, stream));
+    }
+    hipLaunchKernelGGL(sort_identity_kernel, dim3(eblocks), dim3(256), 0, stream, row, col, E, row_out, col_out,
+                       perm_out);
     TSAMD_LAUNCH_CHECK();
+    if (gather_dst != nullptr)
+      TSAMD_HIP_TRY(hipMemcpyAsync(gather_dst, gather_src, (size_t)E * gather_bytes, hipMemcpyDeviceToDevice, stream));
     return TSAMD_OK;
   }
-  const int64_t nb = ceil_div(n, kSortTile);
-  char *p = reinterpret_cast<char *>(workspace);
-  int64_t *tkeys = reinterpret_cast<int64_t *>(p);
-  p += align_up(sizeof(int64_t) * (size_t)n, 256);
-  int64_t *tvals = reinterpret_cast<int64_t *>(p);
-  p += align_up(sizeof(int64_t) * (size_t)n, 256);
-  int64_t *hist = reinterpret_cast<int64_t *>(p);
-  p += align_up(sizeof(int64_t) * (size_t)(kRadix * nb), 256);
-  void *scan_ws = p;
-
-  const int64_t *src_k = keys_in, *src_v = vals_in;
-  for (int pass = 0; pass < passes; ++pass) {
-    const bool to_out = ((passes - 1 - pass) % 2) == 0;
-    int64_t *dst_k = to_out ? keys_out : tkeys;
-    int64_t *dst_v = to_out ? vals_out : tvals;
-    const int shift = pass * kRadixBits;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned int)nb), dim3(kSortThreads), 0, stream,
-                       src_k, n, shift, hist, nb, todo);
+  TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes, stream));
+  const int64_t ntiles = ceil_div(E, kSortTile);
+  {
+    const int64_t nb = ceil_div(E, kBuildThreads * 4);
+    hipLaunchKernelGGL(sort_build_kernel, dim3((unsigned int)(nb < 512 ? nb : 512)), dim3(kBuildThreads), 0, stream,
+                       row, col, E, L, ws.a, ws.hist, ws.hdr, todo, probe ? 1 : 0);
     TSAMD_LAUNCH_CHECK();
-    int st = exclusive_scan_i64(hist, hist, kRadix * nb, nullptr, scan_ws, stream);
-    if (st != TSAMD_OK) return st;
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned int)nb), dim3(kSortThreads), 0, stream,
-                       src_k, src_v, dst_k, dst_v, n, shift, (const int64_t *)hist, nb, todo);
+  }
+  // the passes of a probing sort are decided by the probe's own counter
+  const int64_t *pass_todo = probe ? reinterpret_cast<const int64_t *>(ws.hdr + kHdrDescents) : todo;
+  const unsigned long long *src = ws.a;
+  const unsigned int *isrc = nullptr;  // first pass: payload = position
+  for (int pass = 0; pass < L.passes; ++pass) {
+    const bool last = pass == L.passes - 1;
+    unsigned long long *dst = (src == ws.a) ? ws.b : ws.a;
+    unsigned int *idst = (isrc == ws.ia) ? ws.ib : ws.ia;
+    const int shift = pass * kRadixBits + (L.packed ? L.idx_bits : 0);
+#define TSAMD_SORT_PASS(P, LST)                                                                                     \
+  hipLaunchKernelGGL((onesweep_pass_kernel<P, LST>), dim3((unsigned int)ntiles), dim3(kSortThreads), 0, stream, src, \
+                     isrc, dst, idst, row_out, col_out, perm_out, E, shift, L, ws.hist + pass * kRadix,              \
+                     ws.tile_state, ws.hdr, (unsigned int)(pass + 1), pass_todo, row, col,                          \
+                     (last && probe) ? counts_out : (int64_t *)nullptr, gather_src, gather_dst, gather_bytes)
+    if (L.packed) {
+      if (last) TSAMD_SORT_PASS(true, true);
+      else TSAMD_SORT_PASS(true, false);
+    } else {
+      if (last) TSAMD_SORT_PASS(false, true);
+      else TSAMD_SORT_PASS(false, false);
+    }
+#undef TSAMD_SORT_PASS
     TSAMD_LAUNCH_CHECK();
-    src_k = dst_k;
-    src_v = dst_v;
+    src = dst;
+    isrc = idst;
   }
   return TSAMD_OK;
 }

@@ -117,14 +117,18 @@ class SparseStorage(object):
         presorted_row: Optional[Tensor] = None
         presorted_col: Optional[Tensor] = None
         presorted_value: Optional[Tensor] = None
+        presorted_rowptr: Optional[Tensor] = None
         did_sort = False
         if (col.is_cuda and row is not None and rowptr is None and given_m is not None and given_n is not None and
                 not trust_data and not is_sorted and nnz > 1 and csr2csc is None and csc2csr is None):
             counts_dev = torch.ops.tsamd.coo_check(row.contiguous(), col)
-            presorted_row, presorted_col, perm0 = torch.ops.tsamd.sort_coo_probed(row.contiguous(), col, given_m,
-                                                                                   given_n, counts_dev)
+            # (the values ride along in the sort's last pass when they are plain 4- / 8-byte numbers)
+            presorted_row, presorted_col, perm0, _, vsorted = torch.ops.tsamd.sort_coo_values(
+                row.contiguous(), col, given_m, given_n, 2, counts_dev, value)
             if value is not None:
-                presorted_value = value.index_select(0, perm0)
+                presorted_value = vsorted
+            # (rowptr too: CSR is what every product reads, and a launch behind the read-back would wait for it)
+            presorted_rowptr = torch.ops.torch_sparse.ind2ptr(presorted_row, given_m)
             counts0: List[int] = counts_dev.tolist()  # the one host sync, with everything already in flight
             descents, max_row, max_col = counts0[0], counts0[2], counts0[3]
             did_sort = True
@@ -176,6 +180,7 @@ class SparseStorage(object):
         if did_sort:
             # (sorted or not, the outputs of the device-decided sort are what the storage holds)
             self._row = presorted_row
+            self._rowptr = presorted_rowptr
             self._col = torch.jit._unwrap_optional(presorted_col)
             if value is not None:
                 self._value = presorted_value
@@ -189,18 +194,18 @@ class SparseStorage(object):
             if descents < 0:
                 # nothing was read back: sort decided on the device (a sorted input costs the probe, a few
                 # kernels that return at once and one copy) -- no host sync in this constructor
-                rs, cs, perm, _ = torch.ops.tsamd.sort_coo_auto(r, col, M, N)
+                rs, cs, perm, _, vs = torch.ops.tsamd.sort_coo_values(r, col, M, N, 1, None, value)
                 self._row = rs
                 self._col = cs
                 if value is not None:
-                    self._value = value.index_select(0, perm)
+                    self._value = vs
             elif descents > 0:
-                rs, cs, perm = torch.ops.tsamd.sort_coo(r, col, M, N, True)
+                rs, cs, perm, _, vs = torch.ops.tsamd.sort_coo_values(r, col, M, N, 0, None, value)
                 self._row = rs
                 self._col = cs
                 self._rowptr = None
                 if value is not None:
-                    self._value = value.index_select(0, perm)
+                    self._value = vs
                 self._csr2csc = None
                 self._csc2csr = None
 
@@ -396,6 +401,21 @@ class SparseStorage(object):
         if self._colptr is None and self._colcount is None:
             self._colptr = torch.ops.torch_sparse.ind2ptr(cs, N)
         return cs, rs, perm
+
+    def csc_index_value(self) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
+        """``csc_index()`` plus the values in column-major order: when the permutation is new the values ride along
+        in the sort that produces it (no gather through the permutation afterwards); what `t()` needs."""
+        value = self._value
+        if self._csr2csc is not None or value is None:
+            cs, rs, perm = self.csc_index()
+            return cs, rs, perm, None if value is None else value.index_select(0, perm)
+        N = self._sparse_sizes[1]
+        cs, rs, perm, _, vs = torch.ops.tsamd.sort_coo_values(self._col, self.row(), N, self._sparse_sizes[0], 0, None,
+                                                              value)
+        self._csr2csc = perm
+        if self._colptr is None and self._colcount is None:
+            self._colptr = torch.ops.torch_sparse.ind2ptr(cs, N)
+        return cs, rs, perm, vs
 
     def has_csc2csr(self) -> bool:
         return self._csc2csr is not None

@@ -11,11 +11,11 @@ def t(src: SparseTensor) -> SparseTensor:
     over as the CSR-side caches of the result, so ``A.t().t()`` costs nothing more
     (reference transpose.py:7-31)."""
     st = src.storage
-    col_t, row_t, perm = st.csc_index()  # sorted (col, row) straight from the sort when csr2csc is new
-    value = st.value()
+    # sorted (col, row) -- and the values in that order -- straight from the sort when csr2csc is new
+    col_t, row_t, perm, value_t = st.csc_index_value()
     M, N = st.sparse_sizes()
     out = SparseStorage(row=col_t, rowptr=st._colptr, col=row_t,
-                        value=None if value is None else value.index_select(0, perm), sparse_sizes=(N, M),
+                        value=value_t, sparse_sizes=(N, M),
                         rowcount=st._colcount, colptr=st._rowptr, colcount=st._rowcount,
                         csr2csc=st._csc2csr, csc2csr=perm, is_sorted=True, trust_data=True)
     return src.from_storage(out)

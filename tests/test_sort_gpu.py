@@ -1,0 +1,108 @@
+"""The one-sweep radix sort of COO entries (csrc/sort.hip) and the fused duplicate compaction (csrc/coalesce.hip)
+against the numpy restatement of the reference's sort-on-construct / coalesce (oracle/np_oracle.py): packed words
+(position in the low bits) and key + payload pairs, uniform and power-law inputs (skewed digits), the
+device-decided variants on sorted and unsorted input, tile-boundary sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as no
+from pytorch_sparse_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import pytorch_sparse_amd  # noqa: F401
+    return torch.ops.tsamd
+
+
+def _check(ops, row, col, m, n, dev):
+    rs, cs, perm = ops.sort_coo(row.to(dev), col.to(dev), m, n, True)
+    er, ec, ep = no.sort_coo(row.numpy(), col.numpy(), m, n)
+    assert np.array_equal(perm.cpu().numpy(), ep)
+    assert np.array_equal(rs.cpu().numpy(), er) and np.array_equal(cs.cpu().numpy(), ec)
+    p2 = ops.sort_coo(row.to(dev), col.to(dev), m, n, False)[2]  # permutation only (csr2csc)
+    assert np.array_equal(p2.cpu().numpy(), ep)
+    return er, ec, ep
+
+
+@pytest.mark.parametrize('E,m,n', [
+    (8193, 300, 200),                    # just above the one-launch path: 3 tiles, 16-bit keys (packed)
+    (4096 * 5, 1 << 10, 1 << 10),        # whole tiles only
+    (4096 * 5 + 1, 1 << 10, 1 << 10),    # one entry in the last tile
+    (1000003, 500000, 500000),           # 38-bit keys + 20-bit positions: packed, 5 passes
+    (3000000, (1 << 21) + 5, (1 << 21) - 3),   # 22 + 21 bits + 22 > 64? no: 65 -> pairs, 6 passes
+    (200000, 1 << 31, 1 << 30),          # 61-bit keys: pairs, 8 passes
+    (100000, 1, 1),                      # zero key bits: identity
+    (50000, 1, 70000),                   # row bits = 0
+])
+def test_onesweep_sort_bit_exact(dev, ops, E, m, n):
+    g = torch.Generator().manual_seed(E % 1013)
+    row = torch.randint(0, m, (E, ), generator=g)
+    col = torch.randint(0, n, (E, ), generator=g)
+    q = E // 4
+    row[:q], col[:q] = row[q:2 * q].clone(), col[q:2 * q].clone()  # duplicates: stability is visible in perm
+    _check(ops, row, col, m, n, dev)
+
+
+def test_onesweep_sort_power_law_and_hot_digits(dev, ops):
+    """R-MAT edges in generation order (unsorted; the high row digits take a handful of values -- the wave-uniform
+    histogram path) and a degenerate input with ONE distinct key among random ones."""
+    row, col = synth.rmat_edges(20, 4, seed=3)
+    _check(ops, row, col, 1 << 20, 1 << 20, dev)
+    E = 700001
+    g = torch.Generator().manual_seed(1)
+    row = torch.full((E, ), 77)
+    col = torch.full((E, ), 5)
+    hot = torch.randint(0, E, (1000, ), generator=g)
+    row[hot] = torch.randint(0, 100, (1000, ), generator=g)
+    _check(ops, row, col, 100, 100, dev)
+
+
+def test_device_decided_sort_and_probe(dev, ops):
+    E, m, n = 300000, 4000, 5000
+    g = torch.Generator().manual_seed(2)
+    row = torch.randint(0, m, (E, ), generator=g)
+    col = torch.randint(0, n, (E, ), generator=g)
+    er, ec, ep = no.sort_coo(row.numpy(), col.numpy(), m, n)
+    key = row.numpy().astype(np.int64) * n + col.numpy()
+    # unsorted input: probe counts + the sorted outputs
+    rs, cs, perm, counts = ops.sort_coo_auto(row.to(dev), col.to(dev), m, n)
+    assert counts.tolist() == [int((key[1:] < key[:-1]).sum()), int((key[1:] == key[:-1]).sum())]
+    assert np.array_equal(perm.cpu().numpy(), ep) and np.array_equal(rs.cpu().numpy(), er) and np.array_equal(cs.cpu().numpy(), ec)
+    # sorted input (with duplicates): nothing is sorted, the outputs are a copy and the identity
+    srow, scol = torch.from_numpy(er), torch.from_numpy(ec)
+    rs, cs, perm, counts = ops.sort_coo_auto(srow.to(dev), scol.to(dev), m, n)
+    skey = er.astype(np.int64) * n + ec
+    assert counts.tolist() == [0, int((skey[1:] == skey[:-1]).sum())]
+    assert torch.equal(perm.cpu(), torch.arange(E)) and torch.equal(rs.cpu(), srow) and torch.equal(cs.cpu(), scol)
+    # probed variant: the count comes from coo_check
+    for r_, c_, want_p in ((row, col, ep), (srow, scol, np.arange(E))):
+        chk = ops.coo_check(r_.to(dev), c_.to(dev))
+        rs, cs, perm = ops.sort_coo_probed(r_.to(dev), c_.to(dev), m, n, chk)
+        assert np.array_equal(perm.cpu().numpy(), want_p) and np.array_equal(rs.cpu().numpy(), er)
+    # negative ids read as huge maxima (the constructor's range assert then fires)
+    bad = row.clone()
+    bad[12345] = -1
+    chk = ops.coo_check(bad.to(dev), col.to(dev)).tolist()
+    assert chk[2] < 0 or chk[2] >= m
+
+
+@pytest.mark.parametrize('E', [1, 2047, 2048, 2049, 500000, 3000001])
+def test_fused_compaction(dev, ops, E):
+    g = torch.Generator().manual_seed(E)
+    m, n = 3000, 700
+    row = torch.randint(0, m, (E, ), generator=g)
+    col = torch.randint(0, n, (E, ), generator=g)
+    er, ec, _ = no.sort_coo(row.numpy(), col.numpy(), m, n)
+    key = er.astype(np.int64) * n + ec
+    head = np.ones(E, dtype=bool)
+    head[1:] = key[1:] != key[:-1]
+    pos = np.nonzero(head)[0]
+    ru, cu, seg, nnz = ops.coalesce_index(torch.from_numpy(er).to(dev), torch.from_numpy(ec).to(dev))
+    k = int(nnz)
+    assert k == pos.size
+    assert np.array_equal(ru[:k].cpu().numpy(), er[pos]) and np.array_equal(cu[:k].cpu().numpy(), ec[pos])
+    assert np.array_equal(seg[:k + 1].cpu().numpy(), np.append(pos, E))
