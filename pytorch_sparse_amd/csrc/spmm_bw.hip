@@ -671,11 +671,25 @@ static size_t winrec_bytes(int64_t B, int64_t K, int64_t E) {
   return align_up(sizeof(uint32_t) * (size_t)(B * E) * win_record_stride(K), 256);
 }
 
+// grad_mat route of the pull: winner bit masks + the masked merge-path SpMM (default), or -- TSAMD_MINMAX_BW_LISTS=1,
+// K <= 1024 -- compacted winner lists (csrc/spmm_bw_list.hip).  Same-box A/B on the 2^20 R-MAT graph
+// (profiles/r04_minmax_bw_routes.md): the lists move a third of the bytes but issue ~26 instructions per entry and
+// one LDS add per (row, feature) and end up instruction-bound: 2.08 vs 1.78 ms at configs[2] (bf16, F = 128), ahead
+// only for bf16 F = 64 (1.58 vs 1.75) and fp32 F = 256 (4.30 vs 4.43).  Kept as an option, bit-identical results
+// for value-less narrow types, tests/test_spmm_gpu.py runs both.
+static bool use_lists(int dtype, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E) {
+  const char *env = getenv("TSAMD_MINMAX_BW_LISTS");
+  if (env == nullptr || env[0] != '1') return false;
+  return minmax_bw_lists_supported(dtype, B, M, N, K, E);
+}
+
 extern "C" size_t tsamd_spmm_minmax_bw_csc_workspace_bytes(int dtype, int64_t B, int64_t M, int64_t N,
                                                            int64_t K, int64_t E) {
   if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
   // the masked sum runs on the transposed matrix: N rows, M columns
-  return winrec_bytes(B, K, E) + spmm_masked_sum_workspace_bytes(dtype, B, N, M, K, E);
+  const size_t masked = winrec_bytes(B, K, E) + spmm_masked_sum_workspace_bytes(dtype, B, N, M, K, E);
+  const size_t lists = minmax_bw_lists_supported(dtype, B, M, N, K, E) ? minmax_bw_lists_workspace_bytes(dtype, B, M, N, K, E) : 0;
+  return masked > lists ? masked : lists;
 }
 
 extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const int64_t *col,
@@ -694,6 +708,18 @@ extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const 
   if (total > 0 && (!rowptr || !col || !mat || !grad_out || !arg_out)) return TSAMD_ERR_INVALID;
   if (grad_mat && E > 0 && (!colptr || !csr2csc || !row)) return TSAMD_ERR_INVALID;
   const size_t es = dtype_size(dtype);
+  if (grad_mat && total > 0 && E > 0 && B * N * K > 0 && use_lists(dtype, B, M, N, K, E)) {
+    if (!workspace || workspace_bytes < minmax_bw_lists_workspace_bytes(dtype, B, M, N, K, E) ||
+        (uintptr_t)workspace % 256 != 0)
+      return TSAMD_ERR_WORKSPACE;
+    if (grad_value) {  // the row-parallel kernel (per-row LDS slots, plain stores)
+      int st = tsamd_spmm_minmax_bw(dtype, rowptr, col, value, mat, grad_out, arg_out, grad_value, nullptr, B, M, N,
+                                    K, E, nullptr, 0, stream_);
+      if (st != TSAMD_OK) return st;
+    }
+    return minmax_bw_lists(dtype, row, col, value, grad_out, arg_out, colptr, csr2csc, grad_mat, B, M, N, K, E,
+                           workspace, stream);
+  }
   // grad_value as a masked SDDMM over the records needs 16-byte packets; else the row-parallel LDS kernel
   const bool sddmm_ok = grad_value && row && (K * (int64_t)es) % 16 == 0 && ((uintptr_t)mat % 16) == 0 &&
                         ((uintptr_t)grad_out % 16) == 0;

@@ -28,4 +28,12 @@ int spmm_masked_sum(int dtype, const int64_t *rowptr, bool has_value, const int6
                     const uint32_t *records, const void *mat, void *out, int64_t B, int64_t M, int64_t N,
                     int64_t K, int64_t E, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
+// grad_mat of the min / max backward by winner lists (csrc/spmm_bw_list.hip): compacted (feature, product) pairs per
+// entry instead of one grad_out row per entry.  K <= 1024, ids < 2^32.
+bool minmax_bw_lists_supported(int dtype, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E);
+size_t minmax_bw_lists_workspace_bytes(int dtype, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E);
+int minmax_bw_lists(int dtype, const int64_t *row, const int64_t *col, const void *value, const void *grad_out,
+                    const int64_t *arg_out, const int64_t *colptr, const int64_t *csr2csc, void *grad_mat, int64_t B,
+                    int64_t M, int64_t N, int64_t K, int64_t E, void *workspace, hipStream_t stream);
+
 }  // namespace tsamd

@@ -364,9 +364,11 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     deterministic = bool(torch.equal(bw()[1].view(torch.int16), gmat.view(torch.int16)))
     # autograd wiring of the drop-in front-end: adj.matmul(x, 'max').backward(g) takes the pull route
     xr = x.clone().requires_grad_()
-    o2 = A.matmul(xr, 'max')
-    torch.use_deterministic_algorithms(has_value)  # grad_value too: the pull only on request (ops_spmm.cpp), else the fused scatter
+    # grad_value too: the pull only on request (deterministic algorithms, asked for BEFORE the forward: that is when
+    # the front-end decides whether to build and hand over the CSC arrays), else the fused scatter
+    torch.use_deterministic_algorithms(has_value)
     try:
+        o2 = A.matmul(xr, 'max')
         o2.backward(g)
     finally:
         torch.use_deterministic_algorithms(False)

@@ -225,9 +225,73 @@ def _csc_arrays(rp, c, n_cols):
     return colptr, perm, row
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float64])
+def test_minmax_bw_winner_lists_hub_columns(dev, dtype):
+    """The winner-list route of tsamd_spmm_minmax_bw_csc (csrc/spmm_bw_list.hip, TSAMD_MINMAX_BW_LISTS=1, K <= 1024) on a
+    power-law graph whose hub columns span many 256-position waves of the pull kernel (head / tail carries + fix-up)
+    and whose long rows span many 64-entry chunks of the list kernel (offsets of cut rows): against the default route
+    (win masks + masked merge-path SpMM; same arithmetic, other summation order) and against
+    exact integer arithmetic (small integer operands: every sum is exact in fp32, so BOTH routes must agree bit for
+    bit); K up to the tile limit, a batch, value-less, columns without entries."""
+    import os
+    rp, c = synth.rmat_csr(12, 24, seed=11)
+    n, E = 1 << 12, c.numel()
+    deg_col = torch.bincount(c, minlength=n)
+    assert int(deg_col.max()) > 1024 and int((deg_col == 0).sum()) > 0
+    colptr, perm, row = _csc_arrays(rp, c, n)
+    g = torch.Generator().manual_seed(3)
+    for K, batch, has_value in ((128, (), False), (96, (2, ), True), (1024, (), True), (300, (), False)):
+        shape = tuple(batch) + (n, K)
+        x = torch.randint(-8, 9, shape, generator=g).to(dtype)
+        gout = torch.randint(-4, 5, shape, generator=g).to(dtype)
+        v = torch.randint(1, 4, (E, ), generator=g).to(dtype) if has_value else None
+        out, arg = run_gpu(dev, rp, c, v, x, 'max')
+        args = (rp.to(dev), c.to(dev), None if v is None else v.to(dev), x.to(dev), gout.to(dev), arg,
+                colptr.to(dev), perm.to(dev), row.to(dev))
+        _, gm_masks = nat.spmm_minmax_bw_csc(*args, want_value=False, want_mat=True)
+        os.environ['TSAMD_MINMAX_BW_LISTS'] = '1'
+        try:
+            _, gm = nat.spmm_minmax_bw_csc(*args, want_value=False, want_mat=True)
+        finally:
+            del os.environ['TSAMD_MINMAX_BW_LISTS']
+        _, gm_scatter = nat.spmm_minmax_bw(rp.to(dev), c.to(dev), None if v is None else v.to(dev), x.to(dev), gout.to(dev),
+                                           arg, want_value=False, want_mat=True)
+        if dtype == torch.bfloat16:  # sums beyond 256 round: the two pulls (fp32 sums, one rounding) still agree exactly
+            assert bits_equal(gm, gm_masks), (K, batch)
+        else:
+            assert bits_equal(gm, gm_masks) and bits_equal(gm, gm_scatter), (K, batch)
+        # exact reference on the host: scatter of the integer products
+        a = arg.cpu()
+        valid = a != E
+        a0 = a.masked_fill(~valid, 0)
+        term = gout.double() * (v.double()[a0] if has_value else 1.0)
+        term = term.masked_fill(~valid, 0)
+        want = torch.zeros(shape, dtype=torch.float64)
+        if batch:
+            for b in range(batch[0]):
+                want[b].scatter_add_(0, c[a0[b]], term[b])
+        else:
+            want.scatter_add_(0, c[a0], term)
+        if dtype != torch.bfloat16:
+            assert torch.equal(gm.cpu().double(), want), (K, batch)
+        else:
+            assert torch.equal(gm.cpu(), want.to(dtype)), (K, batch)  # exact sum, rounded once
+
+
+@pytest.fixture(params=['masks', 'lists'])
+def pull_route(request):
+    """Both grad_mat routes of tsamd_spmm_minmax_bw_csc: the default (win masks + masked merge-path SpMM) and the
+    winner lists (TSAMD_MINMAX_BW_LISTS=1)."""
+    import os
+    if request.param == 'lists':
+        os.environ['TSAMD_MINMAX_BW_LISTS'] = '1'
+    yield request.param
+    os.environ.pop('TSAMD_MINMAX_BW_LISTS', None)
+
+
 @pytest.mark.parametrize('reduce', ['min', 'max'])
 @pytest.mark.parametrize('dtype', FLOAT_DTYPES)
-def test_minmax_bw_csc_pull(dev, dtype, reduce):
+def test_minmax_bw_csc_pull(dev, dtype, reduce, pull_route):
     """tsamd_spmm_minmax_bw_csc (winner masks + masked merge-path SpMM over the CSC view) against the fp64
     formulas of csrc/spmm.cpp:204-242: fp32 (fp64) accumulation, one rounding -- so well inside the bound of the
     scatter kernel -- deterministic, identical grad_value; rows above and below 64 entries, K that is not a
@@ -274,11 +338,12 @@ def test_minmax_bw_csc_pull(dev, dtype, reduce):
             vr = None if v is None else v.to(dev).requires_grad_()
             A = ts.SparseTensor(rowptr=rp.to(dev), col=c.to(dev), value=vr, sparse_sizes=(n, n), is_sorted=True,
                                 trust_data=True)
-            o = A.matmul(xr, reduce)
-            # grad_mat alone always takes the pull; with grad_value as well only when reproducible gradients are asked for
-            # (the scatter kernel gets grad_value fused: ops_spmm.cpp)
+            # grad_mat alone always takes the pull; with grad_value as well only when reproducible gradients are asked
+            # for -- before the forward, which is when the front-end builds and hands over the CSC arrays (the scatter
+            # kernel gets grad_value fused: ops_spmm.cpp)
             torch.use_deterministic_algorithms(has_value)
             try:
+                o = A.matmul(xr, reduce)
                 o.backward(gout.to(dev))
             finally:
                 torch.use_deterministic_algorithms(False)
