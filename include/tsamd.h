@@ -332,7 +332,9 @@ int tsamd_sort_coo_probed(const int64_t *row, const int64_t *col, int64_t E, int
                           int64_t *row_out, int64_t *col_out, int64_t *perm_out, const int64_t *descents,
                           void *workspace, size_t workspace_bytes, void *stream);
 /* The three sorts above behind one entry, with the entries' values riding along: mode 0 = tsamd_sort_coo, 1 =
- * tsamd_sort_coo_auto (counts [2] written), 2 = tsamd_sort_coo_probed (counts[0] read).  value / value_out
+ * tsamd_sort_coo_auto (counts [2] written), 2 = tsamd_sort_coo_probed (counts[0] read), 3 = tsamd_coo_check +
+ * tsamd_sort_coo_probed in one go: counts [4] = (#descents, #adjacent duplicates, max row id, max col id) written, the
+ * check riding in the sort's first pass over (row, col).  value / value_out
  * (both or neither): arrays of E elements of value_bytes = 4 or 8 bytes; value_out[i] = value[perm_out[i]] is
  * written by the last radix pass (the `value.index_select(0, perm)` of torch_sparse/storage.py:160-161 without a
  * second pass over the permutation).  E < 2^32, bits(M) + bits(N) <= 64. */

@@ -507,16 +507,28 @@ extern "C" int tsamd_sort_coo_values(int mode, const int64_t *row, const int64_t
                                      const void *value, void *value_out, int64_t value_bytes, void *workspace,
                                      size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (E < 0 || M < 0 || N < 0 || mode < 0 || mode > 2 || (mode != 0 && !counts)) return TSAMD_ERR_INVALID;
+  if (E < 0 || M < 0 || N < 0 || mode < 0 || mode > 3 || (mode != 0 && !counts)) return TSAMD_ERR_INVALID;
   if ((value == nullptr) != (value_out == nullptr)) return TSAMD_ERR_INVALID;
   if (value != nullptr && value_bytes != 4 && value_bytes != 8) return TSAMD_ERR_UNSUPPORTED;
   if (E == 0) {
-    if (mode == 1) TSAMD_HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), stream));
+    if (mode == 1 || mode == 3) TSAMD_HIP_TRY(hipMemsetAsync(counts, 0, (mode == 3 ? 4 : 2) * sizeof(int64_t), stream));
     return TSAMD_OK;
   }
   if (!row || !col || !perm_out) return TSAMD_ERR_INVALID;
   if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < tsamd_sort_coo_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
+  if (mode == 3) {
+    // the constructor's range check (max row / col id) rides in the sort's build pass -- except on the one-launch
+    // path and for keys of zero bits, where the check is its own (tiny) launch and the sort runs "probed"
+    if (E <= kSmallSortMax || key_bits_for(M, N) == 0 || (M <= 1 && N <= 1)) {
+      int st = tsamd_coo_check(row, col, E, counts, stream_);
+      if (st != TSAMD_OK) return st;
+      mode = 2;
+    } else {
+      return sort_coo_onesweep(row, col, E, M, N, row_out, col_out, perm_out, nullptr, true, counts, workspace, stream,
+                               value, value_out, (int)value_bytes, true);
+    }
+  }
   if (small_sort_coo(row, col, E, M, N, row_out, col_out, perm_out, mode == 1 ? counts : nullptr, mode != 0, stream)) {
     TSAMD_LAUNCH_CHECK();
     if (value != nullptr)  // the one-launch path has no payload: a gather through the permutation behind it

@@ -119,8 +119,8 @@ std::tuple<Tensor, Tensor, Tensor> sort_coo_probed(Tensor row, Tensor col, int64
   return std::make_tuple(row_s, col_s, perm);
 }
 
-// The three sorts with the entries' values riding along: mode 0 plain | 1 device-decided (probe) | 2 device-decided from
-// counts[0] (tsamd::coo_check) -> (row_sorted, col_sorted, perm, counts, value[perm] or an empty tensor).
+// The sorts with the entries' values riding along: mode 0 plain | 1 device-decided (probe) | 2 device-decided from
+// counts[0] (tsamd::coo_check) | 3 = check + device-decided sort in one go (counts[4]) -> (row_sorted, col_sorted, perm, counts, value[perm] or an empty tensor).
 // 1-D values of 4- or 8-byte elements that need no gradient are written by the sort's last pass
 // (tsamd_sort_coo_values); anything else is gathered through the permutation afterwards (differentiable).
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sort_coo_values(Tensor row, Tensor col, int64_t M, int64_t N,
@@ -128,7 +128,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sort_coo_values(Tensor row, T
   check_index(row, "row");
   check_index(col, "col");
   TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
-  TORCH_CHECK(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+  TORCH_CHECK(mode >= 0 && mode <= 3, "mode must be 0 .. 3");
   c10::hip::HIPGuard guard(row.get_device());
   row = row.contiguous();
   col = col.contiguous();
@@ -142,7 +142,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sort_coo_values(Tensor row, T
     check_index(counts, "counts");
     TORCH_CHECK(counts.numel() >= 1 && counts.is_contiguous(), "counts must hold the number of descents");
   } else {
-    counts = torch::empty({2}, row.options());
+    counts = torch::empty({mode == 3 ? 4 : 2}, row.options());
   }
   Tensor value, value_s = torch::empty({0}, row.options());
   bool fused = false;

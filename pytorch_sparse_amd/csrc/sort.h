@@ -6,7 +6,8 @@ namespace tsamd {
 //   todo (nullable, device): number of descents of the input known from an earlier probe; 0 at run time = nothing to
 //     sort: every kernel returns at once and the finish kernel writes (copy, identity);
 //   probe: the build kernel counts descents / adjacent duplicates itself (counts_out[0..1], device), and the passes
-//     are decided by that count -- a sort decided on the device without a host sync.
+//     are decided by that count -- a sort decided on the device without a host sync.  check4: the probe also takes
+//     the maxima of the ids (as unsigned numbers) into counts_out[2..3] -- the range check of the constructor.
 //   gather_src / gather_dst (nullable): gather_dst[o] = gather_src[perm_out[o]] for arrays of 4- or 8-byte elements,
 //     written by the last pass (the values of the entries ride along instead of a gather through perm_out later).
 // Inputs are not modified; outputs must not alias them.  E < 2^32, bits(M) + bits(N) <= 64.
@@ -15,5 +16,5 @@ bool sort_coo_supported(int64_t E, int64_t M, int64_t N);
 int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_out,
                       int64_t *col_out, int64_t *perm_out, const int64_t *todo, bool probe, int64_t *counts_out,
                       void *workspace, hipStream_t stream, const void *gather_src = nullptr,
-                      void *gather_dst = nullptr, int gather_bytes = 0);
+                      void *gather_dst = nullptr, int gather_bytes = 0, bool check4 = false);
 }  // namespace tsamd

@@ -33,11 +33,19 @@ namespace tsamd {
 namespace {
 
 constexpr int kSortThreads = 256;
+// Entries per thread.  Same-box A/B at 7.5 M entries (packed words): 8 / 12 / 16 / 20 / 24 / 28 / 32 / 40 items ->
+// 0.41 / 0.34 / 0.31 / 0.29 / 0.29 / 0.28 / 0.27 / 0.32 ms per sort: fewer, bigger tiles shorten the look-back chain
+// (it costs ~25 us per pass at 1831 tiles) until two workgroups per CU no longer fit (64 KB of LDS at 32 items);
+// key + payload pairs (12 bytes per entry in LDS) stop at 24 items for the same reason (75 M entries: 3.03 vs 3.18 ms).
 #ifndef TSAMD_SORT_ITEMS
-#define TSAMD_SORT_ITEMS 16
+#define TSAMD_SORT_ITEMS 32
 #endif
-constexpr int kSortItems = TSAMD_SORT_ITEMS;
-constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 entries per workgroup
+#ifndef TSAMD_SORT_ITEMS_PAIRS
+#define TSAMD_SORT_ITEMS_PAIRS 24
+#endif
+template <bool PACKED>
+constexpr int kItemsOf = PACKED ? TSAMD_SORT_ITEMS : TSAMD_SORT_ITEMS_PAIRS;
+constexpr int kMinTile = kSortThreads * (TSAMD_SORT_ITEMS < TSAMD_SORT_ITEMS_PAIRS ? TSAMD_SORT_ITEMS : TSAMD_SORT_ITEMS_PAIRS);
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 constexpr int kMaxPasses = 8;
@@ -48,11 +56,11 @@ constexpr int kMaxPasses = 8;
 #define TSAMD_SORT_TICKET 0
 #endif
 #ifndef TSAMD_SORT_LOOK
-#define TSAMD_SORT_LOOK 4
+#define TSAMD_SORT_LOOK 8
 #endif
 
 // workspace header (zeroed by the one memset of a sort): 64 words
-constexpr int kHdrDescents = 0, kHdrDups = 1, kHdrError = 2;
+constexpr int kHdrDescents = 0, kHdrDups = 1, kHdrError = 2, kHdrMaxRow = 3, kHdrMaxCol = 4;
 [[maybe_unused]] constexpr int kHdrTicket = 8;  // ticket[kMaxPasses], -DTSAMD_SORT_TICKET=1 only
 constexpr int kHdrWords = 64;
 
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
     if (threadIdx.x < kRadix) cnt[p][threadIdx.x] = 0;
   __syncthreads();
   unsigned int desc = 0, dup = 0;
+  unsigned long long mr = 0, mc = 0;  // probe == 2: the range check's maxima (unsigned: a negative id reads as huge)
   const int lane = (int)(threadIdx.x & 63);
   constexpr int kB = 4;  // entries per thread and step: the loads of a step are all in flight together
   for (int64_t base = (int64_t)blockIdx.x * (kBuildThreads * kB); base < n; base += (int64_t)gridDim.x * (kBuildThreads * kB)) {
@@ -119,6 +128,10 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
       }
       if (ok[u]) {
         words[i] = L.packed ? ((key << L.idx_bits) | (unsigned long long)i) : key;
+        if (probe == 2) {
+          mr = (unsigned long long)r[u] > mr ? (unsigned long long)r[u] : mr;
+          mc = (unsigned long long)c[u] > mc ? (unsigned long long)c[u] : mc;
+        }
         if (probe && i > 0) {
           if (lane == 0) {
             pr = row[i - 1];
@@ -164,6 +177,24 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
       for (int ww = 0; ww < kBuildThreads / 64; ++ww) t += s_cnt[threadIdx.x][ww];
       if (t) atomicAdd(&hdr[threadIdx.x == 0 ? kHdrDescents : kHdrDups], (unsigned long long)t);
     }
+    if (probe == 2) {
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long orr = (unsigned long long)lane_xor((int64_t)mr, off), oc = (unsigned long long)lane_xor((int64_t)mc, off);
+        mr = orr > mr ? orr : mr;
+        mc = oc > mc ? oc : mc;
+      }
+      __shared__ unsigned long long s_max[2][kBuildThreads / 64];
+      if (lane == 0) {
+        s_max[0][threadIdx.x >> 6] = mr;
+        s_max[1][threadIdx.x >> 6] = mc;
+      }
+      __syncthreads();
+      if (threadIdx.x < 2) {
+        unsigned long long t = 0;
+        for (int ww = 0; ww < kBuildThreads / 64; ++ww) t = s_max[threadIdx.x][ww] > t ? s_max[threadIdx.x][ww] : t;
+        if (t > hdr[kHdrMaxRow + threadIdx.x]) atomicMax(&hdr[kHdrMaxRow + threadIdx.x], t);
+      }
+    }
   }
 }
 
@@ -197,11 +228,17 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
     const unsigned long long *__restrict__ hist, unsigned long long *__restrict__ tile_state,
     unsigned long long *__restrict__ hdr, unsigned int epoch, const int64_t *__restrict__ todo,
     const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t *__restrict__ counts_out,
-    const void *__restrict__ gather_src, void *__restrict__ gather_dst, int gather_bytes) {
+    const void *__restrict__ gather_src, void *__restrict__ gather_dst, int gather_bytes, int check4) {
+  constexpr int kSortItems = kItemsOf<PACKED>;
+  constexpr int kSortTile = kSortThreads * kSortItems;
   if constexpr (LAST) {  // the probe's counters travel with the last pass (no separate kernel)
     if (counts_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
       counts_out[0] = (int64_t)hdr[kHdrDescents];
       counts_out[1] = (int64_t)hdr[kHdrDups];
+      if (check4) {
+        counts_out[2] = (int64_t)hdr[kHdrMaxRow];
+        counts_out[3] = (int64_t)hdr[kHdrMaxCol];
+      }
     }
   }
   if (todo != nullptr && *todo == 0) {
@@ -447,7 +484,7 @@ struct SortWs {
 
 size_t carve_sort(void *base, int64_t E, SortWs *ws) {
   const size_t n = (size_t)(E > 0 ? E : 1);
-  const size_t ntiles = (n + kSortTile - 1) / kSortTile;
+  const size_t ntiles = (n + kMinTile - 1) / kMinTile;
   char *p = reinterpret_cast<char *>(base);
   size_t off = 0;
   auto take = [&](size_t bytes) -> void * {
@@ -480,7 +517,7 @@ bool sort_coo_supported(int64_t E, int64_t M, int64_t N) {
 int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_out,
                       int64_t *col_out, int64_t *perm_out, const int64_t *todo, bool probe, int64_t *counts_out,
                       void *workspace, hipStream_t stream, const void *gather_src, void *gather_dst,
-                      int gather_bytes) {
+                      int gather_bytes, bool check4) {
   if (E <= 0) return TSAMD_OK;
   if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
   const KeyLayout L = layout_for(E, M, N);
@@ -501,11 +538,11 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
     return TSAMD_OK;
   }
   TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes, stream));
-  const int64_t ntiles = ceil_div(E, kSortTile);
+  const int64_t ntiles = ceil_div(E, kSortThreads * (L.packed ? kItemsOf<true> : kItemsOf<false>));
   {
     const int64_t nb = ceil_div(E, kBuildThreads * 4);
     hipLaunchKernelGGL(sort_build_kernel, dim3((unsigned int)(nb < 512 ? nb : 512)), dim3(kBuildThreads), 0, stream,
-                       row, col, E, L, ws.a, ws.hist, ws.hdr, todo, probe ? 1 : 0);
+                       row, col, E, L, ws.a, ws.hist, ws.hdr, todo, probe ? (check4 ? 2 : 1) : 0);
     TSAMD_LAUNCH_CHECK();
   }
   // the passes of a probing sort are decided by the probe's own counter
@@ -521,7 +558,8 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
   hipLaunchKernelGGL((onesweep_pass_kernel<P, LST>), dim3((unsigned int)ntiles), dim3(kSortThreads), 0, stream, src, \
                      isrc, dst, idst, row_out, col_out, perm_out, E, shift, L, ws.hist + pass * kRadix,              \
                      ws.tile_state, ws.hdr, (unsigned int)(pass + 1), pass_todo, row, col,                          \
-                     (last && probe) ? counts_out : (int64_t *)nullptr, gather_src, gather_dst, gather_bytes)
+                     (last && probe) ? counts_out : (int64_t *)nullptr, gather_src, gather_dst, gather_bytes,          \
+                     check4 ? 1 : 0)
     if (L.packed) {
       if (last) TSAMD_SORT_PASS(true, true);
       else TSAMD_SORT_PASS(true, false);

@@ -1190,6 +1190,10 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
       const char *env = getenv("TSAMD_SPMM_RELABEL");
       mode = env ? (env[0] == '1' ? 1 : (env[0] == '0' ? 0 : 2)) : 2;
     }
+    // masked sums (the pull of the min / max backward): `col` points at winner records, not at column ids, so there
+    // is nothing to probe; same-box A/B at configs[2]: 1.76 ms with the copy, 1.93 without (the rows gathered are
+    // grad_out rows indexed by the R-MAT ROW ids of the forward, which camp like its column ids)
+    if (mode == 2 && ws.wmask != nullptr) mode = 1;
     ws.relabel_mode = mode;
     const bool cached = ws.cache_state != 0 && mode != 0;
     if (mode == 2 && !(cached && ws.cache_state == 2)) {  // (a reused cache keeps the verdict of its first call)

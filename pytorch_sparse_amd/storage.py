@@ -121,10 +121,10 @@ class SparseStorage(object):
         did_sort = False
         if (col.is_cuda and row is not None and rowptr is None and given_m is not None and given_n is not None and
                 not trust_data and not is_sorted and nnz > 1 and csr2csc is None and csc2csr is None):
-            counts_dev = torch.ops.tsamd.coo_check(row.contiguous(), col)
-            # (the values ride along in the sort's last pass when they are plain 4- / 8-byte numbers)
-            presorted_row, presorted_col, perm0, _, vsorted = torch.ops.tsamd.sort_coo_values(
-                row.contiguous(), col, given_m, given_n, 2, counts_dev, value)
+            # order probe + range check ride in the sort's first pass over (row, col); the values ride along in its
+            # last pass when they are plain 4- / 8-byte numbers
+            presorted_row, presorted_col, perm0, counts_dev, vsorted = torch.ops.tsamd.sort_coo_values(
+                row.contiguous(), col, given_m, given_n, 3, None, value)
             if value is not None:
                 presorted_value = vsorted
             # (rowptr too: CSR is what every product reads, and a launch behind the read-back would wait for it)
@@ -145,7 +145,7 @@ class SparseStorage(object):
             if rowptr is not None:
                 assert rowptr.numel() - 1 == M
             elif need_row_max:
-                assert max_row < M
+                assert max_row < M and (max_row >= 0 or not col.is_cuda)  # (the device check takes unsigned maxima: a negative id reads as -1)
         elif rowptr is not None:
             M = rowptr.numel() - 1
         elif row is not None and row.numel() > 0:
@@ -154,7 +154,7 @@ class SparseStorage(object):
         if given_n is not None:
             N = given_n
             if need_col_max:
-                assert max_col < N
+                assert max_col < N and (max_col >= 0 or not col.is_cuda)
         elif nnz > 0:
             N = max_col + 1
         self._sparse_sizes = (M, N)

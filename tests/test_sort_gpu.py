@@ -106,3 +106,27 @@ def test_fused_compaction(dev, ops, E):
     assert k == pos.size
     assert np.array_equal(ru[:k].cpu().numpy(), er[pos]) and np.array_equal(cu[:k].cpu().numpy(), ec[pos])
     assert np.array_equal(seg[:k + 1].cpu().numpy(), np.append(pos, E))
+
+
+@pytest.mark.parametrize('E', [500, 20000])
+def test_constructor_rejects_out_of_range_and_negative_ids(dev, E):
+    """The enqueue-before-check constructor sorts an untrusted COO before its range assert fires (memory-safe:
+    positions come from ranks); the assert must still fire -- for ids >= the size and for negative ids (read as
+    unsigned maxima) -- on the one-launch path (E <= 8192) and on the general path."""
+    import pytorch_sparse_amd as ts
+    g = torch.Generator().manual_seed(E)
+    m, n = 300, 200
+    row = torch.randint(0, m, (E, ), generator=g)
+    col = torch.randint(0, n, (E, ), generator=g)
+    val = torch.rand(E, generator=g)
+    A = ts.SparseTensor(row=row.to(dev), col=col.to(dev), value=val.to(dev), sparse_sizes=(m, n))
+    er, ec, ep = no.sort_coo(row.numpy(), col.numpy(), m, n)
+    r2, c2, v2 = A.coo()
+    assert np.array_equal(r2.cpu().numpy(), er) and np.array_equal(c2.cpu().numpy(), ec)
+    assert np.array_equal(v2.cpu().numpy(), val.numpy()[ep])
+    assert np.array_equal(A.storage.rowptr().cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(er, minlength=m))]))
+    for which, bad in (('row', m), ('row', -1), ('col', n), ('col', -5)):
+        r_, c_ = row.clone(), col.clone()
+        (r_ if which == 'row' else c_)[E // 2] = bad
+        with pytest.raises((AssertionError, RuntimeError)):
+            ts.SparseTensor(row=r_.to(dev), col=c_.to(dev), value=val.to(dev), sparse_sizes=(m, n))
