@@ -487,6 +487,7 @@ class PipelinedHaloSpMM(object):
         self.spmm_into_fn = spmm_into_fn if spmm_into_fn is not None else (
             _default_spmm_into if spmm_fn is None else None)
         self._works, self._keep = [], []
+        self._agreed = {}  # local (grad mode, needs grad) -> the path every rank agreed on (see __call__)
         self.spmm_fn = spmm_fn or _default_spmm
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -545,18 +546,26 @@ class PipelinedHaloSpMM(object):
     def __call__(self, x_local: Tensor, reduce: str = 'sum', differentiable: Optional[bool] = None) -> Tensor:
         """`differentiable`: take the autograd-recording path (its backward issues collectives, so EVERY rank
         must take the same path).  None (default) = any rank needs a gradient: the local verdict (grad mode,
-        requires_grad of X / the values) is agreed on with one all_reduce per call, so that a rank whose inputs
-        happen not to require grad, or that runs under no_grad, cannot leave its peers waiting in a backward
-        collective.  Pass True / False (the same on every rank) to skip that round trip."""
+        requires_grad of X / the values) is agreed on with one all_reduce the FIRST time this plan sees a local
+        state and remembered per state (`_agreed`), so that a rank whose inputs happen not to require grad cannot
+        leave its peers waiting in a backward collective and later calls pay neither the collective nor the
+        read-back.  Ranks that change state out of step with each other must pass True / False explicitly."""
         if self.world == 1:
             p = self.pieces[0]
             return self.spmm_fn(p['rowptr'], p['col'], p['value'], x_local, reduce)
         if differentiable is None:
             needs_grad = torch.is_grad_enabled() and (
                 x_local.requires_grad or any(p['value'] is not None and p['value'].requires_grad for p in self.pieces))
-            flag = torch.tensor([1 if needs_grad else 0], dtype=torch.int32, device=x_local.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-            differentiable = bool(int(flag))
+            # the agreement (a collective + a read-back, which would serialise the pipelined exchange) is made ONCE
+            # per local state and remembered: ranks of an SPMD program change grad mode / requires_grad in lockstep
+            key = (torch.is_grad_enabled(), needs_grad)
+            verdict = self._agreed.get(key)
+            if verdict is None:
+                flag = torch.tensor([1 if needs_grad else 0], dtype=torch.int32, device=x_local.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                verdict = bool(int(flag))
+                self._agreed[key] = verdict
+            differentiable = verdict
         if differentiable:
             return self._differentiable(x_local, reduce)
         buf = x_local.new_empty((self.n_needed, ) + tuple(x_local.shape[1:]))
