@@ -75,6 +75,9 @@ constexpr int RED_MAX = 2;
 #ifndef TSAMD_MINMAX_UNROLL
 #define TSAMD_MINMAX_UNROLL 2
 #endif
+#ifndef TSAMD_MINMAX_SPLIT_LOOP
+#define TSAMD_MINMAX_SPLIT_LOOP 1  // 0: the round-3 loop (value-mode branch inside the step loop), kept for A/B builds
+#endif
 constexpr int kUnroll = TSAMD_UNROLL;      // gathers in flight per group
 constexpr int kMinMaxUnroll = TSAMD_MINMAX_UNROLL;  // min / max carry (value, arg) per element: fewer
 constexpr int kWavesPerBlock = TSAMD_WPB;  // 256-thread workgroups
@@ -309,6 +312,54 @@ __device__ __forceinline__ void accumulate_window(
   constexpr int kU = RED == RED_ADD ? kUnroll : kMinMaxUnroll;
   const int n = hi - lo;
   const int nsteps = (n + (1 << lgG) - 1) >> lgG;
+#if TSAMD_MINMAX_SPLIT_LOOP
+  if constexpr (RED != RED_ADD) {
+    // min / max: one step loop PER value mode (the wave-uniform `has_value` test sits outside the loop).  The
+    // 2-byte instantiations are bound by VALU issue (SQ counters, round 3: ~80 % of the slots at config 3); with the
+    // branch inside the loop the two paths left their results in different registers (6 v_mov at every back edge),
+    // both fetched the window's weights (2 ds_bpermute the value-less path never reads), and the gather address took
+    // a multiply + a shift-add (now one v_mad_u64_u32 on byte units).  Slots past `hi` re-read the row's last entry:
+    // min / max are idempotent, the duplicate carries the same (value, edge id) as the original, so nothing has to be
+    // masked (strict compares: an equal candidate with a larger or equal id never replaces).  Without values the
+    // candidate is the stored element itself: no product, no rounding.
+    const char *matb = reinterpret_cast<const char *>(matk);
+    const uint32_t kbytes = K * (uint32_t)sizeof(T);
+    auto run = [&](auto with_value) __attribute__((always_inline)) {
+      constexpr bool kWV = decltype(with_value)::value;
+      int pos = lo + g;
+      for (int s = 0; s < nsteps; s += kU) {
+        P x[kU];
+        A w[kU];
+        uint32_t id[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int at = pos + (u << lgG);
+          const int src = at < hi ? at : hi - 1;
+          id[u] = wrel + (uint32_t)src;
+          const uint32_t c = lane_read(c_l, src);
+          if constexpr (kWV) w[u] = lane_read(w_l, src);
+          x[u] = *reinterpret_cast<const P *>(matb + (uint64_t)c * kbytes);
+        }
+        pos += kU << lgG;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const A xv = Traits<T>::to_acc(x[u].v[j]);
+            A p = xv;
+            if constexpr (kWV) p = Traits<T>::round_acc(w[u] * xv);
+            const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
+            val[j] = better ? p : val[j];
+            arg[j] = better ? id[u] : arg[j];
+          }
+        }
+      }
+    };
+    if (has_value) run(std::true_type{});  // wave-uniform
+    else run(std::false_type{});
+    return;
+  }
+#endif
   for (int s = 0; s < nsteps; s += kU) {
     P x[kU];
     A w[kU];
