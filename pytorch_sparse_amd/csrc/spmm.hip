@@ -293,6 +293,53 @@ __device__ __forceinline__ void init_acc(typename Traits<T>::acc_t (&val)[VEC], 
   }
 }
 
+// The elements of a gathered packet as accumulator values.  bf16 packets are taken apart dword by dword (low half:
+// one shift, high half: one AND): left to itself the compiler treats an 8-byte packet as ONE 64-bit integer and spends
+// v_alignbit + v_and on the element that starts at bit 32.
+template <typename T, int VEC>
+__device__ __forceinline__ void unpack_packet(const Pack<T, VEC> &x, typename Traits<T>::acc_t (&out)[VEC]) {
+  if constexpr (std::is_same<T, bf16_t>::value && VEC % 2 == 0) {
+#pragma unroll
+    for (int d = 0; d < VEC / 2; ++d) {
+      uint32_t word;
+      __builtin_memcpy(&word, reinterpret_cast<const char *>(&x) + 4 * d, 4);
+      asm volatile("" : "+v"(word));
+      const uint32_t lo = word << 16, hi = word & 0xFFFF0000u;
+      __builtin_memcpy(&out[2 * d], &lo, 4);
+      __builtin_memcpy(&out[2 * d + 1], &hi, 4);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = Traits<T>::to_acc(x.v[j]);
+  }
+}
+
+// w * x rounded to the element type, for the VEC elements of one packet (what `value * mat` is before the reducer
+// sees it, reducer.h:63-67).  bf16: two products per v_cvt_pk_bf16_f32, taken apart again by one shift / one AND.
+template <typename T, int VEC>
+__device__ __forceinline__ void round_products(typename Traits<T>::acc_t w, typename Traits<T>::acc_t (&xv)[VEC]) {
+  if constexpr (std::is_same<T, bf16_t>::value && VEC % 2 == 0) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int d = 0; d < VEC / 2; ++d) {
+      f32x2 pr;
+      pr.x = w * xv[2 * d];
+      pr.y = w * xv[2 * d + 1];
+      const bf16x2 h = __builtin_convertvector(pr, bf16x2);
+      uint32_t word;
+      __builtin_memcpy(&word, &h, 4);
+      asm volatile("" : "+v"(word));
+      const uint32_t lo = word << 16, hi = word & 0xFFFF0000u;
+      __builtin_memcpy(&xv[2 * d], &lo, 4);
+      __builtin_memcpy(&xv[2 * d + 1], &hi, 4);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) xv[j] = Traits<T>::round_acc(w * xv[j]);
+  }
+}
+
 // Accumulate window entries [lo, hi) (window-relative, 0..64) of one row.  `wrel` is the window's
 // offset from the partition's first edge (min/max args are kept as 32-bit offsets).
 // c_l / w_l hold the window's column ids / weights, one per lane.  All lanes
@@ -343,11 +390,12 @@ __device__ __forceinline__ void accumulate_window(
         pos += kU << lgG;
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
+          A xv[VEC];
+          unpack_packet<T, VEC>(x[u], xv);
+          if constexpr (kWV) round_products<T, VEC>(w[u], xv);
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
-            const A xv = Traits<T>::to_acc(x[u].v[j]);
-            A p = xv;
-            if constexpr (kWV) p = Traits<T>::round_acc(w[u] * xv);
+            const A p = xv[j];
             const bool better = RED == RED_MIN ? (p < val[j]) : (p > val[j]);
             val[j] = better ? p : val[j];
             arg[j] = better ? id[u] : arg[j];
@@ -469,11 +517,12 @@ __device__ __forceinline__ void reduce_level(A (&val)[VEC], ARG (&arg)[VEC]) {
       val[j] += o;
     } else {
       const ARG oa = lane_down<OFF>(arg[j]);
+      // bitwise, not short-circuit: as `||` / `&&` this became four exec-mask branches per element (~22
+      // instructions; a row end of the 2-byte min / max kernels spent ~90 of its ~110 instructions here)
       const bool better = RED == RED_MIN ? (o < val[j]) : (o > val[j]);
-      if (better || (o == val[j] && oa < arg[j])) {
-        val[j] = o;
-        arg[j] = oa;
-      }
+      const bool take = better | ((o == val[j]) & (oa < arg[j]));
+      val[j] = take ? o : val[j];
+      arg[j] = take ? oa : arg[j];
     }
   }
 }

@@ -233,12 +233,126 @@ __device__ inline void wave_radix_sort_lds(uint32_t *&ka, A *&va, uint32_t *&kb,
 // ---------------------------------------------------------------------------
 constexpr int kExpandBatch = 4;
 
+#ifndef TSAMD_SPSPMM_OWNER_SCAN
+#define TSAMD_SPSPMM_OWNER_SCAN 1  // 0: the one-wave kernels locate a product's A entry by the 6-step search (round 1-3), for A/B builds
+#endif
+
 template <typename A>
 struct ExpandScratch {
   int off[65];
   int64_t bs[64];
   A av[64];
+  alignas(4) uint8_t own[256];  // expand_row_wave: owner (lane + 1) of each of the 256 products of a batch
 };
+
+// wave64 inclusive scans on the DPP network (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast 15 / 31
+// across them): six VALU instructions, no LDS-pipe round trips (the ds_bpermute form costs six dependent ones).
+// `old` = 0 is the identity of both operations on unsigned values; lanes without a source keep it.
+#define TSAMD_DPP_STEP(OP, CTRL, ROWMASK) \
+  v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false))
+__device__ __forceinline__ uint32_t dpp_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_scan_add_dpp(uint32_t v) {
+  TSAMD_DPP_STEP(dpp_add, 0x111, 0xF);
+  TSAMD_DPP_STEP(dpp_add, 0x112, 0xF);
+  TSAMD_DPP_STEP(dpp_add, 0x114, 0xF);
+  TSAMD_DPP_STEP(dpp_add, 0x118, 0xF);
+  TSAMD_DPP_STEP(dpp_add, 0x142, 0xA);
+  TSAMD_DPP_STEP(dpp_add, 0x143, 0xC);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max_dpp(uint32_t v) {
+  TSAMD_DPP_STEP(dpp_max, 0x111, 0xF);
+  TSAMD_DPP_STEP(dpp_max, 0x112, 0xF);
+  TSAMD_DPP_STEP(dpp_max, 0x114, 0xF);
+  TSAMD_DPP_STEP(dpp_max, 0x118, 0xF);
+  TSAMD_DPP_STEP(dpp_max, 0x142, 0xA);
+  TSAMD_DPP_STEP(dpp_max, 0x143, 0xC);
+  return v;
+}
+#undef TSAMD_DPP_STEP
+
+// One-wave form of expand_row (rows of at most kSmallCap products: the symbolic and numeric kernels of the small
+// rows).  Same contract -- emit(q, col, value) once per product, q = index in expansion order -- but a lane takes FOUR
+// CONSECUTIVE products of a 256-product batch and finds their A entries without searching: every entry that reaches
+// into the batch leaves (its lane + 1) in a byte at the position of its first product there, and a max-scan over the
+// 256 bytes (in-lane over the dword a lane reads back, then the DPP scan across lanes) carries each owner forward to
+// the products behind it.  The 6-step LDS binary search per product that this replaces was 184 of the 448 VALU
+// instructions a row-wave of the symbolic kernel issued at configs[3] (and 24 dependent LDS reads); the kernels
+// are bound by instruction issue (SQ counters, profiles/r03_sq_counters.md).
+template <typename T, bool WITH_VAL, typename Emit>
+__device__ __forceinline__ int expand_row_wave(const int64_t *__restrict__ colA, const T *__restrict__ valA,
+                                               const int64_t *__restrict__ rowptrB,
+                                               const uint32_t *__restrict__ colB, const T *__restrict__ valB,
+                                               int64_t as, int64_t ae,
+                                               ExpandScratch<typename Traits<T>::acc_t> &sc, Emit emit) {
+  using A = typename Traits<T>::acc_t;
+  const int lane = (int)threadIdx.x;
+  uint32_t *own_w = reinterpret_cast<uint32_t *>(sc.own);
+  int filled = 0;
+  for (int64_t e0 = as; e0 < ae; e0 += 64) {
+    const int64_t e = e0 + lane;
+    int64_t bs = 0;
+    int d = 0;
+    A av = A(1);
+    if (e < ae) {
+      const int64_t c = colA[e];
+      bs = rowptrB[c];
+      d = (int)(rowptrB[c + 1] - bs);
+      if (WITH_VAL && valA != nullptr) av = Traits<T>::to_acc(valA[e]);
+    }
+    const int incl = (int)wave_scan_add_dpp((uint32_t)d);
+    const int off = incl - d;
+    sc.off[lane] = off;
+    sc.bs[lane] = bs;
+    if (WITH_VAL) sc.av[lane] = av;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    for (int b0 = 0; b0 < total; b0 += 256) {
+      own_w[lane] = 0u;
+      __syncthreads();  // (one wave: orders the LDS traffic)
+      if (d > 0 && off < b0 + 256 && off + d > b0) sc.own[(off > b0 ? off : b0) - b0] = (uint8_t)(lane + 1);
+      __syncthreads();
+      const uint32_t w = own_w[lane];
+      uint32_t o[4];
+      o[0] = w & 0xFFu;
+      o[1] = (w >> 8) & 0xFFu;
+      o[2] = (w >> 16) & 0xFFu;
+      o[3] = w >> 24;
+      o[1] = o[1] > o[0] ? o[1] : o[0];
+      o[2] = o[2] > o[1] ? o[2] : o[1];
+      o[3] = o[3] > o[2] ? o[3] : o[2];
+      const uint32_t inc = wave_scan_max_dpp(o[3]);
+      // the lanes below me: the inclusive result of lane - 1 (wave_shr:1; lane 0 keeps 0)
+      const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xF, 0xF, false);
+      int64_t src[4];
+      A a[4];
+      const int qbase = b0 + 4 * lane;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int lo = (int)(o[u] > below ? o[u] : below) - 1;  // >= 0: the entry that covers product b0 marked slot 0
+        const int qq = qbase + u;
+        const int q = qq < total ? qq : total - 1;  // (the owner carried into a slot past the end owns total - 1)
+        src[u] = sc.bs[lo] + (q - sc.off[lo]);
+        a[u] = WITH_VAL ? sc.av[lo] : A(1);
+      }
+      uint32_t c[4];
+      A b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        c[u] = colB[src[u]];
+        b[u] = (WITH_VAL && valB != nullptr) ? Traits<T>::to_acc(valB[src[u]]) : A(1);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int qq = qbase + u;
+        if (qq < total) emit(filled + qq, c[u], a[u] * b[u]);
+      }
+    }
+    filled += total;
+    __syncthreads();
+  }
+  return filled;
+}
 
 // LONG_B: the B rows are expected to be long (the large rows of a power-law product: 733 entries on average in
 // the stress case), so a thread's successive products (BLOCK apart) mostly fall into the same A entry as its
@@ -250,6 +364,10 @@ __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, cons
                                           int64_t as, int64_t ae,
                                           ExpandScratch<typename Traits<T>::acc_t> &sc, Emit emit) {
   using A = typename Traits<T>::acc_t;
+#if TSAMD_SPSPMM_OWNER_SCAN
+  if constexpr (BLOCK == 64 && !LONG_B)
+    return expand_row_wave<T, WITH_VAL>(colA, valA, rowptrB, colB, valB, as, ae, sc, emit);
+#endif
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   int filled = 0;
@@ -518,10 +636,12 @@ __device__ __forceinline__ void compress_and_store(int p, int64_t out, int64_t *
       head = idx == 0 || col_at(idx - 1) != c;
     }
     int tot, pos;
+    bool alone = false;  // known without a read: the entry behind this head starts another column
     if constexpr (BLOCK == 64) {  // one wave: positions from the ballot of the heads
       const unsigned long long m = __ballot(head);
       pos = base + __popcll(m & ((1ull << (tid & 63)) - 1ull));
       tot = __popcll(m);
+      alone = ((m >> 1) >> (tid & 63)) & 1ull;  // (lane 63: unknown, the loop below looks)
     } else {
       pos = base + block_exclusive_scan_small<BLOCK / 64>(head ? 1 : 0, sscan, &tot);
     }
@@ -529,7 +649,8 @@ __device__ __forceinline__ void compress_and_store(int p, int64_t out, int64_t *
       colC[out + pos] = (int64_t)c;
       if (valC != nullptr) {
         A acc = val_at(idx);
-        for (int q = idx + 1; q < p && col_at(q) == c; ++q) acc += val_at(q);
+        if (!alone)
+          for (int q = idx + 1; q < p && col_at(q) == c; ++q) acc += val_at(q);
         valC[out + pos] = Traits<T>::from_acc(acc);
       }
     }

@@ -264,6 +264,39 @@ def test_spspmm_vs_torch_sparse_mm(ts, dev):
             assert torch.equal(vC.cpu(), C._values())  # half-integers: sums are exact in any order
 
 
+def test_spspmm_small_rows_many_entries_and_empty_b_rows(ts, dev):
+    """The one-wave expansion (expand_row_wave): rows of A with 1..200 entries -- several 64-entry chunks, products
+    that start past a chunk's first batch -- against rows of B of 0 / 1 / 2 / 3 / 8 / 40 entries (zero-length rows
+    between the others, batches of 256 products that begin inside a B row).  Oracle = torch.sparse.mm on the CPU;
+    half-integer values keep every sum exact."""
+    g = torch.Generator().manual_seed(11)
+    m, k, n = 600, 900, 700
+    lenB = torch.tensor([0, 0, 1, 2, 3, 8, 40])[torch.randint(0, 7, (k, ), generator=g)]
+    rB = torch.repeat_interleave(torch.arange(k), lenB)
+    cB = torch.cat([torch.randperm(n, generator=g)[:int(l)].sort().values for l in lenB.tolist()])
+    lenA = torch.randint(1, 201, (m, ), generator=g)
+    lenA[::7] = 0
+    rA = torch.repeat_interleave(torch.arange(m), lenA)
+    cA = torch.cat([torch.randperm(k, generator=g)[:int(l)].sort().values for l in lenA.tolist()])
+    for dtype in (torch.float32, torch.float64):
+        vA = torch.randint(-4, 5, (rA.numel(), ), generator=g).to(dtype) / 2
+        vB = torch.randint(-4, 5, (rB.numel(), ), generator=g).to(dtype) / 2
+        A = torch.sparse_coo_tensor(torch.stack([rA, cA]), vA, (m, k)).coalesce()
+        B = torch.sparse_coo_tensor(torch.stack([rB, cB]), vB, (k, n)).coalesce()
+        C = torch.sparse.mm(A, B)
+        iC, vC = ts.spspmm(A._indices().to(dev), A._values().to(dev), B._indices().to(dev),
+                           B._values().to(dev), m, k, n)
+        assert torch.equal(iC.cpu(), C._indices())
+        assert torch.equal(vC.cpu(), C._values())
+    # pattern only (the value-less numeric kernel)
+    At = ts.SparseTensor(row=rA.to(dev), col=cA.to(dev), sparse_sizes=(m, k))
+    Bt = ts.SparseTensor(row=rB.to(dev), col=cB.to(dev), sparse_sizes=(k, n))
+    Cp = At @ Bt
+    row, col, val = Cp.coo()
+    assert val is None
+    assert torch.equal(torch.stack([row, col]).cpu(), C._indices())
+
+
 def test_csr2csc_and_t_large(ts, dev):
     from pytorch_sparse_amd import synth
     rp, c = synth.rmat_csr(16, 12, seed=9, device=dev)
