@@ -75,6 +75,9 @@ constexpr int RED_MAX = 2;
 #ifndef TSAMD_MINMAX_UNROLL
 #define TSAMD_MINMAX_UNROLL 2
 #endif
+#ifndef TSAMD_MASKED_SEGMENT_SKIP
+#define TSAMD_MASKED_SEGMENT_SKIP 1  // 0: the masked sum gathers every entry's whole row (round 3), for A/B builds
+#endif
 #ifndef TSAMD_MINMAX_SPLIT_LOOP
 #define TSAMD_MINMAX_SPLIT_LOOP 1  // 0: the round-3 loop (value-mode branch inside the step loop), kept for A/B builds
 #endif
@@ -116,6 +119,10 @@ struct Workspace {
   // value, so that one 32-byte line serves every random access an entry needs
   const uint32_t *wmask;
   uint32_t rec_stride, rec_meta;  // words per record; word offset of (id, value lo, value hi)
+  // word rec_meta + 3 of a record, when the padding leaves one (rec_has_z): bit s = "mask word s is non-zero", i.e.
+  // the 64-byte segment s of the gathered row (32 two-byte features; 128 bytes of 4-byte ones) has a winner in
+  // this entry at all -- segments without one are neither gathered nor is their mask word read
+  int rec_has_z;
   // operand cache (tsamd_spmm_cached): xperm / relabel_flag live in a caller-owned buffer that survives the
   // call; when both pointers are set the copy kernel returns at once if the two fingerprints agree
   const unsigned long long *fp_stored, *fp_new;
@@ -352,7 +359,8 @@ __device__ __forceinline__ void accumulate_window(
     int lo, int hi, uint32_t wrel, uint32_t c_l, typename Traits<T>::acc_t w_l, bool has_value,
     const T *__restrict__ matk, uint32_t K, int lgG, int g,
     typename Traits<T>::acc_t (&val)[VEC], uint32_t (&arg)[VEC], uint32_t e_l = 0,
-    const uint32_t *__restrict__ maskk = nullptr, uint32_t mask_words = 0, uint32_t mask_shift = 0) {
+    const uint32_t *__restrict__ maskk = nullptr, uint32_t mask_words = 0, uint32_t mask_shift = 0,
+    uint32_t z_l = 0xFFFFFFFFu, uint32_t mask_seg = 0) {
   using A = typename Traits<T>::acc_t;
   using P = Pack<T, VEC>;
   // min/max carry (value, arg) per element: fewer gathers in flight keep the VGPR count down
@@ -413,6 +421,7 @@ __device__ __forceinline__ void accumulate_window(
     A w[kU];
     int idx[kU];
     uint32_t mb[MASKED ? kU : 1];
+    [[maybe_unused]] uint32_t cm[MASKED ? kU : 1], em[MASKED ? kU : 1], on[MASKED ? kU : 1];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       idx[u] = lo + ((s + u) << lgG) + g;
@@ -420,9 +429,40 @@ __device__ __forceinline__ void accumulate_window(
       if constexpr (RED != RED_ADD) idx[u] = src;  // see below: min / max need no mask
       const uint32_t c = lane_read(c_l, src);
       w[u] = lane_read(w_l, src);
-      x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
-      if constexpr (MASKED) mb[u] = maskk[(uint64_t)lane_read(e_l, src) * mask_words];
+      if constexpr (MASKED) {
+#if TSAMD_MASKED_SEGMENT_SKIP
+        cm[u] = c;
+        em[u] = lane_read(e_l, src);
+        on[u] = (lane_read(z_l, src) >> mask_seg) & 1u;
+#else
+        x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
+        mb[u] = maskk[(uint64_t)lane_read(e_l, src) * mask_words];
+#endif
+      } else {
+        x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)c * K);
+      }
     }
+#if TSAMD_MASKED_SEGMENT_SKIP
+    if constexpr (MASKED) {
+      // winners are sparse in the entries of long rows (an entry of a row of degree d wins a feature with
+      // probability ~1/d): the record says which of the row's 32-feature segments have one at all, and only
+      // those are gathered (the lanes of an empty segment sit the load out; their mask word reads as zero).
+      // All cross-lane reads of the step come first, then the loads: one LDS-pipe wait per step, not two per gather.
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        asm volatile("" : "+v"(cm[u]), "+v"(em[u]), "+v"(on[u]));
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        x[u] = P{};
+        mb[u] = 0u;
+        if (on[u] != 0u) {
+          x[u] = *reinterpret_cast<const P *>(matk + (uint64_t)cm[u] * K);
+          mb[u] = maskk[(uint64_t)em[u] * mask_words];
+        }
+      }
+    }
+#endif
     if constexpr (RED == RED_ADD && MASKED) {
       // the masked sum is bound by instruction issue as much as by its gathers (twice the instructions of the
       // plain sum per row): the packet's predicate bits become all-ones / all-zero words (v_bfe_i32) that are
@@ -430,6 +470,10 @@ __device__ __forceinline__ void accumulate_window(
       auto add_masked = [&](auto with_value) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
+#if TSAMD_MASKED_SEGMENT_SKIP
+          // no lane of the wave gathered anything for this slot (hub-row entries mostly win nothing): nothing to add
+          if (__ballot(on[u] != 0u) == 0ull) continue;  // wave-uniform
+#endif
           const uint32_t bits = idx[u] < hi ? (mb[u] >> mask_shift) : 0u;
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
@@ -727,10 +771,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
   const uint64_t carry_off = ((uint64_t)b * ws.P + (uint64_t)p) * K + k0;  // [b][p][K]
   // masked sums: this lane's VEC features sit in one 32-bit word of every entry's mask (VEC divides 32)
   const uint32_t *maskk = nullptr;
-  uint32_t mask_shift = 0;
+  uint32_t mask_shift = 0, mask_seg = 0;
   if constexpr (MASKED) {
     maskk = ws.wmask + (uint64_t)b * (uint64_t)E * ws.rec_stride + (kok ? (k0 >> 5) : 0u);
     mask_shift = kok ? (k0 & 31u) : 0u;
+    mask_seg = kok ? (k0 >> 5) : 0u;
   }
 
   // the first row may have been started by an earlier partition
@@ -741,11 +786,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
   uint32_t c_cur, c_nxt;
   A w_cur, w_nxt;
   uint32_t e_cur = 0, e_nxt = 0;  // MASKED only: the entries' ids (index of their mask)
-  auto load_window = [&](int64_t base, uint32_t &c_l, A &w_l, uint32_t &e_l) {
+  uint32_t z_cur = 0xFFFFFFFFu, z_nxt = 0xFFFFFFFFu;  // MASKED only: which mask words of the entry are non-zero
+  auto load_window = [&](int64_t base, uint32_t &c_l, A &w_l, uint32_t &e_l, uint32_t &z_l) {
     const int64_t e = base + lane;
     c_l = 0;
     w_l = A(1);
-    if constexpr (MASKED) e_l = 0;
+    if constexpr (MASKED) {
+      e_l = 0;
+      z_l = 0xFFFFFFFFu;
+    }
     if (e < e1) {
       const int64_t src_e = ws.perm != nullptr ? ws.perm[e] : e;  // windows are fetched two ahead:
       if constexpr (MASKED) {                                      // the indirection is off the critical path
@@ -762,6 +811,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
           }
         }
         e_l = (uint32_t)src_e;
+        if (ws.rec_has_z) z_l = rec[3];
       } else {
         c_l = (uint32_t)col[src_e];
         if (value != nullptr) w_l = Traits<T>::to_acc(value[src_e]);
@@ -769,8 +819,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
       if (relabel) c_l = hash_row(c_l, (uint32_t)N, ws.hash_bits, ws.hash_mul, ws.hash_shift);
     }
   };
-  load_window(wbase, c_cur, w_cur, e_cur);
-  load_window(wbase + kWave, c_nxt, w_nxt, e_nxt);
+  load_window(wbase, c_cur, w_cur, e_cur, z_cur);
+  load_window(wbase + kWave, c_nxt, w_nxt, e_nxt, z_nxt);
 
   // row ends: lane j holds rowptr[rp_base + 1 + j]
   int64_t rp_base = r0;
@@ -915,14 +965,14 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
     while (short_rows()) {
     }
     wbase = e;
-    load_window(wbase, c_cur, w_cur, e_cur);
-    load_window(wbase + kWave, c_nxt, w_nxt, e_nxt);
+    load_window(wbase, c_cur, w_cur, e_cur, z_cur);
+    load_window(wbase + kWave, c_nxt, w_nxt, e_nxt, z_nxt);
     return true;
   };
 
   // rows (or row pieces) inside the window [wbase, wbase + 64): 0 = window exhausted, 1 = partition done,
   // 2 = a batch of short rows was processed side by side and the windows were re-based (start over)
-  auto process_window = [&](const uint32_t c_w, const A w_w, const uint32_t e_w) __attribute__((always_inline)) -> int {
+  auto process_window = [&](const uint32_t c_w, const A w_w, const uint32_t e_w, const uint32_t z_w) __attribute__((always_inline)) -> int {
     const int64_t wend_raw = wbase + kWave;
     const int64_t wend = wend_raw < e1 ? wend_raw : e1;
     for (;;) {
@@ -943,7 +993,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
       if (e < stop) {
         accumulate_window<T, VEC, RED, MASKED>((int)(e - wbase), (int)(stop - wbase), (uint32_t)(wbase - e0),
                                                c_w, w_w, has_value, matk, K, lgG, g, val, arg, e_w, maskk,
-                                               ws.rec_stride, mask_shift);
+                                               ws.rec_stride, mask_shift, z_w, mask_seg);
         e = stop;
       }
       if (e < rend) return 0;  // window exhausted inside the row
@@ -971,15 +1021,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
   };
   if (!incoming) short_row_batches();  // the partition starts at a row start
   for (;;) {
-    int st = process_window(c_cur, w_cur, e_cur);
+    int st = process_window(c_cur, w_cur, e_cur, z_cur);
     if (st == 1) break;
     if (st == 2) continue;
-    load_window(wbase + 2 * kWave, c_cur, w_cur, e_cur);
+    load_window(wbase + 2 * kWave, c_cur, w_cur, e_cur, z_cur);
     wbase += kWave;
-    st = process_window(c_nxt, w_nxt, e_nxt);
+    st = process_window(c_nxt, w_nxt, e_nxt, z_nxt);
     if (st == 1) break;
     if (st == 2) continue;
-    load_window(wbase + 2 * kWave, c_nxt, w_nxt, e_nxt);
+    load_window(wbase + 2 * kWave, c_nxt, w_nxt, e_nxt, z_nxt);
     wbase += kWave;
   }
   // tail: the piece of the unfinished row r1 that falls into this partition
@@ -1252,6 +1302,7 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.perm = nullptr;
   w.wmask = nullptr;
   w.rec_stride = w.rec_meta = 0;
+  w.rec_has_z = 0;
   w.fp_stored = w.fp_new = nullptr;
   w.cache_fp = nullptr;
   w.cache_state = 0;
@@ -1473,6 +1524,7 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
     ws.wmask = wmask;
     ws.rec_stride = win_record_stride(K);
     ws.rec_meta = (uint32_t)ceil_div(K, 32);
+    ws.rec_has_z = (ws.rec_meta <= 32u && ((ws.rec_meta + 3u) & 3u) != 0u) ? 1 : 0;  // a padding word behind (id, value)
   }
   const size_t es = dtype_size(dtype);
   int vec = es <= 2 ? 4 : (int)(16 / es);  // widest packet for the type (see dispatch_spmm)

@@ -406,6 +406,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
   for (int64_t b = 0; b < B; ++b) {
     const int64_t *a_b = arg_out + (uint64_t)b * M * K;
     uint32_t *rec_l = rec + ((uint64_t)b * (uint64_t)E + (uint64_t)(e0 + lane)) * S;
+    uint32_t z = 0;  // bit s: mask word s of this entry is non-zero (words 0..31; the masked sum skips the others' segments)
     for (uint32_t t0 = 0; t0 < ntiles; t0 += 2) {
       if (mine) *reinterpret_cast<u32x4 *>(tile + lane * 4) = u32x4{0u, 0u, 0u, 0u};
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -435,6 +436,8 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
       __builtin_amdgcn_wave_barrier();
       if (mine) {
         const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + lane * 4);
+        if (2u * t0 < 32u)  // (words past W stay zero in the tile)
+          z |= ((v.x != 0u ? 1u : 0u) | (v.y != 0u ? 2u : 0u) | (v.z != 0u ? 4u : 0u) | (v.w != 0u ? 8u : 0u)) << (2u * t0);
         uint32_t *dst = rec_l + 2u * t0;
         const uint32_t left = W - 2u * t0;  // mask words of this entry from tile t0 on (>= 1)
         if (left >= 4) {
@@ -450,11 +453,12 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
     }
     if (mine) {  // the entry's row id and value behind its mask
       if ((W & 3u) == 0) {
-        *reinterpret_cast<u32x4 *>(rec_l + W) = u32x4{m_l, vlo, vhi, 0u};
+        *reinterpret_cast<u32x4 *>(rec_l + W) = u32x4{m_l, vlo, vhi, z};
       } else {
         rec_l[W] = m_l;
         rec_l[W + 1] = vlo;
         rec_l[W + 2] = vhi;
+        if (((W + 3u) & 3u) != 0u) rec_l[W + 3] = z;  // the record's padding word, when it has one
       }
     }
   }

@@ -13,6 +13,8 @@ namespace tsamd {
 //   words [0, W)   W = ceil(K / 32): bit (k % 32) of word k / 32 = (arg_out[b, row(e), k] == e)
 //   word  W        row(e)                       (the "column" of e in the transposed product)
 //   words W+1, W+2 value[e] as accumulator bits (fp32; fp64 uses both), 1.0 when the matrix has no values
+//   word  W+3      when the padding leaves it ((W + 3) % 4 != 0): bit s = (word s != 0), s < 32 -- which 32-feature
+//                  segments of the gathered row have a winner in this entry at all
 // padded to a multiple of 4 words, so that a 32-byte record (K <= 160) never straddles a 64-byte line and
 // ONE line serves the three random accesses an entry needs.
 static inline uint32_t win_record_stride(int64_t K) {
