@@ -280,22 +280,33 @@ __device__ __forceinline__ uint32_t wave_scan_max_dpp(uint32_t v) {
 // the products behind it.  The 6-step LDS binary search per product that this replaces was 184 of the 448 VALU
 // instructions a row-wave of the symbolic kernel issued at configs[3] (and 24 dependent LDS reads); the kernels
 // are bound by instruction issue (SQ counters, profiles/r03_sq_counters.md).
-template <typename T, bool WITH_VAL, typename Emit>
+// PRE: the caller already holds the per-lane (start of the B row, its length, value of the A entry) of a row of at
+// most 64 entries -- the persistent kernels below fetch them a row ahead (RowPipe).
+template <typename T, bool WITH_VAL, bool PRE = false, typename Emit>
 __device__ __forceinline__ int expand_row_wave(const int64_t *__restrict__ colA, const T *__restrict__ valA,
                                                const int64_t *__restrict__ rowptrB,
                                                const uint32_t *__restrict__ colB, const T *__restrict__ valB,
                                                int64_t as, int64_t ae,
-                                               ExpandScratch<typename Traits<T>::acc_t> &sc, Emit emit) {
+                                               ExpandScratch<typename Traits<T>::acc_t> &sc, Emit emit,
+                                               int64_t pre_bs = 0, int pre_d = 0,
+                                               typename Traits<T>::acc_t pre_av = typename Traits<T>::acc_t(1)) {
   using A = typename Traits<T>::acc_t;
   const int lane = (int)threadIdx.x;
   uint32_t *own_w = reinterpret_cast<uint32_t *>(sc.own);
   int filled = 0;
-  for (int64_t e0 = as; e0 < ae; e0 += 64) {
+  // PRE: exactly one chunk (the caller sends rows of more than 64 entries through the loading form): no load of
+  // this function then sits in a loop around the gathers, where the compiler's wait-count bookkeeping would make
+  // the gathers wait for the caller's prefetches first
+  for (int64_t e0 = as; e0 < (PRE ? (as < ae ? as + 1 : as) : ae); e0 += 64) {
     const int64_t e = e0 + lane;
     int64_t bs = 0;
     int d = 0;
     A av = A(1);
-    if (e < ae) {
+    if constexpr (PRE) {
+      bs = pre_bs;
+      d = pre_d;
+      av = pre_av;
+    } else if (e < ae) {
       const int64_t c = colA[e];
       bs = rowptrB[c];
       d = (int)(rowptrB[c + 1] - bs);
@@ -346,6 +357,15 @@ __device__ __forceinline__ int expand_row_wave(const int64_t *__restrict__ colA,
       for (int u = 0; u < 4; ++u) {
         const int qq = qbase + u;
         if (qq < total) emit(filled + qq, c[u], a[u] * b[u]);
+      }
+      // every gather of the batch has landed before the next batch (or the caller) goes on: without this a lane
+      // whose product lies past the end never reads its register, the load stays "pending" on the loop's back edge,
+      // and the compiler parks a full wait at the TOP of the batch loop -- in front of the gathers, where it also
+      // waits for the caller's prefetches of the next rows
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        asm volatile("" ::"v"(c[u]));
+        if constexpr (WITH_VAL) asm volatile("" ::"v"(b[u]));
       }
     }
     filled += total;
@@ -493,6 +513,164 @@ __global__ __launch_bounds__(BLOCK) void spspmm_symbolic_kernel(
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// Persistent one-wave kernels over the small rows, software-pipelined across rows.
+//
+// A row costs a chain of dependent round trips before its first product can be gathered: prod / rowptrA (uniform)
+// -> colA -> rowptrB -> colB.  With one row per workgroup (rounds 1-3) every wave sat through that chain alone:
+// after the owner scan took the instruction count down, the SQ counters showed the symbolic kernel 61 % of its
+// time parked on a wait with 46 % of the VALU slots used (profiles/r04_sq_counters.md) -- at 8 waves per SIMD the
+// device holds ~8 k rows in flight, and 500 k rows x 4 round trips / 8 k is most of the kernel's time.
+// Here a wave takes rows blockIdx.x, + gridDim.x, ... and keeps THREE future rows in flight: at the top of every
+// iteration it issues rowptrB of the next row (whose colA arrived during the previous iteration), colA (+ valA)
+// of the one after (whose rowptrA arrived ...) and prod / rowptrA (/ rowptrC) of the third -- one stage per row,
+// all in the same round trip as the current row's own gathers.
+// ---------------------------------------------------------------------------
+// MEASURED NEGATIVE (round 4, same box, profiles/r04_ab_spspmm_row_pipe.log): config 4 1.48 -> 1.80-1.82 ms (symbolic
+// 448 -> 532 us, numeric 844 -> 1085 us under the counter pass).  The per-row time of a wave did not move (7.3 -> 7.6 us):
+// what the SQ counters report as "waiting" is the row's LDS traffic and the LDS / VALU pipes shared with the other 7
+// waves of the SIMD (VALU 3.4 us + LDS ~2-3 us of a 7.3 us round at 8 waves per SIMD), not the four global round
+// trips -- those are already covered by the other waves.  On top, a persistent launch of 28 one-wave workgroups per CU
+// does not fit the numeric kernel's 5.9 KB of LDS 28 times (27 do): the 28th waits for a whole wave-lifetime.  Kept
+// behind the macro (default OFF) as the record of the experiment.
+#ifndef TSAMD_SPSPMM_ROW_PIPE
+#define TSAMD_SPSPMM_ROW_PIPE 0
+#endif
+#ifndef TSAMD_SPSPMM_PIPE_WAVES
+#define TSAMD_SPSPMM_PIPE_WAVES 28  // workgroups (= waves) per CU of the persistent launch (LDS: ~5.5-6 KB each of 160 KB)
+#endif
+
+#if TSAMD_SPSPMM_ROW_PIPE
+template <typename T, bool WITH_VAL>
+struct RowPipe {
+  using A = typename Traits<T>::acc_t;
+  // uniform per row: row id, entries [as, ae), products (RAW: whether the row is a small one is only looked at an
+  // iteration after the load was issued -- nothing in issue() may consume what it just asked for), output position
+  struct Head {
+    int64_t row, as, ae, out, pp;
+    __device__ __forceinline__ int p() const { return (pp > 0 && pp <= kSmallCap) ? (int)pp : 0; }
+  };
+  const int64_t *rowptrA, *colA, *rowptrB, *prod, *rowptrC;
+  const T *valA;
+  int64_t M, stride;
+  int lane;
+  Head h0, h1, h2;          // current row, next, the one after
+  uint32_t c1 = 0, c2 = 0;  // first 64 column ids of the rows h1 / h2 (per lane)
+  A av0 = A(1), av1 = A(1), av2 = A(1);
+  int64_t bs0 = 0;
+  int d0 = 0;
+
+  __device__ __forceinline__ Head fetch_head(int64_t r) const {  // stage 1: uniform loads
+    Head h{r, 0, 0, 0, 0};
+    if (r < M) {
+      h.pp = prod[r];
+      h.as = rowptrA[r];
+      h.ae = rowptrA[r + 1];
+      if (rowptrC != nullptr) h.out = rowptrC[r];
+    }
+    return h;
+  }
+  __device__ __forceinline__ void fetch_cols(const Head &h, uint32_t &c, A &av) const {  // stage 2
+    c = 0;
+    av = A(1);
+    const int64_t e = h.as + lane;
+    // (only dwords that stay live until rotate() are asked for: a dead half of a 64-bit load is a register the
+    // allocator hands out again at once, and writing it waits for the load -- the prefetch would stall at issue)
+    if (h.p() != 0 && e < h.ae) {
+      c = *reinterpret_cast<const uint32_t *>(colA + e);  // low half: column ids are < 2^32
+      if (WITH_VAL && valA != nullptr) av = Traits<T>::to_acc(valA[e]);
+    }
+  }
+  __device__ __forceinline__ void fetch_brow(const Head &h, uint32_t c, int64_t &bs, uint32_t &be_lo) const {  // stage 3
+    bs = 0;
+    be_lo = 0;
+    if (h.p() != 0 && h.as + lane < h.ae) {
+      bs = rowptrB[c];
+      be_lo = *reinterpret_cast<const uint32_t *>(rowptrB + (int64_t)c + 1);  // a B row has < 2^31 entries
+    }
+  }
+  __device__ __forceinline__ void start(int64_t first) {
+    h0 = fetch_head(first);
+    h1 = fetch_head(first + stride);
+    h2 = fetch_head(first + 2 * stride);
+    uint32_t c0;
+    fetch_cols(h0, c0, av0);
+    fetch_cols(h1, c1, av1);
+    uint32_t be0;
+    fetch_brow(h0, c0, bs0, be0);
+    d0 = (int)(be0 - (uint32_t)bs0);
+  }
+  // top of an iteration: one stage for each of the three rows behind the current one (loads only)
+  struct Next {
+    Head h3;
+    int64_t bs1;
+    uint32_t be1;
+  };
+  __device__ __forceinline__ Next issue() {
+    Next n;
+    fetch_brow(h1, c1, n.bs1, n.be1);
+    fetch_cols(h2, c2, av2);
+    n.h3 = fetch_head(h2.row + stride);
+    return n;
+  }
+  __device__ __forceinline__ void rotate(const Next &n) {
+    h0 = h1;
+    bs0 = n.bs1;
+    d0 = (int)(n.be1 - (uint32_t)n.bs1);
+    av0 = av1;
+    h1 = h2;
+    c1 = c2;
+    av1 = av2;
+    h2 = n.h3;
+  }
+};
+
+__global__ __launch_bounds__(64) void spspmm_symbolic_small_kernel(
+    const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
+    const int64_t *__restrict__ rowptrB, const uint32_t *__restrict__ colB,
+    const int64_t *__restrict__ prod, int64_t M, int64_t *__restrict__ nnzC) {
+  constexpr int LOG_T = 10, kT = 1 << LOG_T;
+  __shared__ alignas(16) uint32_t tab[kT];
+  __shared__ ExpandScratch<float> sc;
+  const int lane = (int)threadIdx.x;
+  RowPipe<float, false> pipe{rowptrA, colA, rowptrB, prod, nullptr, nullptr, M, (int64_t)gridDim.x, lane};
+  pipe.start((int64_t)blockIdx.x);
+  while (pipe.h0.row < M) {
+    const auto nxt = pipe.issue();
+    if (pipe.h0.p() != 0) {  // wave-uniform
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int t = 0; t < kT / 256; ++t)
+        *reinterpret_cast<u32x4 *>(tab + 4 * (lane + 64 * t)) = u32x4{kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey};
+      __syncthreads();
+      int fresh = 0;
+      auto insert = [&](int, uint32_t c, float) {
+        uint32_t h = (c * 0x9E3779B1u) >> (32 - LOG_T);
+        for (;;) {
+          const uint32_t old = atomicCAS(&tab[h], kEmptyKey, c);
+          if (old == kEmptyKey) {
+            ++fresh;
+            break;
+          }
+          if (old == c) break;
+          h = (h + 1) & (kT - 1);
+        }
+      };
+      if (pipe.h0.ae - pipe.h0.as <= 64)  // wave-uniform; the prefetched chunk is the whole row
+        expand_row_wave<float, false, true>(colA, nullptr, rowptrB, colB, nullptr, pipe.h0.as, pipe.h0.ae, sc, insert,
+                                            pipe.bs0, pipe.d0, 1.0f);
+      else
+        expand_row_wave<float, false, false>(colA, nullptr, rowptrB, colB, nullptr, pipe.h0.as, pipe.h0.ae, sc, insert);
+      fresh = (int)wave_scan_add_dpp((uint32_t)fresh);
+      if (lane == 63) nnzC[pipe.h0.row] = fresh;
+      __syncthreads();
+    }
+    pipe.rotate(nxt);
+  }
+}
+
+#endif  // TSAMD_SPSPMM_ROW_PIPE
 
 // ---------------------------------------------------------------------------
 // wave-level bitonic sort of 64 * I unique 32-bit keys held in registers, element
@@ -702,6 +880,65 @@ __global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
       p, rowptrC[i], colC, valC, sscan, [&](int idx) { return skey[idx] >> kIdxBits; },
       [&](int idx) { return sval[skey[idx] & (uint32_t)(kSmallCap - 1)]; });
 }
+
+#if TSAMD_SPSPMM_ROW_PIPE
+// The same kernel, persistent and pipelined over the rows (RowPipe above).
+template <typename T>
+__global__ __launch_bounds__(64) void spspmm_numeric_small_pipe_kernel(
+    const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
+    const T *__restrict__ valA, const int64_t *__restrict__ rowptrB,
+    const uint32_t *__restrict__ colB, const T *__restrict__ valB,
+    const int64_t *__restrict__ prod, const int64_t *__restrict__ rowptrC, int64_t M,
+    int64_t *__restrict__ colC, T *__restrict__ valC) {
+  using A = typename Traits<T>::acc_t;
+  __shared__ alignas(16) uint32_t skey[kSmallCap];
+  __shared__ A sval[kSmallCap];
+  __shared__ ExpandScratch<A> sc;
+  __shared__ int sscan[8];
+  const int lane = (int)threadIdx.x;
+  const bool with_val = valC != nullptr;
+  auto row_body = [&](auto wv, RowPipe<T, decltype(wv)::value> &pipe) __attribute__((always_inline)) {
+    constexpr bool kWV = decltype(wv)::value;
+    pipe.start((int64_t)blockIdx.x);
+    while (pipe.h0.row < M) {
+      const auto nxt = pipe.issue();
+      const int p = pipe.h0.p();
+      if (p != 0) {  // wave-uniform
+        const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : 8));  // keys per lane
+        for (int q = p + lane; q < 64 * items; q += 64) skey[q] = kEmptyKey;   // padding sorts last
+        auto put = [&](int q, uint32_t c, A v) {
+          skey[q] = (c << kIdxBits) | (uint32_t)q;
+          if constexpr (kWV) sval[q] = v;
+        };
+        if (pipe.h0.ae - pipe.h0.as <= 64)  // wave-uniform; the prefetched chunk is the whole row
+          expand_row_wave<T, kWV, true>(colA, valA, rowptrB, colB, valB, pipe.h0.as, pipe.h0.ae, sc, put, pipe.bs0,
+                                        pipe.d0, pipe.av0);
+        else
+          expand_row_wave<T, kWV, false>(colA, valA, rowptrB, colB, valB, pipe.h0.as, pipe.h0.ae, sc, put);
+        __syncthreads();
+        if (items == 1) sort_lds_keys<1>(skey, lane);
+        else if (items == 2) sort_lds_keys<2>(skey, lane);
+        else if (items == 4) sort_lds_keys<4>(skey, lane);
+        else sort_lds_keys<8>(skey, lane);
+        __syncthreads();
+        compress_and_store<T, 64>(
+            p, pipe.h0.out, colC, valC, sscan, [&](int idx) { return skey[idx] >> kIdxBits; },
+            [&](int idx) { return sval[skey[idx] & (uint32_t)(kSmallCap - 1)]; });
+        __syncthreads();
+      }
+      pipe.rotate(nxt);
+    }
+  };
+  if (with_val) {
+    RowPipe<T, true> pipe{rowptrA, colA, rowptrB, prod, rowptrC, valA, M, (int64_t)gridDim.x, lane};
+    row_body(std::true_type{}, pipe);
+  } else {
+    RowPipe<T, false> pipe{rowptrA, colA, rowptrB, prod, rowptrC, nullptr, M, (int64_t)gridDim.x, lane};
+    row_body(std::false_type{}, pipe);
+  }
+}
+
+#endif  // TSAMD_SPSPMM_ROW_PIPE
 
 // ---------------------------------------------------------------------------
 // numeric, (column, value) pairs sorted in LDS: medium rows (256 threads, bitonic) and small
@@ -1331,6 +1568,27 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, int64_t N, size
   return off;
 }
 
+unsigned int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  return (unsigned int)cus;
+}
+
+#if TSAMD_SPSPMM_ROW_PIPE
+// one-wave workgroups of the pipelined small-row kernels: as many as the device holds at once, never more than rows
+unsigned int pipe_blocks(int64_t M) {
+  const int64_t cap = (int64_t)device_cus() * TSAMD_SPSPMM_PIPE_WAVES;
+  return (unsigned int)(M < cap ? (M > 0 ? M : 1) : cap);
+}
+#endif
+
 unsigned int persistent_blocks() {
   static int cus = 0;  // the LDS footprint allows TSAMD_SPSPMM_ACCUM_WGS workgroups per CU
   if (cus == 0) {
@@ -1437,10 +1695,15 @@ int numeric_rows(const int64_t *rowptrA, const int64_t *colA, const void *valA, 
   const T *vb = reinterpret_cast<const T *>(valB);
   T *vc = reinterpret_cast<T *>(valC);
   {  // small rows: all M rows in natural order, the kernel skips the others
-    if (bits + kIdxBits <= 32)
+    if (bits + kIdxBits <= 32) {
+#if TSAMD_SPSPMM_ROW_PIPE
+      hipLaunchKernelGGL((spspmm_numeric_small_pipe_kernel<T>), dim3(pipe_blocks(M)), dim3(64), 0, stream,
+                         rowptrA, colA, va, rowptrB, colB, vb, prod, rowptrC, M, colC, vc);
+#else
       hipLaunchKernelGGL((spspmm_numeric_small_kernel<T>), dim3((unsigned int)M), dim3(64), 0, stream,
                          rowptrA, colA, va, rowptrB, colB, vb, prod, rowptrC, colC, vc);
-    else
+#endif
+    } else
       hipLaunchKernelGGL((spspmm_numeric_pairs_kernel<T, 64, kSmallCap>), dim3((unsigned int)M), dim3(64),
                          0, stream, rowptrA, colA, va, rowptrB, colB, vb, prod, bins, rowptrC, colC, vc,
                          passes);
@@ -1516,8 +1779,13 @@ extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const in
   if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(dtype, n_large, P_large, N)))
     return TSAMD_ERR_WORKSPACE;
   TSAMD_HIP_TRY(hipMemsetAsync(nnzC, 0, sizeof(int64_t) * (size_t)M, stream));
+#if TSAMD_SPSPMM_ROW_PIPE
+  hipLaunchKernelGGL(spspmm_symbolic_small_kernel, dim3(pipe_blocks(M)), dim3(64), 0, stream, rowptrA, colA,
+                     rowptrB, colB, prod, M, nnzC);
+#else
   hipLaunchKernelGGL((spspmm_symbolic_kernel<64, 10>), dim3((unsigned int)M), dim3(64), 0, stream, rowptrA,
                      colA, rowptrB, colB, prod, bins, nnzC);
+#endif
   TSAMD_LAUNCH_CHECK();
   if (n_medium > 0) {
     hipLaunchKernelGGL((spspmm_symbolic_kernel<256, kMediumLogT>), dim3((unsigned int)n_medium), dim3(256), 0,

@@ -29,11 +29,15 @@ def storage_spmm(st: SparseStorage, other: Tensor, reduce: str) -> Tuple[Tensor,
         value = value.to(other.dtype)
     if reduce == 'min' or reduce == 'max':
         # the CSC arrays (a radix sort on first use) are only built when the pull backward will really run:
-        # a gradient w.r.t. `other` is being recorded, and either the values need none (with grad_value the
-        # backward takes the fused scatter kernel) or deterministic algorithms are asked for
+        # a gradient w.r.t. `other` is being recorded, and either the values need none, or deterministic
+        # algorithms are asked for, or the rows are 2-byte types of >= 128 features -- there the pull (winner
+        # records + masked SDDMM + masked sum that skips segments without winners) beats the fused scatter
+        # kernel also WITH grad_value since round 4 (configs[2]: 2.38 vs 2.54 ms; fp32 F = 128: 3.30 vs 2.97,
+        # bf16 F = 64: 1.98 vs 1.33 -- those keep the scatter; profiles/r04_minmax_bw_wave_skip.log)
         pull = other.requires_grad and torch.is_grad_enabled()
         if pull and value is not None and value.requires_grad:
-            pull = torch.ops.tsamd.deterministic()
+            narrow = other.dtype == torch.bfloat16 or other.dtype == torch.float16
+            pull = torch.ops.tsamd.deterministic() or (narrow and other.size(-1) >= 128)
         if pull:
             # training: hand the CSC arrays over (cached in the storage, as for sum) so that grad_mat is
             # pulled column by column instead of scattered with atomics (tsamd_spmm_minmax_bw_csc)
