@@ -70,24 +70,37 @@ _PMC = None
 
 def pmc_traffic(workload, kernel_substr):
     """Counter-measured fabric bytes per call of one kernel (FETCH_SIZE x 2 + WRITE_SIZE, calibrated in
-    profiles/traffic_ns.json) from the committed builder-run profile profiles/r03_pmc.json -- NOT measured in this
-    run (PMC passes need rocprofv3).  -> dict for a roofline's `traffic` fields, or {} when the file is absent."""
+    profiles/traffic_ns.json) from the committed builder-run profiles -- the newest of profiles/r04_pmc.json /
+    r03_pmc.json that holds the workload AND a kernel of that name -- NOT measured in this run (PMC passes need
+    rocprofv3).  kernel_substr '*' = every kernel of the workload summed (a sort is build + passes).
+    -> dict for a roofline's `traffic` fields, or {} when no file has it."""
     global _PMC
     if _PMC is None:
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r03_pmc.json')
-        try:
-            import json
-            _PMC = json.load(open(path))
-        except Exception:
-            _PMC = {}
-    w = _PMC.get('workloads', {}).get(workload)
-    if not w:
-        return {}
-    for k, v in w['kernels'].items():
-        if kernel_substr in k and 'fabric_bytes_per_call_x2_rule' in v:
-            return dict(traffic=v['fabric_bytes_per_call_x2_rule'], traffic_kernel=k, traffic_kernel_us=round(v['us_per_call'], 1),
-                        traffic_tb_per_s=v.get('fabric_tb_per_s_x2_rule'),
-                        traffic_source='profiles/r03_pmc.json (%s), rocprofv3 --pmc builder run, NOT measured in this run' % workload)
+        import json
+        _PMC = []
+        for name in ('r04_pmc.json', 'r03_pmc.json'):
+            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', name)
+            try:
+                _PMC.append((name, json.load(open(path))))
+            except Exception:
+                pass
+    for name, prof in _PMC:
+        w = prof.get('workloads', {}).get(workload)
+        if not w:
+            continue
+        src = 'profiles/%s (%s), rocprofv3 --pmc builder run, NOT measured in this run' % (name, workload)
+        if kernel_substr == '*':
+            ks = [v for v in w['kernels'].values() if 'fabric_bytes_per_call_x2_rule' in v]
+            if ks:
+                us = sum(v['us_per_call'] for v in ks)
+                nbytes = sum(v['fabric_bytes_per_call_x2_rule'] for v in ks)
+                return dict(traffic=nbytes, traffic_kernel='all %d kernels of the call' % len(ks), traffic_kernel_us=round(us, 1),
+                            traffic_tb_per_s=round(nbytes / us / 1e6, 3) if us > 0 else None, traffic_source=src)
+            continue
+        for k, v in w['kernels'].items():
+            if kernel_substr in k and 'fabric_bytes_per_call_x2_rule' in v:
+                return dict(traffic=v['fabric_bytes_per_call_x2_rule'], traffic_kernel=k, traffic_kernel_us=round(v['us_per_call'], 1),
+                            traffic_tb_per_s=v.get('fabric_tb_per_s_x2_rule'), traffic_source=src)
     return {}
 
 
@@ -691,7 +704,7 @@ def run_construct(dev, cpu=True, iters=5):
                roofline={k: _roof(nbytes[k], ms[k], 'whole call incl. host syncs; bytes = E(16+s) in + E\'(16+s) out '
                                   '(SURVEY 8d; the radix passes are implementation cost)') for k in ms})
     res['ms_total'] = round(sum(ms.values()), 4)
-    res['roofline']['construct'].update(pmc_traffic('sort_coo_7m5', 'radix_scatter_kernel'))
+    res['roofline']['construct'].update(pmc_traffic('sort_coo_7m5', '*'))
     # ---- parity: every index output bit-exact against the numpy restatement, on the host ----
     rn, cn, vn = row.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
     rs, cs, perm = npo.sort_coo(rn, cn, m, n)
