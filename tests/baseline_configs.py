@@ -164,7 +164,7 @@ def ref_spmm_cpu(rp, c, v, x, reduce):
 # ------------------------------------------------------------------------------------------------
 # parity statistics
 # ------------------------------------------------------------------------------------------------
-def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5):
+def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5, fp64_leg=True):
     """fp32 SpMM-sum/mean, WHOLE output against the reference CPU kernel's fp32 output.
 
     The north star's "fp32 within 1e-5 rel" is checked in the two readings it admits:
@@ -178,11 +178,26 @@ def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5):
                                                  case there is 100 * (2.0e-7 + 3.7e-7) = 5.7e-5)
         and the unconditional figures max_rel_vs_ref / frac_rel_vs_ref_gt_1e_5 are printed next to the same
         two figures of the reference against fp64.
-    All operands are host tensors except out_gpu."""
+    All operands are host tensors except out_gpu.  fp64_leg=False (the configs[4]-share TEST: 537 M elements; the
+    bench line's row of the same workload keeps the full statistics) drops the third host product -- the fp64 one --
+    and what is derived from it; the whole output is still compared with the reference's fp32 output."""
     a = out_gpu.detach().cpu()
     if ref_out is None:
         ref_out = ref_spmm_cpu(rp, c, v, x, 'sum')[0]
     l1 = ref_spmm_cpu(rp, c, None if v is None else v.abs(), x.abs(), 'sum')[0].double()
+    if not fp64_leg:
+        l1c = l1.clamp(min=1e-30)
+        refd = ref_out.double()
+        d = (a.double() - refd).abs()
+        bad = d > 1e-5 * refd.abs()
+        res = dict(elements=int(a.numel()),
+                   against='reference CPU kernel (csrc/cpu/spmm_cpu.cpp via oracle/_ref), whole output; criterion: '
+                           '|gpu - ref| <= 1e-5 * sum_e|v_e x_e| for every element, plus |gpu - ref| <= 1e-5 * |ref| for '
+                           'every element with |ref| >= 0.1 * sum_e|v_e x_e| (fp64 statistics: see the bench line)',
+                   max_err_over_l1=float((d / l1c).max()), tol_over_l1=tol,
+                   n_rel_gt_1e_5_where_ref_ge_1e_1_l1=int((bad & (refd.abs() >= 1e-1 * l1)).sum()))
+        res['ok'] = bool(res['max_err_over_l1'] <= tol and res['n_rel_gt_1e_5_where_ref_ge_1e_1_l1'] == 0)
+        return res
     exact = ref_spmm_cpu(rp, c, None if v is None else v.double(), x.double(), 'sum')[0]
     l1c = l1.clamp(min=1e-30)
     refd = ref_out.double()
@@ -265,7 +280,7 @@ def run_c2(dev, cpu=True, iters=20):
 # C5 share: what ONE of the 8 GPUs of configs[4] multiplies -- 2^21 rows, ~32 nnz/row, F = 256 fp32 (1 KB rows: the
 # 1024-item branch of plan_partition) -- plus the row-sharded path with P = 8 logical ranks on this one device
 # ------------------------------------------------------------------------------------------------
-def run_c5_share(dev, cpu=True, iters=10, logical_ranks=8):
+def run_c5_share(dev, cpu=True, iters=10, logical_ranks=8, fp64_leg=True):
     from pytorch_sparse_amd import synth
     from pytorch_sparse_amd import _native as nat
     from pytorch_sparse_amd.parallel import narrow_rows, partition_rows
@@ -316,7 +331,7 @@ def run_c5_share(dev, cpu=True, iters=10, logical_ranks=8):
         t, (ro, _, kind), runs = cpu_time(lambda: ref_spmm_cpu(rpc, cc, vc, xc, 'sum'), budget_s=20.0, max_reps=1)
         res['cpu_baseline'] = dict(value=round(E / t / 1e9, 4), unit='GEdges/s', cores=cores, kind=kind,
                                    ms=round(t * 1e3, 2), sample='full workload, best of %d' % runs)
-        par = sum_parity(out, rpc, cc, vc, xc, ro)
+        par = sum_parity(out, rpc, cc, vc, xc, ro, fp64_leg=fp64_leg)
     par['row_sharded_ok'] = bool(worst <= 1e-5 and max_equal)
     par['ok'] = bool(par.get('ok', True) and par['row_sharded_ok'])
     res['parity'] = par
