@@ -12,6 +12,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef TSAMD_MASKED_SEGMENT_SKIP
+#define TSAMD_MASKED_SEGMENT_SKIP 1  // 0: the masked SDDMM / masked sum gather every entry's whole rows (round 3)
+#endif
+
 namespace tsamd {
 namespace {
 
@@ -89,6 +93,38 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_value_bw_kernel(
         const T *mrow = mat + ((uint64_t)b * N + c) * K;
         const T *grow = grad + ((uint64_t)b * M + r) * K;
         for (uint32_t sl = kl; sl < slots; sl += lpr) {
+#if TSAMD_MASKED_SEGMENT_SKIP
+          if constexpr (MASKED) {
+            // The record word first: an entry of a row of degree d wins a feature with probability ~1/d, and the
+            // entries of a hub row are consecutive in this kernel's (CSR) order -- most slots of most steps hold no
+            // winner at all.  A lane whose VEC features have none sits out its two 16-byte gathers, and a slot in
+            // which NO lane of the wave has one is skipped altogether (the kernel is bound by VALU issue: 0.94 of
+            // the slots at configs[2], profiles/r04_sq_counters.md).  Adding nothing == adding the masked zeros.
+            const uint32_t f0 = sl * VEC;
+            const uint32_t word = rec[((uint64_t)b * (uint64_t)E + (uint64_t)(base + src)) * rec_stride + (f0 >> 5)];
+            const uint32_t bits = (word >> (f0 & 31u)) & (VEC >= 32 ? 0xFFFFFFFFu : ((1u << (VEC & 31)) - 1u));
+            if (__ballot(bits != 0u) == 0ull) continue;  // wave-uniform (every lane runs the same sl sequence)
+            P x{}, y{};
+            if (bits != 0u) {
+              x = *reinterpret_cast<const P *>(mrow + (uint64_t)sl * VEC);
+              y = *reinterpret_cast<const P *>(grow + (uint64_t)sl * VEC);
+            }
+            {
+              typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+              static_assert(sizeof(P) == 16, "masked SDDMM works on 16-byte packets");
+              u32x4 xb, yb;
+              __builtin_memcpy(&xb, &x, 16);
+              __builtin_memcpy(&yb, &y, 16);
+              asm volatile("" : "+v"(xb), "+v"(yb));
+              __builtin_memcpy(&x, &xb, 16);
+              __builtin_memcpy(&y, &yb, 16);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+              acc[u] += ((bits >> j) & 1u) ? Traits<T>::to_acc(x.v[j]) * Traits<T>::to_acc(y.v[j]) : A(0);
+            continue;
+          }
+#endif
           P x = *reinterpret_cast<const P *>(mrow + (uint64_t)sl * VEC);
           P y = *reinterpret_cast<const P *>(grow + (uint64_t)sl * VEC);
           if constexpr (MASKED) {
