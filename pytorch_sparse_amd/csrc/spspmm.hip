@@ -273,13 +273,29 @@ __device__ __forceinline__ uint32_t wave_scan_max_dpp(uint32_t v) {
 #undef TSAMD_DPP_STEP
 
 // One-wave form of expand_row (rows of at most kSmallCap products: the symbolic and numeric kernels of the small
-// rows).  Same contract -- emit(q, col, value) once per product, q = index in expansion order -- but a lane takes FOUR
-// CONSECUTIVE products of a 256-product batch and finds their A entries without searching: every entry that reaches
+// rows).  Same products, same indices q in expansion order, but handed over four at a time -- emit(q0, n, col[4],
+// value[4]): the lane's products q0 .. q0 + n - 1, n in 0..4 (each_product() adapts a per-product functor) -- because a
+// lane takes FOUR CONSECUTIVE products of a 256-product batch and finds their A entries without searching: every entry that reaches
 // into the batch leaves (its lane + 1) in a byte at the position of its first product there, and a max-scan over the
 // 256 bytes (in-lane over the dword a lane reads back, then the DPP scan across lanes) carries each owner forward to
 // the products behind it.  The 6-step LDS binary search per product that this replaces was 184 of the 448 VALU
 // instructions a row-wave of the symbolic kernel issued at configs[3] (and 24 dependent LDS reads); the kernels
 // are bound by instruction issue (SQ counters, profiles/r03_sq_counters.md).
+template <typename Emit>
+struct EachProduct {
+  Emit emit;
+  template <typename A>
+  __device__ __forceinline__ void operator()(int q0, int n, const uint32_t (&c)[4], const A (&v)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < n) emit(q0 + u, c[u], v[u]);
+  }
+};
+template <typename Emit>
+__device__ __forceinline__ EachProduct<Emit> each_product(Emit emit) {
+  return EachProduct<Emit>{emit};
+}
+
 // PRE: the caller already holds the per-lane (start of the B row, its length, value of the A entry) of a row of at
 // most 64 entries -- the persistent kernels below fetch them a row ahead (RowPipe).
 template <typename T, bool WITH_VAL, bool PRE = false, typename Emit>
@@ -314,8 +330,7 @@ __device__ __forceinline__ int expand_row_wave(const int64_t *__restrict__ colA,
     }
     const int incl = (int)wave_scan_add_dpp((uint32_t)d);
     const int off = incl - d;
-    sc.off[lane] = off;
-    sc.bs[lane] = bs;
+    sc.bs[lane] = bs - (int64_t)off;  // position in colB of the chunk's product 0 IF it belonged to this entry: one read per product
     if (WITH_VAL) sc.av[lane] = av;
     const int total = __builtin_amdgcn_readlane(incl, 63);
     for (int b0 = 0; b0 < total; b0 += 256) {
@@ -343,7 +358,7 @@ __device__ __forceinline__ int expand_row_wave(const int64_t *__restrict__ colA,
         const int lo = (int)(o[u] > below ? o[u] : below) - 1;  // >= 0: the entry that covers product b0 marked slot 0
         const int qq = qbase + u;
         const int q = qq < total ? qq : total - 1;  // (the owner carried into a slot past the end owns total - 1)
-        src[u] = sc.bs[lo] + (q - sc.off[lo]);
+        src[u] = sc.bs[lo] + (int64_t)q;
         a[u] = WITH_VAL ? sc.av[lo] : A(1);
       }
       uint32_t c[4];
@@ -353,10 +368,12 @@ __device__ __forceinline__ int expand_row_wave(const int64_t *__restrict__ colA,
         c[u] = colB[src[u]];
         b[u] = (WITH_VAL && valB != nullptr) ? Traits<T>::to_acc(valB[src[u]]) : A(1);
       }
+      {
+        A pr[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int qq = qbase + u;
-        if (qq < total) emit(filled + qq, c[u], a[u] * b[u]);
+        for (int u = 0; u < 4; ++u) pr[u] = a[u] * b[u];
+        const int left = total - qbase;
+        emit(filled + qbase, left < 0 ? 0 : (left > 4 ? 4 : left), c, pr);  // the lane's (up to) four consecutive products
       }
       // every gather of the batch has landed before the next batch (or the caller) goes on: without this a lane
       // whose product lies past the end never reads its register, the load stays "pending" on the loop's back edge,
@@ -386,7 +403,7 @@ __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, cons
   using A = typename Traits<T>::acc_t;
 #if TSAMD_SPSPMM_OWNER_SCAN
   if constexpr (BLOCK == 64 && !LONG_B)
-    return expand_row_wave<T, WITH_VAL>(colA, valA, rowptrB, colB, valB, as, ae, sc, emit);
+    return expand_row_wave<T, WITH_VAL>(colA, valA, rowptrB, colB, valB, as, ae, sc, each_product(emit));
 #endif
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -465,7 +482,17 @@ __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, cons
 // ---------------------------------------------------------------------------
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;  // column ids are < 2^32 - 1
 
-template <int BLOCK, int LOG_T>
+// Slot of a column id in a table of 2^LOG_T entries (multiplicative hashing, linear probing behind it -- any function
+// is CORRECT, a poor one only probes longer).  v_mul_lo_u32 runs at a quarter of the VALU rate; matrices of at most
+// 2^24 columns (template flag of the kernel) take v_mul_u32_u24 instead: the top bits of the low 32 product bits mix every bit
+// of a 24-bit id.
+template <int LOG_T>
+__device__ __forceinline__ uint32_t hash_slot(uint32_t c, bool narrow) {
+  const uint32_t m = narrow ? __umul24(c, 0x9E3779u) : c * 0x9E3779B1u;
+  return m >> (32 - LOG_T);
+}
+
+template <int BLOCK, int LOG_T, bool NARROW>
 __global__ __launch_bounds__(BLOCK) void spspmm_symbolic_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
     const int64_t *__restrict__ rowptrB, const uint32_t *__restrict__ colB,
@@ -488,7 +515,7 @@ __global__ __launch_bounds__(BLOCK) void spspmm_symbolic_kernel(
   int fresh = 0;
   expand_row<float, BLOCK, false>(colA, nullptr, rowptrB, colB, nullptr, rowptrA[i], rowptrA[i + 1], sc,
                                   [&](int, uint32_t c, float) {
-    uint32_t h = (c * 0x9E3779B1u) >> (32 - LOG_T);
+    uint32_t h = hash_slot<LOG_T>(c, NARROW);
     for (;;) {
       const uint32_t old = atomicCAS(&tab[h], kEmptyKey, c);
       if (old == kEmptyKey) {
@@ -646,7 +673,7 @@ __global__ __launch_bounds__(64) void spspmm_symbolic_small_kernel(
       __syncthreads();
       int fresh = 0;
       auto insert = [&](int, uint32_t c, float) {
-        uint32_t h = (c * 0x9E3779B1u) >> (32 - LOG_T);
+        uint32_t h = hash_slot<LOG_T>(c, false);
         for (;;) {
           const uint32_t old = atomicCAS(&tab[h], kEmptyKey, c);
           if (old == kEmptyKey) {
@@ -658,10 +685,11 @@ __global__ __launch_bounds__(64) void spspmm_symbolic_small_kernel(
         }
       };
       if (pipe.h0.ae - pipe.h0.as <= 64)  // wave-uniform; the prefetched chunk is the whole row
-        expand_row_wave<float, false, true>(colA, nullptr, rowptrB, colB, nullptr, pipe.h0.as, pipe.h0.ae, sc, insert,
-                                            pipe.bs0, pipe.d0, 1.0f);
+        expand_row_wave<float, false, true>(colA, nullptr, rowptrB, colB, nullptr, pipe.h0.as, pipe.h0.ae, sc,
+                                            each_product(insert), pipe.bs0, pipe.d0, 1.0f);
       else
-        expand_row_wave<float, false, false>(colA, nullptr, rowptrB, colB, nullptr, pipe.h0.as, pipe.h0.ae, sc, insert);
+        expand_row_wave<float, false, false>(colA, nullptr, rowptrB, colB, nullptr, pipe.h0.as, pipe.h0.ae, sc,
+                                             each_product(insert));
       fresh = (int)wave_scan_add_dpp((uint32_t)fresh);
       if (lane == 63) nnzC[pipe.h0.row] = fresh;
       __syncthreads();
@@ -850,7 +878,7 @@ __global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
     T *__restrict__ valC) {
   using A = typename Traits<T>::acc_t;
   __shared__ alignas(16) uint32_t skey[kSmallCap];
-  __shared__ A sval[kSmallCap];
+  __shared__ alignas(32) A sval[kSmallCap];
   __shared__ ExpandScratch<A> sc;
   __shared__ int sscan[8];
   const int lane = (int)threadIdx.x;
@@ -860,6 +888,40 @@ __global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
   const bool with_val = valC != nullptr;
   const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : 8));  // keys per lane
   for (int q = p + lane; q < 64 * items; q += 64) skey[q] = kEmptyKey;   // padding sorts last
+#if TSAMD_SPSPMM_OWNER_SCAN
+  __syncthreads();  // (one wave: the padding above is ordered before the packet stores below)
+  // the lane's four consecutive products as ONE 16-byte store of keys (and one packet of values) when their slots
+  // are a whole aligned group inside the arrays; slots past the row's end get the padding key again (they are padding:
+  // nothing but a later chunk of the same row ever writes them, and that comes later in program order)
+  auto put4 = [&](auto wv, int q0, int n, const uint32_t (&c)[4], const A (&v)[4]) __attribute__((always_inline)) {
+    if ((q0 & 3) == 0 && q0 + 4 <= kSmallCap) {
+      Pack<uint32_t, 4> k4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k4.v[u] = u < n ? ((c[u] << kIdxBits) | (uint32_t)(q0 + u)) : kEmptyKey;
+      *reinterpret_cast<Pack<uint32_t, 4> *>(__builtin_assume_aligned(skey + q0, 16)) = k4;
+      if constexpr (decltype(wv)::value) {
+        Pack<A, 4> v4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v4.v[u] = v[u];
+        *reinterpret_cast<Pack<A, 4> *>(__builtin_assume_aligned(sval + q0, 16)) = v4;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < n) {
+          skey[q0 + u] = (c[u] << kIdxBits) | (uint32_t)(q0 + u);
+          if constexpr (decltype(wv)::value) sval[q0 + u] = v[u];
+        }
+      }
+    }
+  };
+  if (with_val)
+    expand_row_wave<T, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+                             [&](int q0, int n, const uint32_t (&c)[4], const A (&v)[4]) { put4(std::true_type{}, q0, n, c, v); });
+  else
+    expand_row_wave<T, false>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+                              [&](int q0, int n, const uint32_t (&c)[4], const A (&v)[4]) { put4(std::false_type{}, q0, n, c, v); });
+#else
   if (with_val) {
     expand_row<T, 64, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
                             [&](int q, uint32_t c, A v) {
@@ -870,6 +932,7 @@ __global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
     expand_row<T, 64, false>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
                              [&](int q, uint32_t c, A) { skey[q] = (c << kIdxBits) | (uint32_t)q; });
   }
+#endif
   __syncthreads();
   if (items == 1) sort_lds_keys<1>(skey, lane);
   else if (items == 2) sort_lds_keys<2>(skey, lane);
@@ -911,10 +974,10 @@ __global__ __launch_bounds__(64) void spspmm_numeric_small_pipe_kernel(
           if constexpr (kWV) sval[q] = v;
         };
         if (pipe.h0.ae - pipe.h0.as <= 64)  // wave-uniform; the prefetched chunk is the whole row
-          expand_row_wave<T, kWV, true>(colA, valA, rowptrB, colB, valB, pipe.h0.as, pipe.h0.ae, sc, put, pipe.bs0,
-                                        pipe.d0, pipe.av0);
+          expand_row_wave<T, kWV, true>(colA, valA, rowptrB, colB, valB, pipe.h0.as, pipe.h0.ae, sc, each_product(put),
+                                        pipe.bs0, pipe.d0, pipe.av0);
         else
-          expand_row_wave<T, kWV, false>(colA, valA, rowptrB, colB, valB, pipe.h0.as, pipe.h0.ae, sc, put);
+          expand_row_wave<T, kWV, false>(colA, valA, rowptrB, colB, valB, pipe.h0.as, pipe.h0.ae, sc, each_product(put));
         __syncthreads();
         if (items == 1) sort_lds_keys<1>(skey, lane);
         else if (items == 2) sort_lds_keys<2>(skey, lane);
@@ -1779,17 +1842,26 @@ extern "C" int tsamd_spspmm_symbolic(int dtype, const int64_t *rowptrA, const in
   if (n_large > 0 && (!workspace || workspace_bytes < tsamd_spspmm_workspace_bytes(dtype, n_large, P_large, N)))
     return TSAMD_ERR_WORKSPACE;
   TSAMD_HIP_TRY(hipMemsetAsync(nnzC, 0, sizeof(int64_t) * (size_t)M, stream));
+  const bool narrow_cols = N <= ((int64_t)1 << 24);  // hash_slot: 24-bit multiply
 #if TSAMD_SPSPMM_ROW_PIPE
   hipLaunchKernelGGL(spspmm_symbolic_small_kernel, dim3(pipe_blocks(M)), dim3(64), 0, stream, rowptrA, colA,
                      rowptrB, colB, prod, M, nnzC);
 #else
-  hipLaunchKernelGGL((spspmm_symbolic_kernel<64, 10>), dim3((unsigned int)M), dim3(64), 0, stream, rowptrA,
-                     colA, rowptrB, colB, prod, bins, nnzC);
+  if (narrow_cols)
+    hipLaunchKernelGGL((spspmm_symbolic_kernel<64, 10, true>), dim3((unsigned int)M), dim3(64), 0, stream, rowptrA,
+                       colA, rowptrB, colB, prod, bins, nnzC);
+  else
+    hipLaunchKernelGGL((spspmm_symbolic_kernel<64, 10, false>), dim3((unsigned int)M), dim3(64), 0, stream, rowptrA,
+                       colA, rowptrB, colB, prod, bins, nnzC);
 #endif
   TSAMD_LAUNCH_CHECK();
   if (n_medium > 0) {
-    hipLaunchKernelGGL((spspmm_symbolic_kernel<256, kMediumLogT>), dim3((unsigned int)n_medium), dim3(256), 0,
-                       stream, rowptrA, colA, rowptrB, colB, prod, bins, nnzC);
+    if (narrow_cols)
+      hipLaunchKernelGGL((spspmm_symbolic_kernel<256, kMediumLogT, true>), dim3((unsigned int)n_medium), dim3(256), 0,
+                         stream, rowptrA, colA, rowptrB, colB, prod, bins, nnzC);
+    else
+      hipLaunchKernelGGL((spspmm_symbolic_kernel<256, kMediumLogT, false>), dim3((unsigned int)n_medium), dim3(256), 0,
+                         stream, rowptrA, colA, rowptrB, colB, prod, bins, nnzC);
     TSAMD_LAUNCH_CHECK();
   }
   if (n_large > 0) {
