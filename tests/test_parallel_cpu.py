@@ -76,6 +76,8 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
                 continue
             out_local = op(x_local, reduce)
             res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]))
+        if hasattr(op, '_agreed'):  # pipelined halo: the four calls above shared ONE agreement on the autograd path
+            assert len(op._agreed) == 1 and list(op._agreed.values()) == [False], op._agreed
         # backward: the gradient of x is a partial sum on every rank and has to reach the owning rank
         # (reduce-scatter / reverse all_to_all), for sum and -- across ranks -- for min / max; the value
         # gradient is local
