@@ -1631,6 +1631,7 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, int64_t N, size
   return off;
 }
 
+#if TSAMD_SPSPMM_ROW_PIPE
 unsigned int device_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -1644,7 +1645,6 @@ unsigned int device_cus() {
   return (unsigned int)cus;
 }
 
-#if TSAMD_SPSPMM_ROW_PIPE
 // one-wave workgroups of the pipelined small-row kernels: as many as the device holds at once, never more than rows
 unsigned int pipe_blocks(int64_t M) {
   const int64_t cap = (int64_t)device_cus() * TSAMD_SPSPMM_PIPE_WAVES;
