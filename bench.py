@@ -270,7 +270,32 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+# what main() leaves for its wrapper once the headline of an N > 1 run is settled: the bare line, the rank, the "printed" flag
+_SETTLED = {}
+
+
 def main():
+    """`_main()`; N > 1 only: if an explanatory leg raises after the headline was settled (they have never run on real
+    xGMI hardware), rank 0 still prints the headline line -- with the exception in `extras` -- instead of dying silently,
+    and the process leaves with status 0 (its peers are ended by their watchdogs)."""
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as exc:  # noqa: BLE001
+        if not _SETTLED:
+            raise
+        import traceback
+        traceback.print_exc()
+        if _SETTLED['rank'] == 0 and not _SETTLED['printed'].is_set():
+            line = dict(_SETTLED['bare'])
+            line['extras'] = 'withheld: an explanatory leg after the timed region raised %s: %s' % (
+                type(exc).__name__, str(exc)[:300])
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -439,6 +464,7 @@ def main():
                 print(json.dumps(bare), flush=True)
             os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
+        _SETTLED.update(bare=bare, rank=rank, printed=line_printed)
 
     # N = 1: the same steps with the operand cache opted IN (torch.ops.tsamd.operand_cache(True)): the second and
     # later calls with an unchanged X find its relabelled copy (tsamd_spmm_cached) -- bit-identical output

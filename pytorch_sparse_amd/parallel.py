@@ -732,7 +732,10 @@ def exchange_breakdown(sharded, ref_plan, x_local: Tensor, spmm_call: Callable, 
         with torch.no_grad():
             for _ in range(reps):
                 fn()
-        sync()
+                # one call in flight at a time: an all-gather allocates its landing buffers per call (17 GB at configs[4],
+                # N = 8), and buffers a collective stream still owns cannot be handed out again -- ten calls queued
+                # back to back would hold ten sets
+                sync()
         dist.barrier(group)
         t_parts.append((time.perf_counter() - t1) / reps * 1e3)
     part = torch.tensor(t_parts + [float(rows_in)], dtype=torch.float64, device=x_local.device)
