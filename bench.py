@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -129,23 +130,142 @@ def cpu_baseline(rowptr, col, value, x, reduce, out):
     return res
 
 
-def secondary(dev, cpu=True):
+def secondary(dev, cpu=True, stress=False):
     """BASELINE.json configs[0..3] at their stated size (tests/baseline_configs.py): C1 (legacy spmm), C2 forward, C2
-    value-grad + sum forward/backward, C3 (value-less and with values, forward + backward), construct / coalesce /
-    transpose / t() on the C4 input, C4, SpSpMM stress -- each with ms, roofline, cpu_baseline and whole-output parity."""
+    value-grad + sum forward/backward, C3 (value-less and with values, forward + backward), the configs[4] per-GPU share,
+    construct / coalesce / transpose / t() on the C4 input, C4 -- each with ms, roofline, cpu_baseline and whole-output
+    parity (statistics with ATen on the device); `--stress` adds the SpSpMM R-MAT stress row.  `wall_s` = what the row
+    cost this run."""
     from tests import baseline_configs as bc
+    legs = [lambda: bc.run_c1(dev, cpu=cpu), lambda: bc.run_c2(dev, cpu=cpu), lambda: bc.run_c2_backward(dev, cpu=cpu),
+            lambda: bc.run_c3(dev, False, cpu=cpu), lambda: bc.run_c3(dev, True, cpu=cpu),
+            lambda: bc.run_c5_share(dev, cpu=cpu, fp64_leg=False),
+            lambda: bc.run_construct(dev, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu)]
+    if stress:  # SURVEY 8d stress row: property checks (the host SpGEMM would take minutes)
+        legs.append(lambda: bc.run_spspmm(dev, 'stress', cpu=False, iters=3))
     res = []
-    for fn in (lambda: bc.run_c1(dev, cpu=cpu), lambda: bc.run_c2(dev, cpu=cpu), lambda: bc.run_c2_backward(dev, cpu=cpu),
-               lambda: bc.run_c3(dev, False, cpu=cpu), lambda: bc.run_c3(dev, True, cpu=cpu),
-               lambda: bc.run_c5_share(dev, cpu=cpu),
-               lambda: bc.run_construct(dev, cpu=cpu), lambda: bc.run_spspmm(dev, 'c4', cpu=cpu),
-               lambda: bc.run_spspmm(dev, 'stress', cpu=False, iters=3)):  # SURVEY 8d stress row: property checks
+    for fn in legs:
+        t0 = time.perf_counter()
         try:
-            res.append(fn())
+            row = fn()
         except Exception as exc:  # a failing secondary must not take the headline down
-            res.append(dict(error='%s: %s' % (type(exc).__name__, exc)))
+            row = dict(error='%s: %s' % (type(exc).__name__, exc))
+        torch.cuda.synchronize()
+        row['wall_s'] = round(time.perf_counter() - t0, 1)
+        print('[bench] secondary %s: %.1f s' % (row.get('config', '?'), row['wall_s']), file=sys.stderr, flush=True)
+        res.append(row)
         torch.cuda.empty_cache()
     return res
+
+
+# ------------------------------------------------------------------------------------------------
+# the ONE stdout line: numbers only, a few KB (the driver parses the tail of stdout; round 4's 22 KB line did not
+# fit its window).  Everything else -- notes, scopes, full parity statistics -- goes to stderr and to
+# profiles/bench_last_full.json / gpurun_out/bench_last_full.json.
+# ------------------------------------------------------------------------------------------------
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + '~'
+
+
+def compact_row(r):
+    """One secondary row -> config, ms, frac, ok, cpu_ms (<= ~250 bytes)."""
+    if 'error' in r:
+        return dict(config=r.get('config', '?'), error=_short(r['error'], 80))
+    o = dict(config=r['config'] + ('_val' if r.get('has_value') else ''))
+    o.update(_pick(r, ('ms', 'fw_ms', 'bw_ms', 'bw_atomic_ms', 'value_bw_ms', 'fw_bw_ms', 'fw_bw_fixed_weights_ms',
+                       'gedges_per_s', 'gproducts_per_s')))
+    roof = r.get('roofline') or {}
+    if 'frac' in roof:
+        o['frac'] = roof['frac']
+    elif roof:  # construct: one roofline per call
+        o['frac'] = {k: v.get('frac') for k, v in roof.items() if isinstance(v, dict)}
+    for extra in ('roofline_bw', 'roofline_fw_bw'):
+        if isinstance(r.get(extra), dict) and 'frac' in r[extra]:
+            o['frac_' + extra[9:]] = r[extra]['frac']
+    cb = r.get('cpu_baseline')
+    if cb:
+        o['cpu_ms'] = cb.get('ms')
+        o['cpu_kind'] = cb.get('kind')
+    if isinstance(r.get('parity'), dict):
+        o['ok'] = r['parity'].get('ok')
+    if isinstance(r.get('reference_gpu_route'), dict) and 'ms' in r['reference_gpu_route']:
+        o['hipsparse_ms'] = r['reference_gpu_route']['ms']
+    return o
+
+
+HEAD_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+             'vs_baseline', 'dtype', 'data')
+ROOF_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'balg_over_peak',
+             'algorithmic_bytes_per_launch', 'b_min', 'kernel_ms', 'pre_ms', 'fixup_ms')
+MAX_LINE_BYTES = 6000
+
+
+def compact_line(full):
+    """The stdout line of a run from its full result: contract fields, `roofline`, `cpu_baseline`, `parity` of the
+    headline, one small object per secondary row (and per exchange at N > 1).  No prose; < MAX_LINE_BYTES."""
+    line = {k: (_short(full[k], 60) if isinstance(full[k], str) else full[k]) for k in HEAD_KEYS if k in full}
+    cfg = full.get('config', {})
+    line['config'] = {k: _short(v, 100) for k, v in _pick(cfg, ('workload', 'reduce', 'rows_per_gpu', 'cols', 'edges_per_gpu',
+                                                                'features', 'parallelism', 'exchange_fallback')).items()}
+    roof = _pick(full.get('roofline', {}), ROOF_KEYS)
+    if 'traffic_source' in roof:
+        src = roof['traffic_source']
+        roof['traffic_source'] = 'this run: rocprofv3 --pmc, 2 passes' if src.startswith('this run') else _short(src, 40)
+    line['roofline'] = roof
+    cb = full.get('cpu_baseline')
+    if cb:
+        line['cpu_baseline'] = _pick(cb, ('value', 'unit', 'cores', 'kind', 'ms'))
+        line['cpu_baseline']['sample'] = _short(cb.get('sample', ''), 60)
+        par = cb.get('parity')
+        if par:
+            p = _pick(par, ('ok', 'elements', 'max_err_over_l1', 'tol_over_l1', 'ours_vs_fp64_over_l1', 'ref_vs_fp64_over_l1',
+                            'n_rel_gt_1e_5_where_ref_ge_1e_1_l1'))
+            p.update(_pick(par.get('survey_8d_literal_bound', {}), ('n_viol_ours_vs_ref', 'n_viol_ours_vs_fp64',
+                                                                    'n_viol_ref_vs_fp64')))
+            line['parity'] = p
+    for k in ('repeated_operand', 'relabelled_layout', 'control'):
+        if isinstance(full.get(k), dict):
+            line[k] = _pick(full[k], ('ms_per_step', 'ms', 'gedges_per_s'))
+    ex = full.get('exchange')
+    if isinstance(ex, dict):
+        line['exchange'] = {k: v for k, v in ex.items() if isinstance(v, (int, float, bool))}
+        if isinstance(ex.get('overlap'), dict):
+            line['exchange']['overlap_parity_ok'] = (ex['overlap'].get('parity_vs_serial') or {}).get('ok')
+    for k in ('exchange_variants_ms_per_step', 'extras'):
+        if k in full:
+            line[k] = _short(full[k], 160) if isinstance(full[k], str) else full[k]
+    if isinstance(full.get('weak_scaling_reference'), dict):
+        line['weak_scaling_reference'] = _pick(full['weak_scaling_reference'], ('gedges_per_s_per_gpu', ))
+    if 'secondary' in full:
+        line['secondary'] = [compact_row(r) for r in full['secondary']]
+    if 'wall_s' in full:
+        line['wall_s'] = full['wall_s']
+    line['detail'] = 'profiles/bench_last_full.json'
+    if len(json.dumps(line)) > MAX_LINE_BYTES:  # never let the explanatory part cost the headline
+        for k in ('secondary', 'exchange', 'exchange_variants_ms_per_step', 'control', 'relabelled_layout', 'repeated_operand'):
+            line.pop(k, None)
+            if len(json.dumps(line)) <= MAX_LINE_BYTES:
+                break
+    return line
+
+
+def emit(full):
+    """Full result -> stderr + profiles/bench_last_full.json + gpurun_out/bench_last_full.json; compact line -> stdout,
+    LAST (nothing may be printed to stdout after it)."""
+    text = json.dumps(full)
+    for d in ('profiles', 'gpurun_out'):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            with open(os.path.join(ROOT, d, 'bench_last_full.json'), 'w') as fh:
+                fh.write(text + '\n')
+        except OSError:
+            pass
+    print('[bench] full result: ' + text, file=sys.stderr, flush=True)
+    print(json.dumps(compact_line(full)), flush=True)
 
 
 def relabelled_leg(rowptr, col, value, x, out, reduce, steps, dev):
@@ -291,7 +411,7 @@ def main():
             line = dict(_SETTLED['bare'])
             line['extras'] = 'withheld: an explanatory leg after the timed region raised %s: %s' % (
                 type(exc).__name__, str(exc)[:300])
-            print(json.dumps(line), flush=True)
+            print(json.dumps(compact_line(line)), flush=True)
         os._exit(0)
 
 
@@ -306,6 +426,7 @@ def _main():
     ap.add_argument('--reduce', default='sum', choices=['sum', 'mean', 'min', 'max'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the C2 / C3 / C4 entries (N = 1 only)')
+    ap.add_argument('--stress', action='store_true', help='add the SpSpMM R-MAT stress row to the secondary rows (~40 s)')
     ap.add_argument('--headline-only', action='store_true',
                     help='only the timed north-star steps + the roofline launches (for rocprofv3: every launch of the '
                          'dominant kernel in the trace is then the headline workload)')
@@ -461,7 +582,7 @@ def _main():
             if watchdog_done.wait(args.extras_timeout):
                 return
             if rank == 0 and not line_printed.is_set():
-                print(json.dumps(bare), flush=True)
+                print(json.dumps(compact_line(bare)), flush=True)
             os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         _SETTLED.update(bare=bare, rank=rank, printed=line_printed)
@@ -668,9 +789,10 @@ def _main():
             del x_full, out, sharded
             torch.cuda.empty_cache()
             line['control'] = control_graph(m_local, ef, F, dev, nat)
-            line['secondary'] = secondary(dev, cpu=not args.no_cpu_baseline)
+            line['secondary'] = secondary(dev, cpu=not args.no_cpu_baseline, stress=args.stress)
+        line['wall_s'] = round(time.perf_counter() - T_START, 1)
         line_printed.set()
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
     if watchdog_done is not None:  # (armed through the last barrier: a peer that stalled must not keep the others)

@@ -196,6 +196,27 @@ int tsamd_gather_rows(const void *src, const int64_t *idx, void *dst, int64_t n,
                       int64_t row_bytes, void *stream);
 
 /* ------------------------------------------------------------------------ *
+ * Legacy functional SpMM on a SMALL, UNSORTED COO in one launch.  Replaces the
+ * ATen composition of torch_sparse/spmm.py:25-31
+ *   (matrix.index_select(-2, col) * value.unsqueeze(-1)  ->  scatter_add over row)
+ * where launch latency is all that counts (BASELINE.json configs[0]).
+ *
+ *   out[r, :] = sum over entries e with row[e] == r of value[e] * mat[col[e], :]
+ *
+ *   row, col [E] int64 in any order, duplicates add up; value [E] dtype (required);
+ *   mat [N, K] dtype; out [M, K] dtype, fully written (rows without entries = 0).
+ * No workspace, no host sync, no pre-zeroed output.  fp sums are formed in
+ * arrival order (like a device scatter_add); integer sums are exact (wrapping).
+ * tsamd_spmm_coo_small_supported(...) == 0: use the sorted route (tsamd_sort_coo*
+ * + tsamd_ind2ptr + tsamd_spmm); the entry point itself then returns
+ * TSAMD_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------ */
+int tsamd_spmm_coo_small_supported(int dtype, int64_t E, int64_t M, int64_t K);
+int tsamd_spmm_coo_small(int dtype, const int64_t *row, const int64_t *col,
+                         const void *value, const void *mat, void *out,
+                         int64_t E, int64_t M, int64_t N, int64_t K, void *stream);
+
+/* ------------------------------------------------------------------------ *
  * Gradient of SUM/MEAN SpMM w.r.t. the sparse values (an SDDMM over the
  * pattern).  Replaces spmm_value_bw_cuda / spmm_value_bw_cpu
  * (csrc/cuda/spmm_cuda.cu:196-237, csrc/cpu/spmm_cpu.cpp:103-152).

@@ -17,8 +17,12 @@ __global__ void ind2ptr_kernel(const int64_t *__restrict__ ind, int64_t *__restr
                                int64_t M, int64_t E) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t > E) return;
-  const int64_t lo = t == 0 ? 0 : ind[t - 1] + 1;
-  const int64_t hi = t == E ? M : ind[t];
+  // ids outside [0, M) write nothing (the sort-on-construct path enqueues this kernel BEFORE its range check is
+  // read back: an invalid id must not reach past the (M + 1)-word output before the constructor raises)
+  int64_t lo = t == 0 ? 0 : ind[t - 1] + 1;
+  int64_t hi = t == E ? M : ind[t];
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > M ? M : hi;
   if (hi - lo >= kLongRun) return;
   for (int64_t i = lo; i <= hi; ++i) out[i] = t;
 }

@@ -760,6 +760,37 @@ Tensor ptr2ind(Tensor ptr, int64_t E) {
   return out;
 }
 
+// torch_sparse.spmm(index, value, m, n, matrix) on a small unsorted COO: ONE launch (tsamd_spmm_coo_small).  No
+// autograd: the Python front-end takes this route only when nothing asks for a gradient.
+bool spmm_coo_small_supported(Tensor value, int64_t E, int64_t M, int64_t K) {
+  switch (value.scalar_type()) {
+    case at::kFloat: case at::kDouble: case at::kHalf: case at::kBFloat16: case at::kInt: case at::kLong:
+    case at::kByte: case at::kChar: case at::kShort: break;
+    default: return false;
+  }
+  return tsamd_spmm_coo_small_supported(dtype_code(value), E, M, K) != 0;
+}
+
+Tensor spmm_coo_small(Tensor index, Tensor value, int64_t M, int64_t N, Tensor mat) {
+  check_gpu(index, "index");
+  check_gpu(value, "value");
+  check_gpu(mat, "matrix");
+  TORCH_CHECK(index.scalar_type() == at::kLong && index.dim() == 2 && index.size(0) == 2, "index must be [2, nnz] int64");
+  TORCH_CHECK(mat.dim() == 2 && mat.size(0) == N, "matrix must be [n, F]");
+  TORCH_CHECK(value.dim() == 1 && value.size(0) == index.size(1), "value must be [nnz]");
+  TORCH_CHECK(value.scalar_type() == mat.scalar_type(), "value and matrix must have the same dtype");
+  c10::hip::HIPGuard guard(mat.get_device());
+  index = index.contiguous();
+  value = value.contiguous();
+  mat = mat.contiguous();
+  const int64_t E = index.size(1), K = mat.size(1);
+  Tensor out = torch::empty({M, K}, mat.options().requires_grad(false));
+  check_status(tsamd_spmm_coo_small(dtype_code(mat), index.data_ptr<int64_t>(), index.data_ptr<int64_t>() + E,
+                                    value.data_ptr(), mat.data_ptr(), out.data_ptr(), E, M, N, K, current_stream(mat)),
+               "tsamd_spmm_coo_small");
+  return out;
+}
+
 int64_t cuda_version() { return tsamd_hip_version(); }
 
 // torch.are_deterministic_algorithms_enabled() for TorchScript callers (storage_spmm)
@@ -779,6 +810,8 @@ static auto registry_spmm = torch::RegisterOperators()
                            .op("torch_sparse::ind2ptr", &ind2ptr)
                            .op("torch_sparse::ptr2ind", &ptr2ind)
                            .op("torch_sparse::cuda_version", &cuda_version)
+                           .op("tsamd::spmm_coo_small", &spmm_coo_small)
+                           .op("tsamd::spmm_coo_small_supported", &spmm_coo_small_supported)
                            .op("tsamd::spmm_minmax", &spmm_minmax)
                            .op("tsamd::deterministic", &deterministic_mode)
                            .op("tsamd::spmm_sum_owned", &spmm_sum_owned)

@@ -203,31 +203,103 @@ def _native_partial(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_
     nat.spmm_partial(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_none, accumulate, deg_rowptr)
 
 
-class _ChunkedGather(torch.autograd.Function):
-    """The chunked all-gather of an ``OverlappedAllGatherSpMM`` for the training path: every chunk's collective is
-    enqueued asynchronously (the caller waits per chunk); backward = reduce-scatter of every buffer's gradient."""
+def _native_value_bw(row, rowptr, col, mat, grad):
+    """[E] gradient of the block's entries (SDDMM): tsamd_spmm_value_bw."""
+    from . import _native as nat
+    return nat.spmm_value_bw(row, rowptr, col, mat, grad, 'sum')
+
+
+def _native_minmax_bw(rowptr, col, value, mat, grad, arg, want_value):
+    """(grad_value [E] or None, grad_mat [rows of mat, K]) of a min / max block from its winners: tsamd_spmm_minmax_bw."""
+    from . import _native as nat
+    if value is not None and value.dtype != mat.dtype:
+        value = value.to(mat.dtype)
+    return nat.spmm_minmax_bw(rowptr, col, value, mat, grad, arg, want_value=want_value, want_mat=True)
+
+
+class _OverlappedProduct(torch.autograd.Function):
+    """One training step of an ``OverlappedAllGatherSpMM`` as ONE autograd node (round 5; before, every stage went
+    through the drop-in operator -- a probe and possibly a relabelled copy of each landed buffer per stage -- and
+    min / max fell back to the serial exchange).
+
+    forward  = the inference step: chunk collectives enqueued, partial products of the landed column blocks through
+               ``partial_fn`` (tsamd_spmm_partial: no copy of the landed operand); the landed buffers, the result's
+               winners (min / max) and the weights are kept for the backward.
+    backward, sum / mean (csrc/spmm.cpp:88-112 per column block):
+               grad of buffer c   = A[:, block c]^T g      partial product over the block's CSC arrays (built once)
+               -> reduce-scatter to the owners, enqueued as soon as the block's product is queued: it runs under the
+               next block's product; the local block comes last and needs no collective;
+               grad_value[block]  = SDDMM of the block (tsamd_spmm_value_bw) against the buffer it multiplied.
+    backward, min / max (csrc/spmm.cpp:204-242 per column block): the winner ids of the whole result are translated to
+               each block's entry numbering (entries of other blocks read as "no winner") and the block's scatter
+               kernel (tsamd_spmm_minmax_bw) yields grad_value[block] and the gradient of the block's buffer, which
+               is reduce-scattered like above -- the winner's gradient reaches the rank that owns the winning row of X.
+    Every rank issues the same collectives whatever its own inputs require (the differentiable path is entered by
+    all ranks or by none)."""
 
     @staticmethod
-    def forward(ctx, x_pad: Tensor, plan):
-        ctx.plan = plan
+    def forward(ctx, x_local: Tensor, value: Optional[Tensor], plan, reduce: str):
+        x_pad = plan.wire_order(x_local.detach())
         bufs = plan._start_gathers(x_pad)
-        return tuple(bufs)
+        works, plan._works = plan._works, []
+        vals = None if value is None else [value.detach()[st['src']] for st in plan.stages]
+        out, arg = plan.multiply_landed(x_pad, bufs, reduce, works, stage_values=vals)
+        ctx.plan, ctx.reduce, ctx.has_value = plan, reduce, value is not None
+        ctx.n_local = x_local.size(0)
+        ctx.mats = [x_pad] + list(bufs)
+        ctx.vals = vals
+        ctx.arg = arg
+        return out
 
     @staticmethod
-    def backward(ctx, *grads):
-        plan = ctx.plan
-        cs, world, rank = plan.cs, plan.world, plan.rank
-        pieces = []
-        for g in grads:
-            g = g.contiguous()
-            if dist.get_backend(plan.group) != 'gloo':
-                o = g.new_empty((cs, ) + tuple(g.shape[1:]))
-                dist.reduce_scatter_tensor(o, g, group=plan.group)
-            else:  # gloo has no reduce_scatter
-                dist.all_reduce(g, group=plan.group)
-                o = g[rank * cs:(rank + 1) * cs].clone()
-            pieces.append(o)
-        return torch.cat(pieces, 0), None
+    def backward(ctx, g: Tensor):
+        plan, reduce = ctx.plan, ctx.reduce
+        g = g.contiguous()
+        mats, vals, arg = ctx.mats, ctx.vals, ctx.arg
+        need_v = ctx.has_value and ctx.needs_input_grad[1]
+        minmax = reduce in ('min', 'max')
+        if reduce == 'mean':
+            deg = (plan.rowptr[1:] - plan.rowptr[:-1]).clamp(min=1).to(g.dtype)
+            g = g / deg.view(-1, *([1] * (g.dim() - 1)))
+        gv = None
+        if need_v:
+            gv = torch.zeros(plan.E, dtype=mats[0].dtype, device=g.device)
+        extra = plan.training_arrays()
+        arg_c, stage_of_arg = None, None
+        if minmax:
+            none = arg >= plan.E
+            arg_c = arg.masked_fill(none, 0)
+            stage_of_arg = extra['stage_of'][arg_c].masked_fill(none, -1)
+            arg_c = extra['local_id'][arg_c]
+        pieces, works = [None] * plan.chunks, []
+        g0 = None
+        for i in list(range(1, len(plan.stages))) + [0]:  # remote blocks first: their collectives run under what follows
+            st, ex = plan.stages[i], extra['stages'][i]
+            Ei = st['col'].numel()
+            v_i = None if vals is None else vals[i]
+            if minmax:
+                arg_i = torch.where(stage_of_arg == i, arg_c, torch.full_like(arg_c, Ei))
+                gval_i, gmat_i = plan.minmax_bw_fn(st['rowptr'], st['col'], v_i, mats[i], g, arg_i, need_v)
+            else:
+                gmat_i = mats[i].new_empty(mats[i].shape)
+                vt = None if v_i is None else v_i[ex['perm']]
+                plan.partial_fn(ex['colptr'], ex['rowidx'], vt, g, 'sum', gmat_i, None, None, Ei, False, None)
+                gval_i = plan.value_bw_fn(ex['row'], st['rowptr'], st['col'], mats[i], g) if need_v else None
+            if need_v and gval_i is not None:
+                gv[st['src']] = gval_i.to(gv.dtype)
+            if i == 0:
+                g0 = gmat_i
+            else:
+                o, w = plan._reduce_scatter(gmat_i)
+                pieces[i - 1] = o
+                works.append(w)
+        for w in works:
+            if w is not None:
+                w.wait()
+        grad_pad = g0 + torch.cat(pieces, 0)
+        grad_x = grad_pad.index_select(0, plan.positions[plan.rank][:ctx.n_local])  # row i sits at position positions[i]
+        ctx.mats = ctx.vals = ctx.arg = None
+        return grad_x, gv, None, None
 
 
 class OverlappedAllGatherSpMM(object):
@@ -247,18 +319,24 @@ class OverlappedAllGatherSpMM(object):
     per-owner schedule of point-to-point steps would not; the column blocks are "by owner AND chunk" instead.
     sum / mean / min / max; out (and arg_out) equal the serial product -- exactly for min / max (ties between
     blocks go to the smaller entry id), up to the association of the partial sums for sum / mean.
-    Differentiable for sum / mean (the chunk buffers are autograd nodes whose backward reduce-scatters);
-    min / max under autograd fall back to the serial path.
+    Differentiable for sum / mean / min / max: the training step is one autograd node (`_OverlappedProduct`) around the
+    same kernels; its backward multiplies every column block's transpose (or scatters the winners' gradients, min /
+    max) and reduce-scatters each buffer's gradient to the owners under the next block's product.
 
-    ``partial_fn(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_none, accumulate, deg_rowptr)`` is
-    injectable for the CPU (gloo) tests; the product default is tsamd_spmm_partial."""
+    ``partial_fn(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_none, accumulate, deg_rowptr)``,
+    ``value_bw_fn(row, rowptr, col, mat, grad)`` and ``minmax_bw_fn(rowptr, col, value, mat, grad, arg, want_value)``
+    are injectable for the CPU (gloo) tests; the product defaults are tsamd_spmm_partial / tsamd_spmm_value_bw /
+    tsamd_spmm_minmax_bw."""
 
     def __init__(self, rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
                  group=None, spmm_fn: Optional[Callable] = None, chunks: int = 4,
-                 partial_fn: Optional[Callable] = None, positions_fn: Optional[Callable] = None):
+                 partial_fn: Optional[Callable] = None, positions_fn: Optional[Callable] = None,
+                 value_bw_fn: Optional[Callable] = None, minmax_bw_fn: Optional[Callable] = None):
         self.group = group
         self.spmm_fn = spmm_fn or _default_spmm
         self.partial_fn = partial_fn or _native_partial
+        self.value_bw_fn = value_bw_fn or _native_value_bw
+        self.minmax_bw_fn = minmax_bw_fn or _native_minmax_bw
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         assert len(x_sizes) == self.world
@@ -284,6 +362,8 @@ class OverlappedAllGatherSpMM(object):
     # ---- exchange ----------------------------------------------------------------------------
     def wire_order(self, x_local: Tensor) -> Tensor:
         """[chunks * cs, K]: the local shard in the row order it is stored and sent in (padding rows are never read)."""
+        if x_local.size(0) == 0:  # a rank that owns no row of X still takes part in every collective
+            return x_local.new_zeros((self.inv.numel(), ) + tuple(x_local.shape[1:]))
         return pack_rows(x_local, self.inv) if not x_local.requires_grad else x_local.index_select(0, self.inv)
 
     def _start_gathers(self, x_pad: Tensor, reuse: bool = False):
@@ -320,15 +400,21 @@ class OverlappedAllGatherSpMM(object):
     def _stage_value(self, st):
         return None if self.value is None else self.value.detach()[st['src']]
 
-    def multiply_landed(self, x_pad: Tensor, bufs, reduce: str, works=None):
-        """The staged product on buffers that have landed (or land as `works` complete) -> (out, arg_out or None)."""
+    def multiply_landed(self, x_pad: Tensor, bufs, reduce: str, works=None, stage_values=None):
+        """The staged product on buffers that have landed (or land as `works` complete) -> (out, arg_out or None).
+        `stage_values`: the per-stage weights of THIS call (the training step); None = the cached copies of self.value."""
         minmax = reduce in ('min', 'max')
         out = x_pad.new_empty((self.rows, ) + tuple(x_pad.shape[1:]))
         arg = torch.empty(out.shape, dtype=torch.long, device=out.device) if minmax else None
         last = len(self.stages) - 1
-        if getattr(self, '_stage_values_of', self) is not self.value:  # fixed weights: gathered once per value tensor
+        # the per-stage copies of the edge weights are gathered once per STATE of the value tensor: identity, storage
+        # and version counter (an optimizer step updates a trainable value in place: the next inference call must
+        # see it, ADVICE r4)
+        vkey = None if self.value is None else (id(self.value), self.value.data_ptr(), self.value._version)
+        if stage_values is None and getattr(self, '_stage_values_key', 0) != vkey:
             self._stage_values = [self._stage_value(st) for st in self.stages]
-            self._stage_values_of = self.value
+            self._stage_values_key = vkey
+        svals = stage_values if stage_values is not None else self._stage_values
         for i, st in enumerate(self.stages):
             mat = x_pad if i == 0 else bufs[i - 1]
             if i > 0 and works is not None:
@@ -336,7 +422,7 @@ class OverlappedAllGatherSpMM(object):
             red = reduce
             if reduce == 'mean' and i < last:
                 red = 'sum'
-            self.partial_fn(st['rowptr'], st['col'], self._stage_values[i], mat, red, out, arg,
+            self.partial_fn(st['rowptr'], st['col'], svals[i], mat, red, out, arg,
                             st['src'] if minmax else None, self.E, i > 0, self.rowptr if red == 'mean' else None)
         return out, arg
 
@@ -360,23 +446,45 @@ class OverlappedAllGatherSpMM(object):
         return (out, arg) if return_arg else out
 
     def _differentiable(self, x_local: Tensor, reduce: str) -> Tensor:
-        if reduce in ('min', 'max'):  # the winner's gradient crosses blocks: serial path
-            return RowShardedSpMM(self.rowptr, self.col, self.value, self.x_sizes, self.group, self.spmm_fn)(x_local, reduce)
-        x_pad = x_local.index_select(0, self.inv)
-        bufs = _ChunkedGather.apply(x_pad, self)
-        works, self._works = self._works, []
-        total = None
+        """The training step: one autograd node (`_OverlappedProduct`) around the inference step's kernels."""
+        return _OverlappedProduct.apply(x_local, self.value, self, reduce)
+
+    def training_arrays(self):
+        """What only the backward needs, built on first use: per column block the CSC view (colptr over the rows of the
+        buffer it multiplies, the local row of every entry in column order, the CSR -> CSC permutation) and the local
+        row of every entry in CSR order; for min / max the block and the block-local id of every entry of the row
+        block.  Index arrays only: the weights are gathered per step."""
+        cached = getattr(self, '_training', None)
+        if cached is not None:
+            return cached
+        dev = self.col.device
+        M = self.rows
+        stage_of = torch.empty(self.E, dtype=torch.long, device=dev)
+        local_id = torch.empty(self.E, dtype=torch.long, device=dev)
+        stages = []
         for i, st in enumerate(self.stages):
-            mat = x_pad if i == 0 else bufs[i - 1]
-            if i > 0:
-                works[i - 1].wait()
-            v = None if self.value is None else self.value[st['src']]
-            part = self.spmm_fn(st['rowptr'], st['col'], v, mat, 'sum')
-            total = part if total is None else total + part
-        if reduce == 'mean':
-            deg = (self.rowptr[1:] - self.rowptr[:-1]).clamp(min=1).to(total.dtype)
-            total = total / deg.view(-1, *([1] * (total.dim() - 1)))
-        return total
+            src, col = st['src'], st['col']
+            n_i = self.chunks * self.cs if i == 0 else self.world * self.cs
+            row = torch.repeat_interleave(torch.arange(M, dtype=torch.long, device=dev), st['rowptr'][1:] - st['rowptr'][:-1])
+            perm = torch.sort(col, stable=True)[1]
+            colptr = torch.zeros(n_i + 1, dtype=torch.long, device=dev)
+            if col.numel() > 0:
+                torch.cumsum(torch.bincount(col, minlength=n_i), 0, out=colptr[1:])
+            stages.append(dict(row=row, perm=perm, colptr=colptr, rowidx=row[perm].contiguous()))
+            stage_of[src] = i
+            local_id[src] = torch.arange(src.numel(), dtype=torch.long, device=dev)
+        self._training = dict(stages=stages, stage_of=stage_of, local_id=local_id)
+        return self._training
+
+    def _reduce_scatter(self, gbuf: Tensor):
+        """Gradient of a landed buffer [world * cs, K] -> this rank's chunk [cs, K], asynchronously -> (chunk, work)."""
+        cs = self.cs
+        gbuf = gbuf.contiguous()
+        if dist.get_backend(self.group) != 'gloo':
+            o = gbuf.new_empty((cs, ) + tuple(gbuf.shape[1:]))
+            return o, dist.reduce_scatter_tensor(o, gbuf, group=self.group, async_op=True)
+        dist.all_reduce(gbuf, group=self.group)  # gloo has no reduce_scatter
+        return gbuf[self.rank * cs:(self.rank + 1) * cs].clone(), None
 
 
 class _ExchangeRows(torch.autograd.Function):

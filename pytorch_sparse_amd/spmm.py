@@ -5,6 +5,8 @@ Here the COO is ordered once (stable radix sort decided on the device, duplicate
 as in the reference) and the CSR SpMM kernel does the rest, without a host sync; autograd w.r.t. ``value`` and ``matrix`` comes
 from the op's own backward kernels.
 """
+from typing import Optional
+
 import torch
 from torch import Tensor
 
@@ -15,6 +17,13 @@ def spmm(index: Tensor, value: Tensor, m: int, n: int, matrix: Tensor) -> Tensor
     matrix = matrix if matrix.dim() > 1 else matrix.unsqueeze(-1)
     value = value.to(matrix.dtype) if value.dtype != matrix.dtype else value
     nnz = col.numel()
+    # small inputs, nothing to differentiate: ONE launch on the unsorted COO (tsamd_spmm_coo_small: workgroups own row
+    # ranges of `out` in LDS and scan the entries) -- what the reference's three ATen calls do, without the [nnz, F]
+    # temporary; the sorted route below costs 8+ launches whatever the size
+    wants_grad = torch.is_grad_enabled() and (value.requires_grad or matrix.requires_grad)
+    if (matrix.is_cuda and matrix.dim() == 2 and not wants_grad and index.dim() == 2 and
+            torch.ops.tsamd.spmm_coo_small_supported(value, nnz, m, matrix.size(1))):
+        return torch.ops.tsamd.spmm_coo_small(index, value.detach(), m, n, matrix.detach())
     if nnz > 1:
         # ordered on the device without asking the host (tsamd::sort_coo_auto: a sorted input only pays the
         # probe and a copy): the whole call enqueues kernels and returns -- no sync
@@ -22,7 +31,8 @@ def spmm(index: Tensor, value: Tensor, m: int, n: int, matrix: Tensor) -> Tensor
         value = value.index_select(0, perm)  # differentiable gather (the identity when the input was in order)
     rowptr = torch.ops.torch_sparse.ind2ptr(row, m)
     need_csc = matrix.requires_grad
-    colptr = csr2csc = None
+    colptr: Optional[Tensor] = None
+    csr2csc: Optional[Tensor] = None
     if need_csc:
         _, _, csr2csc = torch.ops.tsamd.sort_coo(col, row, n, m, False)
         colptr = torch.ops.torch_sparse.ind2ptr(col[csr2csc], n)

@@ -113,7 +113,7 @@ class SparseStorage(object):
         # Both sizes given, unsorted COO, no caller caches to preserve: the check, the device-decided sort and the
         # gather of the values are ENQUEUED back to back and the check's four words are read afterwards -- the one
         # read-back no longer sits between the probe and the sort (an out-of-range id is still reported, after a
-        # sort whose result is then thrown away; nothing indexes with the unchecked ids before that)
+        # sort whose result is then thrown away; ind2ptr clamps the ids it fills with to [0, M], csrc/convert.hip)
         presorted_row: Optional[Tensor] = None
         presorted_col: Optional[Tensor] = None
         presorted_value: Optional[Tensor] = None

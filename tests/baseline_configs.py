@@ -181,30 +181,31 @@ def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5, fp64_leg=True):
     All operands are host tensors except out_gpu.  fp64_leg=False (the configs[4]-share TEST: 537 M elements; the
     bench line's row of the same workload keeps the full statistics) drops the third host product -- the fp64 one --
     and what is derived from it; the whole output is still compared with the reference's fp32 output."""
-    a = out_gpu.detach().cpu()
+    dev = out_gpu.device  # the statistics run with ATen in fp64 ON THE DEVICE (independent of the kernels under test):
+    a = out_gpu.detach()  # 268-537 M elements take seconds there instead of a minute on the host
     if ref_out is None:
         ref_out = ref_spmm_cpu(rp, c, v, x, 'sum')[0]
-    l1 = ref_spmm_cpu(rp, c, None if v is None else v.abs(), x.abs(), 'sum')[0].double()
+    l1 = ref_spmm_cpu(rp, c, None if v is None else v.abs(), x.abs(), 'sum')[0].to(dev).double()
+    refd = ref_out.to(dev).double()
     if not fp64_leg:
         l1c = l1.clamp(min=1e-30)
-        refd = ref_out.double()
         d = (a.double() - refd).abs()
         bad = d > 1e-5 * refd.abs()
         res = dict(elements=int(a.numel()),
                    against='reference CPU kernel (csrc/cpu/spmm_cpu.cpp via oracle/_ref), whole output; criterion: '
                            '|gpu - ref| <= 1e-5 * sum_e|v_e x_e| for every element, plus |gpu - ref| <= 1e-5 * |ref| for '
-                           'every element with |ref| >= 0.1 * sum_e|v_e x_e| (fp64 statistics: see the bench line)',
+                           'every element with |ref| >= 0.1 * sum_e|v_e x_e| (fp64 statistics: headline row)',
                    max_err_over_l1=float((d / l1c).max()), tol_over_l1=tol,
                    n_rel_gt_1e_5_where_ref_ge_1e_1_l1=int((bad & (refd.abs() >= 1e-1 * l1)).sum()))
         res['ok'] = bool(res['max_err_over_l1'] <= tol and res['n_rel_gt_1e_5_where_ref_ge_1e_1_l1'] == 0)
         return res
-    exact = ref_spmm_cpu(rp, c, None if v is None else v.double(), x.double(), 'sum')[0]
+    exact = ref_spmm_cpu(rp, c, None if v is None else v.double(), x.double(), 'sum')[0].to(dev)
     l1c = l1.clamp(min=1e-30)
-    refd = ref_out.double()
-    d = (a.double() - refd).abs()
+    ad = a.double()
+    d = (ad - refd).abs()
     relb = d / refd.abs().clamp(min=1e-30)
     bad = relb > 1e-5
-    e_ours = (a.double() - exact).abs() / l1c
+    e_ours = (ad - exact).abs() / l1c
     e_ref = (refd - exact).abs() / l1c
     rel_ref64 = (refd - exact).abs() / exact.abs().clamp(min=1e-30)
     res = dict(elements=int(a.numel()),
@@ -218,6 +219,7 @@ def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5, fp64_leg=True):
                n_elements_ref_ge_1e_2_l1=int((refd.abs() >= 1e-2 * l1).sum()),
                ref_vs_fp64_frac_rel_gt_1e_5=float((rel_ref64 > 1e-5).double().mean()),
                ours_vs_fp64_over_l1=float(e_ours.max()), ref_vs_fp64_over_l1=float(e_ref.max()))
+    del d, relb, bad, e_ours, e_ref, rel_ref64
     # SURVEY 8(d)'s bound as written: |a - b| <= 1e-5 * max(|b|, 1e-5 * ||row||_1).  It is element-wise relative
     # down to 1e-5 of the row's L1 mass, i.e. it also bites on cancelled sums -- where ANY fp32 summation order,
     # the reference's own sequential one included, misses it against the exact (fp64) sum.  So the counts are
@@ -227,7 +229,7 @@ def sum_parity(out_gpu, rp, c, v, x, ref_out=None, tol=1e-5, fp64_leg=True):
         return int(((a_ - b_).abs() > 1e-5 * torch.maximum(b_.abs(), 1e-5 * l1)).sum())
     res['survey_8d_literal_bound'] = dict(
         bound='|a - b| <= 1e-5 * max(|b|, 1e-5 * L1(row))',
-        n_viol_ours_vs_ref=literal(a.double(), refd), n_viol_ours_vs_fp64=literal(a.double(), exact),
+        n_viol_ours_vs_ref=literal(ad, refd), n_viol_ours_vs_fp64=literal(ad, exact),
         n_viol_ref_vs_fp64=literal(refd, exact))
     lb = res['survey_8d_literal_bound']
     lb['ours_le_ref'] = bool(lb['n_viol_ours_vs_fp64'] <= lb['n_viol_ref_vs_fp64'])
@@ -460,8 +462,8 @@ def run_c3(dev, has_value, cpu=True, iters=10):
                                    ms=round(t * 1e3, 2), sample='full workload forward, best of %d' % runs)
         # forward: bit-exact values and arg_out over all M*K elements
         par['elements'] = int(ra.numel())
-        par['arg_out_mismatches'] = int((arg.cpu() != ra).sum())
-        par['out_bit_mismatches'] = int((out.cpu().view(torch.int16) != ro.view(torch.int16)).sum())
+        par['arg_out_mismatches'] = int((arg != ra.to(dev)).sum())  # compared on the device (ATen)
+        par['out_bit_mismatches'] = int((out.view(torch.int16) != ro.to(dev).view(torch.int16)).sum())
         par['against'] = 'reference CPU kernel (forward, bit-exact); fp64 formulas of csrc/spmm.cpp:204-242 (backward)'
     par['ok'] = bool(par.get('arg_out_mismatches', 0) == 0 and par.get('out_bit_mismatches', 0) == 0 and
                      par['grad_mat_max_err_over_bound'] <= 1.0 and par['grad_mat_autograd_equal_bound'] <= 1.0 and
@@ -580,11 +582,12 @@ def run_spspmm(dev, kind='c4', cpu=True, iters=5):
                                    ms=round(t * 1e3, 1), sample='full workload, torch.sparse.mm on the host, 1 run')
         Cc = Cc.coalesce()
         row, col, val = C.coo()
-        idx_ok = torch.equal(torch.stack([row, col]).cpu(), Cc._indices())
-        ev = Cc._values().double()
+        ci = Cc._indices().to(dev)  # whole-output comparison with ATen on the device
+        idx_ok = bool(ci.size(1) == row.numel() and torch.equal(row, ci[0]) and torch.equal(col, ci[1]))
+        ev = Cc._values().to(dev).double()
         # fp32 sums of ~1 product each, different order: 1e-5 relative to the L1 mass (>= |value|)
         l1 = (A.set_value(A.storage.value().abs(), 'coo') @ At.set_value(At.storage.value().abs(), 'coo')).storage.value()
-        err = float(((val.cpu().double() - ev).abs() / l1.cpu().double().clamp(min=1e-30)).max()) if idx_ok else float('inf')
+        err = float(((val.double() - ev).abs() / l1.double().clamp(min=1e-30)).max()) if idx_ok else float('inf')
         res['parity'] = dict(against='torch.sparse.mm (CPU), whole output', nnz=int(nnzC), index_bit_exact=bool(idx_ok),
                              value_max_err_over_l1=err, tol_over_l1=1e-5, ok=bool(idx_ok and err <= 1e-5))
     return res

@@ -35,8 +35,11 @@ def torch_spmm_sum(rowptr, col, value, x, reduce):
     M = rowptr.numel() - 1
     row = torch.repeat_interleave(torch.arange(M), rowptr[1:] - rowptr[:-1])
     prod = value[:, None] * x[col]
-    if reduce == 'sum':
-        return torch.zeros(M, x.size(1), dtype=x.dtype).index_add_(0, row, prod)
+    if reduce in ('sum', 'mean'):
+        tot = torch.zeros(M, x.size(1), dtype=x.dtype).index_add_(0, row, prod)
+        if reduce == 'mean':
+            tot = tot / (rowptr[1:] - rowptr[:-1]).clamp(min=1).to(x.dtype)[:, None]
+        return tot
     assert reduce in ('min', 'max')
     return torch.zeros(M, x.size(1), dtype=x.dtype).scatter_reduce(
         0, row[:, None].expand_as(prod), prod, reduce='a' + reduce, include_self=False)
@@ -54,8 +57,8 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
         # forward parity for every reduction, local multiply = C oracle
         kw = {}
         if exchange == 'allgather':  # the overlapped all-gather: column-block partial products, combined by the
-            from tests.util import ref_partial  # restated contract of tsamd_spmm_partial; a shuffled wire order
-            kw = dict(chunks=3, partial_fn=ref_partial,
+            from tests.util import ref_minmax_bw, ref_partial, ref_value_bw  # restated contracts of tsamd_spmm_partial /
+            kw = dict(chunks=3, partial_fn=ref_partial, value_bw_fn=ref_value_bw, minmax_bw_fn=ref_minmax_bw,  # _value_bw / _minmax_bw
                       positions_fn=lambda k, dev: torch.randperm(k, generator=torch.Generator().manual_seed(k)))
         op, (s, e) = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=oracle_spmm, exchange=exchange, **kw)
         sizes = op.x_sizes
@@ -84,7 +87,7 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
         opd, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=torch_spmm_sum, exchange=exchange, **kw)
         e0, e1 = int(rp[s]), int(rp[e])
         ok = True
-        for reduce in ('sum', 'max', 'min'):
+        for reduce in ('sum', 'mean', 'max', 'min'):
             xl = x_local.clone().requires_grad_()
             vl = v[e0:e1].clone().requires_grad_()
             if hasattr(opd, 'pieces'):  # pipelined: the pieces hold views of the value array
@@ -103,6 +106,22 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
             ok = ok and bool(torch.allclose(xl.grad, xg.grad[xs:xs + sizes[rank]], rtol=1e-5, atol=1e-5))
             ok = ok and bool(torch.allclose(vl.grad, vg.grad[e0:e1], rtol=1e-5, atol=1e-5))
         res['grad'] = ok
+        if exchange == 'allgather':
+            # the training step is ONE autograd node around the inference step's kernels: same forward values
+            with torch.no_grad():
+                inf = opd(x_local, 'max', differentiable=False)
+            trn = opd(x_local.clone().requires_grad_(), 'max')
+            res['grad'] = res['grad'] and bool(torch.equal(inf, trn.detach())) and type(trn.grad_fn).__name__.startswith('_OverlappedProduct')
+            # edge weights updated in place between two inference calls (optimizer.step() on a trainable value, then
+            # eval): the per-stage copies of the weights must follow (they were keyed on identity only)
+            w = v[e0:e1].clone()
+            opi, _ = shard_matrix(rp, c, v, n, balance=balance, spmm_fn=oracle_spmm, exchange=exchange, **kw)
+            opi.value = w
+            a = opi(x_local, 'sum', differentiable=False)
+            with torch.no_grad():
+                w.mul_(2.0)
+            b = opi(x_local, 'sum', differentiable=False)
+            res['grad'] = res['grad'] and bool(torch.allclose(b, 2.0 * a, rtol=1e-6, atol=1e-6))
         res['range'] = (s, e)
         q.put((rank, res))
     finally:

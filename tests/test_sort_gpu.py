@@ -130,3 +130,21 @@ def test_constructor_rejects_out_of_range_and_negative_ids(dev, E):
         (r_ if which == 'row' else c_)[E // 2] = bad
         with pytest.raises((AssertionError, RuntimeError)):
             ts.SparseTensor(row=r_.to(dev), col=c_.to(dev), value=val.to(dev), sparse_sizes=(m, n))
+
+
+def test_ind2ptr_never_writes_past_its_output_on_invalid_ids(dev):
+    """the sort-on-construct path enqueues ind2ptr on rows whose range check has not been read back yet.
+    Ids in (M, M + 1024) and negative ids must not make the fill loop write outside the (M + 1)-word output: the
+    words in front of and behind it keep their sentinel."""
+    from pytorch_sparse_amd import _native as nat
+    L = nat.lib()
+    M, guard = 1000, 4096
+    for bad in ([M + 1, M + 500, M + 1023], [-3, -1], [M + 5000], [M, M]):
+        ind = torch.tensor(sorted([5, 7, 7, 400] + bad), dtype=torch.long, device=dev)
+        buf = torch.full((guard + M + 1 + guard, ), 0x5A5A5A5A, dtype=torch.long, device=dev)
+        out = buf[guard:guard + M + 1]
+        with torch.cuda.device(dev):
+            st = L.tsamd_ind2ptr(nat._ptr(ind), nat._i64(M), nat._i64(ind.numel()), nat._ptr(out), nat.stream_ptr(dev))
+        assert st == 0
+        torch.cuda.synchronize()
+        assert bool((buf[:guard] == 0x5A5A5A5A).all()) and bool((buf[guard + M + 1:] == 0x5A5A5A5A).all()), bad

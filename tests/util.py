@@ -120,3 +120,17 @@ def ref_partial(rowptr, col, value, mat, reduce, out, arg_out, arg_map, arg_none
     take = take & (deg > 0)
     out.copy_(torch.where(take, po, ev))
     arg_out.copy_(torch.where(take, ca, ea))
+
+
+def ref_value_bw(row, rowptr, col, mat, grad):
+    """Injected value_bw_fn of the gloo tests: the C oracle's SDDMM (csrc/cpu/spmm_cpu.cpp:103-152 restated)."""
+    gv = oc.spmm_value_bw(CODE[mat.dtype], 'sum', tonp(row), tonp(rowptr), tonp(col), tonp(mat), tonp(grad))
+    return fromnp(gv, mat.dtype)
+
+
+def ref_minmax_bw(rowptr, col, value, mat, grad, arg, want_value):
+    """Injected minmax_bw_fn of the gloo tests: the C oracle's restatement of csrc/spmm.cpp:204-242 -> (grad_value or
+    None, grad_mat)."""
+    gv, gm = oc.spmm_minmax_bw(CODE[mat.dtype], tonp(col), tonp(value), tonp(mat), tonp(grad), tonp(arg),
+                               want_value=want_value and value is not None, want_mat=True)
+    return (None if gv is None else fromnp(gv, mat.dtype)), fromnp(gm, mat.dtype)
