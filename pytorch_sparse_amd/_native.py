@@ -19,6 +19,7 @@ SYMBOLS = [
     'tsamd_spmm_partial_workspace_bytes', 'tsamd_spmm_partial',
     'tsamd_spmm_operand_cache_bytes', 'tsamd_spmm_cached_workspace_bytes', 'tsamd_spmm_cached',
     'tsamd_gather_rows', 'tsamd_relabel_ids', 'tsamd_spmm_relabelled_workspace_bytes', 'tsamd_spmm_relabelled',
+    'tsamd_spmm_coo_small_supported', 'tsamd_spmm_coo_small',
     'tsamd_spmm_value_bw',
     'tsamd_spmm_minmax_bw_workspace_bytes', 'tsamd_spmm_minmax_bw',
     'tsamd_spmm_minmax_bw_csc_workspace_bytes', 'tsamd_spmm_minmax_bw_csc',

@@ -771,14 +771,15 @@ bool spmm_coo_small_supported(Tensor value, int64_t E, int64_t M, int64_t K) {
   return tsamd_spmm_coo_small_supported(dtype_code(value), E, M, K) != 0;
 }
 
+// -> the product [M, K], or an EMPTY 1-D tensor when the direct route does not take this problem (too big, a batch
+// of matrices, a dtype it has no kernel for): one operator call decides and computes, the caller falls through to the
+// sorted route on the sentinel.
 Tensor spmm_coo_small(Tensor index, Tensor value, int64_t M, int64_t N, Tensor mat) {
-  check_gpu(index, "index");
-  check_gpu(value, "value");
-  check_gpu(mat, "matrix");
-  TORCH_CHECK(index.scalar_type() == at::kLong && index.dim() == 2 && index.size(0) == 2, "index must be [2, nnz] int64");
-  TORCH_CHECK(mat.dim() == 2 && mat.size(0) == N, "matrix must be [n, F]");
-  TORCH_CHECK(value.dim() == 1 && value.size(0) == index.size(1), "value must be [nnz]");
-  TORCH_CHECK(value.scalar_type() == mat.scalar_type(), "value and matrix must have the same dtype");
+  if (!(index.device().is_cuda() && value.device().is_cuda() && mat.device().is_cuda()) || mat.dim() != 2 ||
+      index.dim() != 2 || index.size(0) != 2 || index.scalar_type() != at::kLong || value.dim() != 1 ||
+      value.size(0) != index.size(1) || value.scalar_type() != mat.scalar_type() || mat.size(0) != N ||
+      !spmm_coo_small_supported(value, index.size(1), M, mat.size(1)))
+    return torch::empty({0}, mat.options().requires_grad(false));
   c10::hip::HIPGuard guard(mat.get_device());
   index = index.contiguous();
   value = value.contiguous();

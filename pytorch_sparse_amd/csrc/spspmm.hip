@@ -28,6 +28,7 @@
 #include "common.h"
 #include "scan.h"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -1121,15 +1122,49 @@ constexpr int kMaxRanges = 8192;         // LDS counters / cursors of the hist a
 template <typename T>
 constexpr int kLgRange = sizeof(typename Traits<T>::acc_t) == 4 ? TSAMD_SPSPMM_LG_RANGE : TSAMD_SPSPMM_LG_RANGE - 1;  // fp32 / fp64 columns per range
 
+// Scratch layout of the binned products (round 5).  4-byte values: ONE array of (column, value) pairs -- the bin kernel
+// stores 8 bytes per product with one instruction (two 4-byte stores into two arrays wrote 22 GB for 17 GB of payload
+// on the stress product: a wave's run of a few products per range is a partial line in BOTH arrays) and the numeric
+// kernels fetch a product with one 8-byte load; the symbolic kernels read the columns with stride 2.  8-byte values
+// keep the two arrays (a 12-byte pair has no aligned store).
+#ifndef TSAMD_SPSPMM_PAIRS
+#define TSAMD_SPSPMM_PAIRS 1
+#endif
+template <typename T>
+constexpr bool kPairs = TSAMD_SPSPMM_PAIRS && sizeof(T) == 4;
+template <typename T>
+__device__ __forceinline__ void bin_load(const uint32_t *__restrict__ bcol, const T *__restrict__ bval, int64_t p, bool want_val,
+                                         uint32_t &c, typename Traits<T>::acc_t &v) {
+  using A = typename Traits<T>::acc_t;
+  if constexpr (kPairs<T>) {
+    const uint2 e = reinterpret_cast<const uint2 *>(bcol)[p];
+    c = e.x;
+    T t;
+    __builtin_memcpy(&t, &e.y, 4);
+    v = want_val ? Traits<T>::to_acc(t) : A(0);
+  } else {
+    c = bcol[p];
+    v = want_val ? Traits<T>::to_acc(bval[p]) : A(0);
+  }
+}
+
+// Sub-bins (round 5: reproducible sums).  The four waves of a workgroup take a FIXED subset of a row's products
+// (product q of a chunk goes to thread q mod 256), but their cursor atomics interleaved in arrival order, so the ORDER
+// of a bin's products in the scratch changed from run to run -- and with it the rounding of every sum formed in that
+// order.  Now every (row, range) bin is cut into `sub` = 4 consecutive segments, one per wave (counted separately
+// here, reserved separately in the bin kernel): inside a wave the reservations happen in program order and the heads
+// of one instruction are served in lane order, so a bin's content is the same sequence every run.  sub = 1 (more than
+// kMaxRanges / 4 ranges: the counters would not fit LDS) keeps the shared cursors -- and the run-dependent order.
 __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
     const int64_t *__restrict__ rowptrB, const uint32_t *__restrict__ colB,
-    const int64_t *__restrict__ rows, int lg_range, int nr, int64_t *__restrict__ hist) {
+    const int64_t *__restrict__ rows, int lg_range, int nr, int sub, int64_t *__restrict__ hist) {
   __shared__ int cnt[kMaxRanges];
   __shared__ ExpandScratch<float> sc;
   const int tid = (int)threadIdx.x;
   const int64_t i = rows[blockIdx.x];
-  for (int q = tid; q < nr; q += kLargeThreads) cnt[q] = 0;
+  const int nc = nr * sub;
+  for (int q = tid; q < nc; q += kLargeThreads) cnt[q] = 0;
   __syncthreads();
   // Consecutive products come from one sorted B row, so the 64 lanes of a wave form a few RUNS of equal range:
   // the head of every run adds the run's length with one LDS atomic (all heads in the same instruction, mostly
@@ -1137,6 +1172,7 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
   // operand are 64 counters, per-product atomics serialise on them.  The active lanes of a step are a prefix of
   // the wave (q < total cuts a suffix), so "the lane below" is active for every active lane but lane 0.
   const int lane = tid & 63;
+  const int wsel = sub == 1 ? 0 : (tid >> 6);
   expand_row<float, kLargeThreads, false, true>(colA, nullptr, rowptrB, colB, nullptr, rowptrA[i], rowptrA[i + 1], sc,
                                                 [&](int, uint32_t c, float) {
     const int q = (int)(c >> lg_range);
@@ -1146,28 +1182,37 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
     if (head) {
       const unsigned long long above = hm & ~((2ull << lane) - 1ull);
       const int next = above ? (int)__builtin_ctzll(above) : 64 - (int)__builtin_clzll(act);
-      atomicAdd(&cnt[q], next - lane);
+      atomicAdd(&cnt[q * sub + wsel], next - lane);
     }
   });
   __syncthreads();
-  for (int q = tid; q < nr; q += kLargeThreads) hist[(int64_t)blockIdx.x * nr + q] = cnt[q];
+  for (int q = tid; q < nc; q += kLargeThreads) hist[(int64_t)blockIdx.x * nc + q] = cnt[q];
+}
+
+// bin_off[t] = offset of the first sub-bin of bin t (the consumers of the bins do not care about the cut)
+__global__ __launch_bounds__(256) void spspmm_bin_offsets_kernel(const int64_t *__restrict__ sub_off, int sub,
+                                                                int64_t ntask, int64_t *__restrict__ bin_off) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t <= ntask) bin_off[t] = sub_off[t * sub];
 }
 
 template <typename T, bool WITH_VAL>
 __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA, const T *__restrict__ valA,
     const int64_t *__restrict__ rowptrB, const uint32_t *__restrict__ colB, const T *__restrict__ valB,
-    const int64_t *__restrict__ rows, int lg_range, int nr, const int64_t *__restrict__ bin_off,
+    const int64_t *__restrict__ rows, int lg_range, int nr, int sub, const int64_t *__restrict__ sub_off,
     uint32_t *__restrict__ bcol, T *__restrict__ bval) {
   using A = typename Traits<T>::acc_t;
   __shared__ int cursor[kMaxRanges];
   __shared__ ExpandScratch<A> sc;
   const int tid = (int)threadIdx.x;
   const int64_t i = rows[blockIdx.x];
-  for (int q = tid; q < nr; q += kLargeThreads) cursor[q] = 0;
+  const int nc = nr * sub;
+  for (int q = tid; q < nc; q += kLargeThreads) cursor[q] = 0;
   __syncthreads();
-  const int64_t *off = bin_off + (int64_t)blockIdx.x * nr;
+  const int64_t *off = sub_off + (int64_t)blockIdx.x * nc;
   const int lane = tid & 63;
+  const int wsel = sub == 1 ? 0 : (tid >> 6);  // this wave's segment of every bin (see the hist kernel)
   expand_row<T, kLargeThreads, WITH_VAL, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
                                                [&](int, uint32_t c, A v) {
     // runs of equal range inside the wave (see the hist kernel): the head of a run reserves the run's slots
@@ -1183,12 +1228,25 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
     if (head) {
       const unsigned long long above = hm & ~((2ull << lane) - 1ull);
       const int next = above ? (int)__builtin_ctzll(above) : 64 - (int)__builtin_clzll(act);
-      base = atomicAdd(&cursor[q], next - lane);
+      base = atomicAdd(&cursor[q * sub + wsel], next - lane);
     }
     base = lane_read(base, leader);
-    const int64_t pos = off[q] + base + (lane - leader);
-    bcol[pos] = c;  // the FULL column: small bins are merged across ranges (classify), the dense kernels mask
-    if (WITH_VAL) bval[pos] = Traits<T>::from_acc(v);
+    const int64_t pos = off[q * sub + wsel] + base + (lane - leader);
+    // the FULL column: small bins are merged across ranges (classify), the dense kernels mask
+    if constexpr (kPairs<T>) {
+      if (WITH_VAL) {
+        const T t = Traits<T>::from_acc(v);
+        uint2 e;
+        e.x = c;
+        __builtin_memcpy(&e.y, &t, 4);
+        reinterpret_cast<uint2 *>(bcol)[pos] = e;
+      } else {
+        bcol[2 * pos] = c;
+      }
+    } else {
+      bcol[pos] = c;
+      if (WITH_VAL) bval[pos] = Traits<T>::from_acc(v);
+    }
   });
 }
 
@@ -1244,7 +1302,7 @@ struct BinFeed {
 // symbolic: distinct columns per bin, added up per row
 __global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
     const int64_t *__restrict__ rows, int nr, const int64_t *__restrict__ big, const int64_t *__restrict__ n_big,
-    const int64_t *__restrict__ bin_off, const uint32_t *__restrict__ bcol, int range_words,
+    const int64_t *__restrict__ bin_off, const uint32_t *__restrict__ bcol, int bstride, int range_words,
     int64_t *__restrict__ bin_cnt, unsigned long long *__restrict__ nnzC, unsigned long long *queue) {
   __shared__ uint32_t bits[(1 << 15) / 32];
   __shared__ int s_part[kAccumThreads / 64];
@@ -1263,7 +1321,7 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_count_kernel(
 #pragma unroll
       for (int u = 0; u < kBinBatch; ++u) {
         const int64_t p = p0 + (int64_t)u * kAccumThreads;
-        c[u] = bcol[p < b1 ? p : b1 - 1] & (uint32_t)(range_words * 32 - 1);  // a repeated entry sets the same bit again
+        c[u] = bcol[(p < b1 ? p : b1 - 1) * bstride] & (uint32_t)(range_words * 32 - 1);  // a repeated entry sets the same bit again
       }
 #pragma unroll
       for (int u = 0; u < kBinBatch; ++u) atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
@@ -1323,8 +1381,8 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
       for (int u = 0; u < kBinBatch; ++u) {
         const int64_t p = p0 + (int64_t)u * kAccumThreads;
         const bool ok = p < b1;
-        c[u] = bcol[ok ? p : b1 - 1] & (uint32_t)(kCols - 1);
-        v[u] = (ok && valC != nullptr) ? Traits<T>::to_acc(bval[p]) : A(0);  // a repeat adds zero
+        bin_load<T>(bcol, bval, ok ? p : b1 - 1, ok && valC != nullptr, c[u], v[u]);  // a repeat adds zero
+        c[u] &= (uint32_t)(kCols - 1);
       }
 #pragma unroll
       for (int u = 0; u < kBinBatch; ++u) {
@@ -1376,6 +1434,100 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
     __syncthreads();
     if (wd) bits[tid] = 0;
     __syncthreads();  // the bitmap is clear before the next bin sets bits
+  }
+}
+
+// numeric, big bins, REPRODUCIBLE form (round 5, the default when the bins were cut into per-wave segments): ONE wave per
+// bin.  The bin's products are added in their scratch order -- ascending positions, 64 per LDS instruction: the
+// instructions of one wave execute in program order and the lanes of one ds_add_f32 that hit the same accumulator are
+// served in a fixed order -- so every sum is formed in the same order every run (the 256-thread kernel above lets four
+// waves race on the accumulators).  A bin of 10^5 products keeps one wave busy for ~0.2 ms: the persistent
+// grid draws bins from the ticket counter, so the others keep going.
+#ifndef TSAMD_SPSPMM_WAVE_BATCH
+#define TSAMD_SPSPMM_WAVE_BATCH 8
+#endif
+template <typename T>
+__global__ __launch_bounds__(64) void spspmm_large_accum_wave_kernel(
+    const int64_t *__restrict__ rows, int nr, const int64_t *__restrict__ big, const int64_t *__restrict__ n_big,
+    const int64_t *__restrict__ bin_off, const uint32_t *__restrict__ bcol, const T *__restrict__ bval,
+    const int64_t *__restrict__ bin_pref,
+    const int64_t *__restrict__ rowptrC, int64_t *__restrict__ colC, T *__restrict__ valC,
+    unsigned long long *queue) {
+  using A = typename Traits<T>::acc_t;
+  constexpr int kCols = 1 << kLgRange<T>;
+  constexpr int kWords = kCols / 32;
+  constexpr int kU = TSAMD_SPSPMM_WAVE_BATCH;
+  static_assert(kWords % 64 == 0, "whole words per lane");
+  __shared__ A acc[kCols];
+  __shared__ uint32_t bits[kWords];
+  __shared__ uint16_t stage[2048];
+  __shared__ int64_t s_desc[2][4];
+  const int lane = (int)threadIdx.x;
+  for (int c = lane; c < kCols; c += 64) acc[c] = A(0);
+  for (int w = lane; w < kWords; w += 64) bits[w] = 0;
+  BinFeed feed{queue, big, *n_big, bin_off, rows, bin_pref, rowptrC, nr};
+  feed.start(s_desc[0]);
+  for (int cur = 0;; cur ^= 1) {
+    const int64_t task = s_desc[cur][0];
+    if (task < 0) break;
+    const int64_t b0 = s_desc[cur][1], b1 = s_desc[cur][2], out0 = s_desc[cur][3];
+    feed.step_a();
+    for (int64_t p0 = b0; p0 < b1; p0 += 64 * kU) {
+      uint32_t c[kU];
+      A v[kU];
+      bool ok[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t p = p0 + u * 64 + lane;
+        ok[u] = p < b1;
+        bin_load<T>(bcol, bval, ok[u] ? p : b1 - 1, ok[u] && valC != nullptr, c[u], v[u]);
+        c[u] &= (uint32_t)(kCols - 1);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {  // instruction u holds positions p0 + 64 u .. + 63: ascending order overall
+        if (ok[u]) {
+          atomicOr(&bits[c[u] >> 5], 1u << (c[u] & 31u));
+          if (valC != nullptr) atomicAdd(&acc[c[u]], v[u]);
+        }
+      }
+    }
+    __syncthreads();
+    feed.step_b();
+    // emit in column order, 64 bitmap words (2048 columns) at a time: lane L owns word L of the chunk, the DPP scan
+    // gives the position of its first set bit among the chunk's, every lane drops the column offsets of ITS set bits
+    // into a staging array at those positions (LDS scatter), and the chunk's entries are then stored with lane =
+    // output position (coalesced) -- no search per output (the 256-thread kernel's 10-step binary search over the word
+    // prefixes + 5-step bit select cost more than the accumulation itself once 64 lanes had to do it alone).
+    const int64_t col0 = (task % nr) << kLgRange<T>;
+    int emitted = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < kWords / 64; ++ch) {
+      uint32_t word = bits[ch * 64 + lane];
+      const int pc = __popc(word);
+      const uint32_t incl = wave_scan_add_dpp((uint32_t)pc);
+      const int tot_ch = (int)lane_read(incl, 63);
+      if (tot_ch == 0) continue;  // (wave-uniform)
+      int pos = (int)incl - pc;
+      if (word) bits[ch * 64 + lane] = 0;  // the bitmap is clear again before the next bin sets bits
+      while (word) {
+        const int bit = __builtin_ctz(word);
+        word &= word - 1u;
+        stage[pos++] = (uint16_t)(lane * 32 + bit);
+      }
+      __syncthreads();
+      for (int o = lane; o < tot_ch; o += 64) {
+        const int idx = ch * 2048 + (int)stage[o];
+        colC[out0 + emitted + o] = col0 + idx;
+        if (valC != nullptr) {
+          valC[out0 + emitted + o] = Traits<T>::from_acc(acc[idx]);
+          acc[idx] = A(0);
+        }
+      }
+      emitted += tot_ch;
+      __syncthreads();
+    }
+    feed.step_c(s_desc[cur ^ 1]);
+    __syncthreads();
   }
 }
 
@@ -1499,7 +1651,7 @@ constexpr int kGroupLogT = kSmallBinCap <= 512 ? 10 : (kSmallBinCap <= 1024 ? 11
 __global__ __launch_bounds__(64) void spspmm_smallbin_count_kernel(
     const int64_t *__restrict__ rows, int nr, const int64_t *__restrict__ small,
     const unsigned long long *__restrict__ n_small, const int64_t *__restrict__ bin_off,
-    const uint32_t *__restrict__ bcol, int64_t *__restrict__ bin_cnt, unsigned long long *__restrict__ nnzC) {
+    const uint32_t *__restrict__ bcol, int bstride, int64_t *__restrict__ bin_cnt, unsigned long long *__restrict__ nnzC) {
   constexpr int kT = 1 << kGroupLogT;
   __shared__ uint32_t tab[kT];
   const int lane = (int)threadIdx.x;
@@ -1518,7 +1670,7 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_count_kernel(
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int q = q0 + u * 64 + lane;
-        c[u] = q < n ? bcol[b0 + q] : kEmptyKey;
+        c[u] = q < n ? bcol[(b0 + q) * bstride] : kEmptyKey;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1569,8 +1721,11 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
     for (int q = lane; q < 64 * items; q += 64) {
       uint32_t k = kEmptyKey;
       if (q < p) {
-        k = ((bcol[b0 + q] - col_base) << kBinIdxBits) | (uint32_t)q;
-        if (valC != nullptr) sval[q] = Traits<T>::to_acc(bval[b0 + q]);
+        uint32_t cq;
+        A vq;
+        bin_load<T>(bcol, bval, b0 + q, valC != nullptr, cq, vq);
+        k = ((cq - col_base) << kBinIdxBits) | (uint32_t)q;
+        if (valC != nullptr) sval[q] = vq;
       }
       skey[q] = k;
     }
@@ -1592,8 +1747,16 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
   }
 }
 
+#ifndef TSAMD_SPSPMM_SUBBINS
+#define TSAMD_SPSPMM_SUBBINS 1  // 0: shared cursors (round-4 behaviour: bin order and big-bin sums run-dependent), for A/B builds
+#endif
+#ifndef TSAMD_SPSPMM_WAVE_ACCUM
+#define TSAMD_SPSPMM_WAVE_ACCUM 1  // 0: the 256-thread accumulation (sums in arrival order), for A/B builds
+#endif
 struct LargeWs {
-  int64_t *hist;      // [n_large * nr + 1] products per bin, scanned in place -> bin offsets
+  int64_t *hist;      // [n_large * nr * sub + 1] products per (bin, wave segment), scanned in place -> segment offsets
+  int64_t *bin_off;   // [n_large * nr + 1] offset of every bin = of its first segment
+  int sub;            // wave segments per bin: 4 (reproducible bin order) or 1 (too many ranges for the LDS counters)
   int64_t *bin_cnt;   // [n_large * nr + 1] distinct columns per bin, scanned at numeric time
   uint32_t *bcol;     // [P_large] column inside its range
   void *bval;         // [P_large] value (numeric stage)
@@ -1619,14 +1782,25 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, int64_t N, size
   l.nr = (int)((N + ((int64_t)1 << l.lg_range) - 1) >> l.lg_range);
   if (l.nr < 1) l.nr = 1;
   l.ntask = n_large * (int64_t)l.nr;
-  l.hist = (int64_t *)take(8 * (size_t)(l.ntask + 1));
+  static const bool subbins = [] {  // TSAMD_SPSPMM_SUBBINS=0 in the environment: the round-4 shared cursors (A/B runs)
+    const char *e = getenv("TSAMD_SPSPMM_SUBBINS");
+    return e ? e[0] != '0' : (TSAMD_SPSPMM_SUBBINS != 0);
+  }();
+  l.sub = (subbins && l.nr <= kMaxRanges / (kLargeThreads / 64)) ? kLargeThreads / 64 : 1;
+  l.hist = (int64_t *)take(8 * (size_t)(l.ntask * l.sub + 1));
+  l.bin_off = (int64_t *)take(8 * (size_t)(l.ntask + 1));
   l.bin_cnt = (int64_t *)take(8 * (size_t)(l.ntask + 1));
-  l.bcol = (uint32_t *)take(4 * (size_t)P_large);
-  l.bval = take(esize * (size_t)P_large);
+  if (TSAMD_SPSPMM_PAIRS && esize == 4) {  // (column, value) pairs in one array
+    l.bcol = (uint32_t *)take(8 * (size_t)P_large);
+    l.bval = nullptr;
+  } else {
+    l.bcol = (uint32_t *)take(4 * (size_t)P_large);
+    l.bval = take(esize * (size_t)P_large);
+  }
   l.queue = (unsigned long long *)take(64);
   l.lists = (int64_t *)take(16 * (size_t)l.ntask);
   l.counts = (unsigned long long *)take(64);
-  l.scan_ws = take(scan_workspace_bytes(l.ntask + 1));
+  l.scan_ws = take(scan_workspace_bytes(l.ntask * l.sub + 1));
   if (w) *w = l;
   return off;
 }
@@ -1651,6 +1825,15 @@ unsigned int pipe_blocks(int64_t M) {
   return (unsigned int)(M < cap ? (M > 0 ? M : 1) : cap);
 }
 #endif
+
+unsigned int persistent_blocks();
+// one-wave workgroups of the reproducible accumulation: as many as the LDS of the device holds at once
+template <typename T>
+unsigned int persistent_wave_blocks() {
+  const size_t lds = sizeof(typename Traits<T>::acc_t) * ((size_t)1 << kLgRange<T>) + 4 * (((size_t)1 << kLgRange<T>) / 32) + 4096 + 128;
+  const unsigned int per_cu = (unsigned int)((size_t)160 * 1024 / lds);
+  return persistent_blocks() / TSAMD_SPSPMM_ACCUM_WGS * (per_cu < 1 ? 1 : per_cu);
+}
 
 unsigned int persistent_blocks() {
   static int cus = 0;  // the LDS footprint allows TSAMD_SPSPMM_ACCUM_WGS workgroups per CU
@@ -1677,35 +1860,38 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const void *valA
   carve_large(workspace, n_large, P_large, N, esize, &w);
   if (w.nr > kMaxRanges) return TSAMD_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(spspmm_large_hist_kernel, dim3((unsigned int)n_large), dim3(kLargeThreads), 0, stream,
-                     rowptrA, colA, rowptrB, colB, rows, w.lg_range, w.nr, w.hist);
+                     rowptrA, colA, rowptrB, colB, rows, w.lg_range, w.nr, w.sub, w.hist);
   TSAMD_LAUNCH_CHECK();
-  TSAMD_HIP_TRY(hipMemsetAsync(w.hist + w.ntask, 0, 8, stream));
-  int st = exclusive_scan_i64(w.hist, w.hist, w.ntask + 1, nullptr, w.scan_ws, stream);
+  TSAMD_HIP_TRY(hipMemsetAsync(w.hist + w.ntask * w.sub, 0, 8, stream));
+  int st = exclusive_scan_i64(w.hist, w.hist, w.ntask * w.sub + 1, nullptr, w.scan_ws, stream);
   if (st != TSAMD_OK) return st;
+  hipLaunchKernelGGL(spspmm_bin_offsets_kernel, dim3((unsigned int)ceil_div(w.ntask + 1, 256)), dim3(256), 0, stream,
+                     (const int64_t *)w.hist, w.sub, w.ntask, w.bin_off);
+  TSAMD_LAUNCH_CHECK();
   if (with_values)
     hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
                        stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
-                       reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, (const int64_t *)w.hist,
+                       reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, w.sub, (const int64_t *)w.hist,
                        w.bcol, reinterpret_cast<T *>(w.bval));
   else
     hipLaunchKernelGGL((spspmm_large_bin_kernel<T, false>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
                        stream, rowptrA, colA, (const T *)nullptr, rowptrB, colB, (const T *)nullptr, rows,
-                       w.lg_range, w.nr, (const int64_t *)w.hist, w.bcol, (T *)nullptr);
+                       w.lg_range, w.nr, w.sub, (const int64_t *)w.hist, w.bcol, (T *)nullptr);
   TSAMD_LAUNCH_CHECK();
   TSAMD_HIP_TRY(hipMemsetAsync(w.queue, 0, 64, stream));
   TSAMD_HIP_TRY(hipMemsetAsync(w.counts, 0, 64, stream));
   hipLaunchKernelGGL(spspmm_large_classify_kernel, dim3((unsigned int)ceil_div(n_large, 256)), dim3(256), 0, stream,
-                     (const int64_t *)w.hist, n_large, w.nr, w.ntask, w.lists, w.counts, w.bin_cnt);
+                     (const int64_t *)w.bin_off, n_large, w.nr, w.ntask, w.lists, w.counts, w.bin_cnt);
   TSAMD_LAUNCH_CHECK();
   const unsigned int small_grid = (unsigned int)(w.ntask < kSmallBinWaves ? w.ntask : kSmallBinWaves);
   hipLaunchKernelGGL(spspmm_smallbin_count_kernel, dim3(small_grid), dim3(64), 0, stream, rows, w.nr,
-                     (const int64_t *)w.lists, (const unsigned long long *)w.counts, (const int64_t *)w.hist,
-                     (const uint32_t *)w.bcol, w.bin_cnt,
+                     (const int64_t *)w.lists, (const unsigned long long *)w.counts, (const int64_t *)w.bin_off,
+                     (const uint32_t *)w.bcol, kPairs<T> ? 2 : 1, w.bin_cnt,
                      reinterpret_cast<unsigned long long *>(nnzC));
   TSAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(spspmm_large_count_kernel, dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream, rows,
                      w.nr, (const int64_t *)(w.lists + w.ntask), (const int64_t *)(w.counts + 1),
-                     (const int64_t *)w.hist, (const uint32_t *)w.bcol, (1 << w.lg_range) / 32, w.bin_cnt,
+                     (const int64_t *)w.bin_off, (const uint32_t *)w.bcol, kPairs<T> ? 2 : 1, (1 << w.lg_range) / 32, w.bin_cnt,
                      reinterpret_cast<unsigned long long *>(nnzC), w.queue);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
@@ -1723,7 +1909,7 @@ int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA,
   if (valC != nullptr && !values_binned) {  // the symbolic stage binned the columns only; the values follow the same offsets
     hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
                        stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
-                       reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, (const int64_t *)w.hist,
+                       reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, w.sub, (const int64_t *)w.hist,
                        w.bcol, bv);
     TSAMD_LAUNCH_CHECK();
   }
@@ -1734,14 +1920,20 @@ int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA,
   // (the lists of small / big bins were left in the workspace by the symbolic stage)
   const unsigned int small_grid = (unsigned int)(w.ntask < kSmallBinWaves ? w.ntask : kSmallBinWaves);
   hipLaunchKernelGGL((spspmm_smallbin_accum_kernel<T>), dim3(small_grid), dim3(64), 0, stream, rows, w.nr,
-                     (const int64_t *)w.lists, (const unsigned long long *)w.counts, (const int64_t *)w.hist,
+                     (const int64_t *)w.lists, (const unsigned long long *)w.counts, (const int64_t *)w.bin_off,
                      (const uint32_t *)w.bcol, (const T *)bv, (const int64_t *)w.bin_cnt, rowptrC, colC,
                      reinterpret_cast<T *>(valC));
   TSAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL((spspmm_large_accum_kernel<T>), dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream,
-                     rows, w.nr, (const int64_t *)(w.lists + w.ntask), (const int64_t *)(w.counts + 1),
-                     (const int64_t *)w.hist, (const uint32_t *)w.bcol, (const T *)bv, (const int64_t *)w.bin_cnt,
-                     rowptrC, colC, reinterpret_cast<T *>(valC), w.queue);
+  if (w.sub > 1 && TSAMD_SPSPMM_WAVE_ACCUM)  // bins in a reproducible order: sum them in that order, one wave per bin
+    hipLaunchKernelGGL((spspmm_large_accum_wave_kernel<T>), dim3(persistent_wave_blocks<T>()), dim3(64), 0, stream,
+                       rows, w.nr, (const int64_t *)(w.lists + w.ntask), (const int64_t *)(w.counts + 1),
+                       (const int64_t *)w.bin_off, (const uint32_t *)w.bcol, (const T *)bv, (const int64_t *)w.bin_cnt,
+                       rowptrC, colC, reinterpret_cast<T *>(valC), w.queue);
+  else
+    hipLaunchKernelGGL((spspmm_large_accum_kernel<T>), dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream,
+                       rows, w.nr, (const int64_t *)(w.lists + w.ntask), (const int64_t *)(w.counts + 1),
+                       (const int64_t *)w.bin_off, (const uint32_t *)w.bcol, (const T *)bv, (const int64_t *)w.bin_cnt,
+                       rowptrC, colC, reinterpret_cast<T *>(valC), w.queue);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }

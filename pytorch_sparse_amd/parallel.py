@@ -277,7 +277,9 @@ class _OverlappedProduct(torch.autograd.Function):
             st, ex = plan.stages[i], extra['stages'][i]
             Ei = st['col'].numel()
             v_i = None if vals is None else vals[i]
-            if minmax:
+            if Ei == 0:  # a column block without entries on this rank (unequal shards): its buffer's gradient is zero,
+                gval_i, gmat_i = None, torch.zeros_like(mats[i])  # but the collective still has to be joined
+            elif minmax:
                 arg_i = torch.where(stage_of_arg == i, arg_c, torch.full_like(arg_c, Ei))
                 gval_i, gmat_i = plan.minmax_bw_fn(st['rowptr'], st['col'], v_i, mats[i], g, arg_i, need_v)
             else:

@@ -21,9 +21,10 @@ def spmm(index: Tensor, value: Tensor, m: int, n: int, matrix: Tensor) -> Tensor
     # ranges of `out` in LDS and scan the entries) -- what the reference's three ATen calls do, without the [nnz, F]
     # temporary; the sorted route below costs 8+ launches whatever the size
     wants_grad = torch.is_grad_enabled() and (value.requires_grad or matrix.requires_grad)
-    if (matrix.is_cuda and matrix.dim() == 2 and not wants_grad and index.dim() == 2 and
-            torch.ops.tsamd.spmm_coo_small_supported(value, nnz, m, matrix.size(1))):
-        return torch.ops.tsamd.spmm_coo_small(index, value.detach(), m, n, matrix.detach())
+    if matrix.is_cuda and not wants_grad and m * matrix.size(-1) > 0:
+        out = torch.ops.tsamd.spmm_coo_small(index, value, m, n, matrix)  # (an empty tensor: not taken)
+        if out.dim() == 2:
+            return out
     if nnz > 1:
         # ordered on the device without asking the host (tsamd::sort_coo_auto: a sorted input only pays the
         # probe and a copy): the whole call enqueues kernels and returns -- no sync

@@ -372,6 +372,34 @@ def test_spspmm_rmat_all_size_classes(ts, dev):
     assert C.is_coalesced()
 
 
+def test_spspmm_values_are_reproducible_run_to_run(ts, dev):
+    """Rounding-sensitive fp32 values (not the exact half-integers of the tests above) on a product whose hub rows fill
+    (row, range) bins of far more than 1024 products -- the dense accumulation of the large-row path.  Round 4 summed
+    those bins in atomic arrival order (not reproducible run to run, unlike the reference's CPU
+    path); since round 5 a bin's products lie in a fixed order (per-wave segments) and one wave adds them in that
+    order: five runs, bit-identical values; and they agree with torch.sparse.mm within 1e-5 of the L1 mass."""
+    from pytorch_sparse_amd import synth
+    rp, c = synth.rmat_csr(15, 12, seed=9, device=dev)
+    n = 1 << 15
+    val = synth.values(c.numel(), seed=3, device=dev) - 0.5
+    A = ts.SparseTensor(rowptr=rp, col=c, value=val, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+    At = A.t()
+    rpB = At.storage.rowptr()
+    prod = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, A.storage.row(), (rpB[1:] - rpB[:-1])[c])
+    assert int(prod.max()) > 200000  # hub rows: bins of >> 1024 products (4 column ranges at this size)
+    first = A @ At
+    r0, c0, v0 = first.coo()
+    for _ in range(4):
+        again = A @ At
+        r1, c1, v1 = again.coo()
+        assert torch.equal(r0, r1) and torch.equal(c0, c1)
+        assert torch.equal(v0.view(torch.int32), v1.view(torch.int32))
+    Cc = torch.sparse.mm(A.cpu().to_torch_sparse_coo_tensor(), At.cpu().to_torch_sparse_coo_tensor()).coalesce()
+    assert torch.equal(torch.stack([r0, c0]).cpu(), Cc._indices())
+    l1 = (A.set_value(val.abs(), 'coo') @ At.set_value(At.storage.value().abs(), 'coo')).storage.value()
+    assert bool(((v0.cpu().double() - Cc._values().double()).abs() <= 1e-5 * l1.cpu().double() + 1e-30).all())
+
+
 def test_fuzz_coalesce_transpose_spspmm(ts, dev):
     """Random small COO inputs (empty, single entry, all duplicates, tall/wide) against the numpy
     oracle: indices bit-exact, values exact (small integers)."""
