@@ -2,6 +2,9 @@
 // sampling, relabelling, induced sub-graphs.  See ops_spmm.cpp for the conventions.
 #include "ops_common.h"
 
+#include <algorithm>
+#include <map>
+
 namespace tsamd_ops {
 namespace {
 
@@ -165,19 +168,22 @@ std::tuple<Tensor, Tensor, OptTensor, Tensor> relabel_one_hop(Tensor rowptr, Ten
   return std::make_tuple(out_ptr, r.local, out_value, r.n_id);
 }
 
-// Entries of the segments idx of (ptr, ind) whose index is itself in idx:
-// -> (position of the segment in idx, position of the index in idx, position of the entry), in
-// idx order and stored order inside a segment.  Two host syncs.
-std::tuple<Tensor, Tensor, Tensor> induced_entries(Tensor idx, Tensor ptr, Tensor ind) {
-  idx = idx.contiguous();
-  const int64_t M = ptr.numel() - 1, n = idx.numel();
+// Entries of the segments `seg_idx` of (ptr, ind) whose index is in `map_idx` (ids of a space of M_map nodes):
+// -> (position of the segment in seg_idx, position of the index in map_idx, position of the entry), in
+// seg_idx order and stored order inside a segment.  Two host syncs.  (Homogeneous graphs: seg_idx == map_idx;
+// a relation of a heterogeneous graph: destination nodes select the segments, source nodes the entries.)
+std::tuple<Tensor, Tensor, Tensor> induced_entries_bipartite(Tensor seg_idx, Tensor map_idx, int64_t M_map, Tensor ptr,
+                                                             Tensor ind) {
+  seg_idx = seg_idx.contiguous();
+  map_idx = map_idx.contiguous();
+  const int64_t n = map_idx.numel();
   auto iopt = ptr.options().requires_grad(false);
   void *stream = current_stream(ptr);
-  Tensor assoc = torch::empty({M}, iopt), err = torch::empty({1}, iopt);
-  check_status(tsamd_subset_assoc(idx.data_ptr<int64_t>(), n, M, assoc.data_ptr<int64_t>(),
+  Tensor assoc = torch::empty({M_map}, iopt), err = torch::empty({1}, iopt);
+  check_status(tsamd_subset_assoc(map_idx.data_ptr<int64_t>(), n, M_map, assoc.data_ptr<int64_t>(),
                                   err.data_ptr<int64_t>(), stream),
                "tsamd_subset_assoc");
-  auto sel = select_segments(ptr, ind, idx, true, true);  // sync 1 (raises on bad ids)
+  auto sel = select_segments(ptr, ind, seg_idx, true, true);  // sync 1 (raises on bad ids)
   Tensor seg = std::get<1>(sel), nbr = std::get<2>(sel), pos = std::get<3>(sel);
   const int64_t T = nbr.numel();
   Tensor cnt = torch::empty({1}, iopt);
@@ -195,6 +201,10 @@ std::tuple<Tensor, Tensor, Tensor> induced_entries(Tensor idx, Tensor ptr, Tenso
                                   map_out.data_ptr<int64_t>(), src.data_ptr<int64_t>(), stream),
                "tsamd_filter_write");
   return std::make_tuple(seg_out, map_out, pos.index_select(0, src));
+}
+
+std::tuple<Tensor, Tensor, Tensor> induced_entries(Tensor idx, Tensor ptr, Tensor ind) {
+  return induced_entries_bipartite(idx, idx, ptr.numel() - 1, ptr, ind);
 }
 
 // torch_sparse::saint_subgraph(Tensor idx, Tensor rowptr, Tensor row, Tensor col)
@@ -284,6 +294,305 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> neighbor_sample(const Tensor &colptr_
                          edges.empty() ? none : torch::cat(edges));
 }
 
+// ---- heterogeneous multi-hop sampling (csrc/cpu/neighbor_sample_cpu.cpp:135-507) --------------------------------
+using node_t = std::string;
+using rel_t = std::string;
+using edge_t = std::tuple<std::string, std::string, std::string>;
+using TensorDict = c10::Dict<std::string, Tensor>;
+
+struct Drawn {
+  Tensor out_ptr, nbr, e;  // per frontier node: segment pointer; per draw: the neighbour id and its position in `row`
+  int64_t T;
+};
+
+// one hop over one CSC: k in-neighbours of every frontier node (k < 0: all) -- the plan / draw pair of neighbor_sample
+Drawn draw_neighbors(const Tensor &colptr, const Tensor &row, const Tensor &frontier, int64_t k, bool replace, uint64_t seed) {
+  const int64_t M = colptr.numel() - 1, F = frontier.numel();
+  auto iopt = colptr.options().requires_grad(false);
+  void *stream = current_stream(colptr);
+  Drawn d;
+  d.out_ptr = torch::empty({F + 1}, iopt);
+  Tensor info = torch::empty({2}, iopt);
+  Tensor ws = workspace(tsamd_sample_workspace_bytes(F), colptr);
+  check_status(tsamd_sample_plan(colptr.data_ptr<int64_t>(), M, frontier.data_ptr<int64_t>(), F, k, replace ? 1 : 0,
+                                 d.out_ptr.data_ptr<int64_t>(), info.data_ptr<int64_t>(), ws.data_ptr(),
+                                 (size_t)ws.numel(), stream),
+               "tsamd_sample_plan");
+  Tensor h = info.cpu();  // host sync
+  d.T = h.data_ptr<int64_t>()[0];
+  const int64_t bad = h.data_ptr<int64_t>()[1];
+  TORCH_CHECK_INDEX(bad == 0, "index out of range: ", bad, " node ids are outside [0, ", M, ")");
+  d.e = torch::empty({d.T}, iopt);
+  d.nbr = torch::empty({d.T}, iopt);
+  if (k < 0)
+    check_status(tsamd_select_fill(colptr.data_ptr<int64_t>(), M, row.data_ptr<int64_t>(), frontier.data_ptr<int64_t>(), F,
+                                   d.out_ptr.data_ptr<int64_t>(), d.T, nullptr, d.nbr.data_ptr<int64_t>(),
+                                   d.e.data_ptr<int64_t>(), stream),
+                 "tsamd_select_fill");
+  else
+    check_status(tsamd_sample_draw(colptr.data_ptr<int64_t>(), row.data_ptr<int64_t>(), frontier.data_ptr<int64_t>(), F, k,
+                                   replace ? 1 : 0, seed, d.out_ptr.data_ptr<int64_t>(), d.e.data_ptr<int64_t>(),
+                                   d.nbr.data_ptr<int64_t>(), stream),
+                 "tsamd_sample_draw");
+  return d;
+}
+
+Tensor segment_ids(const Tensor &out_ptr, int64_t F, int64_t T) {
+  Tensor seg = torch::empty({T}, out_ptr.options());
+  check_status(tsamd_ptr2ind(out_ptr.data_ptr<int64_t>(), F, T, seg.data_ptr<int64_t>(), current_stream(out_ptr)),
+               "tsamd_ptr2ind");
+  return seg;
+}
+
+uint64_t host_seed() {  // from torch's CPU generator: torch.manual_seed() makes the draws reproducible
+  return (uint64_t)torch::randint(0, std::numeric_limits<int64_t>::max(), {1}, torch::TensorOptions().dtype(torch::kLong))
+      .item<int64_t>();
+}
+
+struct HeteroSetup {
+  std::map<rel_t, edge_t> to_edge_type;
+  std::map<node_t, int64_t> num_nodes;  // id space of every node type (the dense relabel needs it)
+  std::vector<rel_t> rels_sorted;       // the keys of num_neighbors_dict in ascending order (the reference's hop order)
+  Tensor any;                           // some device tensor (options / device of the outputs)
+};
+
+HeteroSetup hetero_setup(const std::vector<node_t> &node_types, const std::vector<edge_t> &edge_types,
+                         const TensorDict &colptr_dict, const TensorDict &row_dict, const TensorDict &input_node_dict,
+                         const c10::Dict<rel_t, std::vector<int64_t>> &num_neighbors_dict) {
+  HeteroSetup hs;
+  for (const auto &k : edge_types) hs.to_edge_type[std::get<0>(k) + "__" + std::get<1>(k) + "__" + std::get<2>(k)] = k;
+  for (const auto &t : node_types) hs.num_nodes[t] = 0;
+  bool have = false;
+  for (const auto &kv : colptr_dict) {
+    const Tensor &cp = kv.value();
+    check_index(cp, "colptr");
+    TORCH_CHECK(cp.numel() >= 1, "hetero_neighbor_sample: empty colptr");
+    TORCH_CHECK(hs.to_edge_type.count(kv.key()), "unknown relation ", kv.key());
+    if (!have) {
+      hs.any = cp;
+      have = true;
+    }
+    auto &n = hs.num_nodes[std::get<2>(hs.to_edge_type.at(kv.key()))];  // destination type: one column per node
+    n = std::max<int64_t>(n, cp.numel() - 1);
+  }
+  TORCH_CHECK(have, "hetero_neighbor_sample: no relations");
+  // source types: the largest id any relation or input refers to (one read-back per tensor, setup only)
+  for (const auto &kv : row_dict) {
+    const Tensor &r = kv.value();
+    check_index(r, "row");
+    auto &n = hs.num_nodes[std::get<0>(hs.to_edge_type.at(kv.key()))];
+    if (r.numel() > 0) n = std::max<int64_t>(n, r.max().item<int64_t>() + 1);
+  }
+  for (const auto &kv : input_node_dict) {
+    const Tensor &x = kv.value();
+    check_index(x, "input_node");
+    TORCH_CHECK(hs.num_nodes.count(kv.key()), "unknown node type ", kv.key());
+    auto &n = hs.num_nodes[kv.key()];
+    if (x.numel() > 0) n = std::max<int64_t>(n, x.max().item<int64_t>() + 1);
+  }
+  for (const auto &kv : num_neighbors_dict) hs.rels_sorted.push_back(kv.key());
+  std::sort(hs.rels_sorted.begin(), hs.rels_sorted.end());
+  return hs;
+}
+
+std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> pack_hetero(
+    const std::vector<node_t> &node_types, const TensorDict &colptr_dict, std::map<node_t, Tensor> &samples,
+    std::map<rel_t, std::vector<Tensor>> &rows, std::map<rel_t, std::vector<Tensor>> &cols,
+    std::map<rel_t, std::vector<Tensor>> &edges, const Tensor &any) {
+  auto iopt = any.options().requires_grad(false);
+  Tensor none = torch::empty({0}, iopt);
+  auto join = [&](std::vector<Tensor> &v) { return v.empty() ? none : (v.size() == 1 ? v[0] : torch::cat(v)); };
+  TensorDict out_node, out_row, out_col, out_edge;
+  for (const auto &t : node_types) out_node.insert(t, samples.count(t) ? samples[t] : none);
+  for (const auto &kv : colptr_dict) {
+    out_row.insert(kv.key(), join(rows[kv.key()]));
+    out_col.insert(kv.key(), join(cols[kv.key()]));
+    out_edge.insert(kv.key(), join(edges[kv.key()]));
+  }
+  return std::make_tuple(out_node, out_row, out_col, out_edge);
+}
+
+// torch_sparse::hetero_neighbor_sample(str[] node_types, (str, str, str)[] edge_types, Dict(str, Tensor) colptr_dict,
+//     Dict(str, Tensor) row_dict, Dict(str, Tensor) input_node_dict, Dict(str, int[]) num_neighbors_dict, int num_hops,
+//     bool replace, bool directed) -> (Dict(str, Tensor) node, Dict(str, Tensor) row, Dict(str, Tensor) col, Dict(str, Tensor) edge)
+// (reference schema, csrc/neighbor_sample.cpp:29-45; CPU-only there).  Per hop the relations are visited in ascending
+// key order; relation src__rel__dst draws in-neighbours (of type src) of the dst nodes discovered in the PREVIOUS hop
+// (the slices move at the end of a hop, neighbor_sample_cpu.cpp:216-219, 352-361) and appends the new ones to src's
+// node list in first-occurrence order.  Everything that is not random is identical to the reference.
+std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> hetero_neighbor_sample(
+    const std::vector<node_t> &node_types, const std::vector<edge_t> &edge_types, const TensorDict &colptr_dict,
+    const TensorDict &row_dict, const TensorDict &input_node_dict,
+    const c10::Dict<rel_t, std::vector<int64_t>> &num_neighbors_dict, int64_t num_hops, bool replace, bool directed) {
+  HeteroSetup hs = hetero_setup(node_types, edge_types, colptr_dict, row_dict, input_node_dict, num_neighbors_dict);
+  c10::hip::HIPGuard guard(hs.any.get_device());
+  auto iopt = hs.any.options().requires_grad(false);
+  std::map<node_t, Tensor> samples;
+  std::map<node_t, std::pair<int64_t, int64_t>> slice;
+  for (const auto &t : node_types) {
+    samples[t] = input_node_dict.contains(t) ? input_node_dict.at(t).contiguous() : torch::empty({0}, iopt);
+    slice[t] = {0, samples[t].numel()};
+  }
+  std::map<rel_t, std::vector<Tensor>> rows, cols, edges;
+  const uint64_t seed0 = host_seed();
+  uint64_t draw_no = 0;
+  for (int64_t ell = 0; ell < num_hops; ++ell) {
+    for (const auto &rel : hs.rels_sorted) {
+      const edge_t &et = hs.to_edge_type.at(rel);
+      const node_t &src_t = std::get<0>(et), &dst_t = std::get<2>(et);
+      const auto &fan = num_neighbors_dict.at(rel);
+      TORCH_CHECK((int64_t)fan.size() > ell, "num_neighbors_dict[", rel, "] has fewer than num_hops entries");
+      const int64_t k = fan[ell];
+      const int64_t begin = slice.at(dst_t).first, F = slice.at(dst_t).second - begin;
+      ++draw_no;
+      if (F == 0) continue;
+      Tensor colptr = colptr_dict.at(rel).contiguous(), row = row_dict.at(rel).contiguous();
+      Tensor frontier = samples.at(dst_t).narrow(0, begin, F);
+      Drawn d = draw_neighbors(colptr, row, frontier, k, replace, seed0 + 0x9E3779B97F4A7C15ull * draw_no);
+      Relabelled r = relabel_impl(samples.at(src_t), d.nbr, hs.num_nodes.at(src_t), directed);
+      if (directed) {
+        Tensor seg = segment_ids(d.out_ptr, F, d.T);
+        rows[rel].push_back(r.local);
+        cols[rel].push_back(begin > 0 ? seg + begin : seg);
+        edges[rel].push_back(d.e);
+      }
+      samples[src_t] = r.n_id;
+    }
+    for (const auto &t : node_types) slice[t] = {slice[t].second, samples[t].numel()};
+  }
+  if (!directed) {  // every stored edge between the sampled nodes, relation by relation (neighbor_sample_cpu.cpp:366-397)
+    for (const auto &kv : colptr_dict) {
+      const edge_t &et = hs.to_edge_type.at(kv.key());
+      const node_t &src_t = std::get<0>(et), &dst_t = std::get<2>(et);
+      if (samples.at(dst_t).numel() == 0 || samples.at(src_t).numel() == 0) continue;
+      auto sub = induced_entries_bipartite(samples.at(dst_t), samples.at(src_t), hs.num_nodes.at(src_t),
+                                           kv.value().contiguous(), row_dict.at(kv.key()).contiguous());
+      rows[kv.key()].push_back(std::get<1>(sub));
+      cols[kv.key()].push_back(std::get<0>(sub));
+      edges[kv.key()].push_back(std::get<2>(sub));
+    }
+  }
+  return pack_hetero(node_types, colptr_dict, samples, rows, cols, edges, hs.any);
+}
+
+// First-occurrence relabel of (node, root) PAIRS (the temporal sampler keeps one computation tree per root,
+// neighbor_sample_cpu.cpp:255-266): `old_key` are the pairs already numbered 0 .. n-1 (distinct), `new_key` the
+// candidates in draw order.  -> (local id of every candidate, mask of the candidates that open a new id, in order).
+// The key space (nodes x roots) is far too large for the dense slot array of relabel_impl: a device sort (ATen unique) and a
+// scatter-min of the positions instead -- this variant is the tail of SURVEY 8f rank 4, not a hot path.
+std::pair<Tensor, Tensor> relabel_pairs(const Tensor &old_key, const Tensor &new_key) {
+  const int64_t n = old_key.numel(), T = new_key.numel();
+  auto iopt = new_key.options().requires_grad(false);
+  if (T == 0) return {torch::empty({0}, iopt), torch::empty({0}, iopt.dtype(torch::kBool))};
+  Tensor all = torch::cat({old_key, new_key});
+  auto uq = at::_unique2(all, /*sorted=*/true, /*return_inverse=*/true, /*return_counts=*/false);
+  Tensor inverse = std::get<1>(uq);
+  const int64_t U = std::get<0>(uq).numel();
+  Tensor pos = torch::arange(n + T, iopt);
+  Tensor first = torch::full({U}, std::numeric_limits<int64_t>::max(), iopt).scatter_reduce_(0, inverse, pos, "amin", true);
+  Tensor opens = torch::zeros({n + T}, iopt.dtype(torch::kBool));
+  opens.index_fill_(0, first, true);                 // positions that are the first occurrence of their pair
+  Tensor opens_new = opens.narrow(0, n, T);          // ... among the candidates (the old pairs open themselves)
+  Tensor rank = opens_new.to(torch::kLong).cumsum(0) - 1;  // id - n of the pair a first occurrence opens
+  Tensor first_of = first.index_select(0, inverse.narrow(0, n, T));  // first position of every candidate's pair
+  Tensor local = torch::where(first_of < n, first_of, rank.index_select(0, (first_of - n).clamp_min(0)) + n);
+  return {local, opens_new};
+}
+
+// torch_sparse::hetero_temporal_neighbor_sample(..., Dict(str, Tensor) node_time_dict, int num_hops, bool replace,
+//     bool directed)                               (reference schema, csrc/neighbor_sample.cpp:47-63; directed only)
+// The hetero sampler with a time constraint: a neighbour v of type src may be drawn for a node of root time t only if
+// node_time[src][v] <= t (types without a time tensor are unconstrained), every root keeps its own computation tree --
+// nodes are (node, root) pairs -- and a drawn node inherits the root time of the node it was drawn for.
+//   take-all / without replacement: the draw of the untimed sampler, then the violating draws are dropped (as in
+//       neighbor_sample_cpu.cpp:240-262, 305-330: fewer than num_neighbors may remain);
+//   with replacement: num_neighbors uniform draws among the neighbours that satisfy the constraint (the reference
+//       redraws until one does, :268-300 -- and never returns when none does; here such a node draws nothing).
+std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> hetero_temporal_neighbor_sample(
+    const std::vector<node_t> &node_types, const std::vector<edge_t> &edge_types, const TensorDict &colptr_dict,
+    const TensorDict &row_dict, const TensorDict &input_node_dict,
+    const c10::Dict<rel_t, std::vector<int64_t>> &num_neighbors_dict, const TensorDict &node_time_dict, int64_t num_hops,
+    bool replace, bool directed) {
+  TORCH_CHECK(directed, "Temporal sampling requires 'directed' sampling");
+  HeteroSetup hs = hetero_setup(node_types, edge_types, colptr_dict, row_dict, input_node_dict, num_neighbors_dict);
+  c10::hip::HIPGuard guard(hs.any.get_device());
+  auto iopt = hs.any.options().requires_grad(false);
+  std::map<node_t, Tensor> tnode, troot, ttime;
+  std::map<node_t, std::pair<int64_t, int64_t>> slice;
+  int64_t R = 1;  // stride of the root index inside a pair key
+  for (const auto &kv : input_node_dict) R = std::max<int64_t>(R, kv.value().numel());
+  for (const auto &t : node_types) {
+    if (input_node_dict.contains(t)) {
+      TORCH_CHECK(node_time_dict.contains(t), "hetero_temporal_neighbor_sample: no node_time for input type ", t);
+      Tensor x = input_node_dict.at(t).contiguous();
+      tnode[t] = x;
+      troot[t] = torch::arange(x.numel(), iopt);
+      ttime[t] = node_time_dict.at(t).index_select(0, x);
+    } else {
+      tnode[t] = torch::empty({0}, iopt);
+      troot[t] = torch::empty({0}, iopt);
+      ttime[t] = torch::empty({0}, iopt);
+    }
+    slice[t] = {0, tnode[t].numel()};
+  }
+  std::map<rel_t, std::vector<Tensor>> rows, cols, edges;
+  const uint64_t seed0 = host_seed();
+  uint64_t draw_no = 0;
+  for (int64_t ell = 0; ell < num_hops; ++ell) {
+    for (const auto &rel : hs.rels_sorted) {
+      const edge_t &et = hs.to_edge_type.at(rel);
+      const node_t &src_t = std::get<0>(et), &dst_t = std::get<2>(et);
+      const auto &fan = num_neighbors_dict.at(rel);
+      TORCH_CHECK((int64_t)fan.size() > ell, "num_neighbors_dict[", rel, "] has fewer than num_hops entries");
+      const int64_t k = fan[ell];
+      const int64_t begin = slice.at(dst_t).first, F = slice.at(dst_t).second - begin;
+      ++draw_no;
+      if (F == 0) continue;
+      Tensor colptr = colptr_dict.at(rel).contiguous(), row = row_dict.at(rel).contiguous();
+      Tensor frontier = tnode.at(dst_t).narrow(0, begin, F).contiguous();
+      Tensor f_root = troot.at(dst_t).narrow(0, begin, F), f_time = ttime.at(dst_t).narrow(0, begin, F);
+      const bool timed = node_time_dict.contains(src_t);
+      const bool redraw = replace && k >= 0;  // draws with replacement are made among the VALID neighbours
+      Drawn d = draw_neighbors(colptr, row, frontier, redraw ? -1 : k, false, seed0 + 0x9E3779B97F4A7C15ull * draw_no);
+      Tensor seg = segment_ids(d.out_ptr, F, d.T), nbr = d.nbr, e = d.e;
+      if (timed && d.T > 0) {
+        Tensor keep = node_time_dict.at(src_t).index_select(0, nbr) <= f_time.index_select(0, seg);
+        Tensor idx = torch::nonzero(keep).view(-1);  // host sync
+        nbr = nbr.index_select(0, idx);
+        e = e.index_select(0, idx);
+        seg = seg.index_select(0, idx);
+      }
+      if (redraw && nbr.numel() > 0) {
+        Tensor cnt = torch::bincount(seg, {}, F);                       // valid neighbours per frontier node
+        Tensor vptr = torch::cumsum(cnt, 0) - cnt;                      // ... and where their list starts
+        Tensor has = torch::nonzero(cnt > 0).view(-1);                  // host sync
+        Tensor u = torch::rand({has.numel(), k}, iopt.dtype(torch::kDouble));
+        Tensor c_h = cnt.index_select(0, has).view({-1, 1});
+        Tensor pick = torch::minimum((u * c_h.to(torch::kDouble)).to(torch::kLong), c_h - 1) + vptr.index_select(0, has).view({-1, 1});
+        pick = pick.view(-1);
+        nbr = nbr.index_select(0, pick);
+        e = e.index_select(0, pick);
+        seg = has.view({-1, 1}).expand({has.numel(), k}).reshape(-1);
+      } else if (redraw) {
+        seg = seg.narrow(0, 0, 0);
+      }
+      Tensor c_root = f_root.index_select(0, seg), c_time = f_time.index_select(0, seg);
+      auto rel_new = relabel_pairs(tnode.at(src_t) * R + troot.at(src_t), nbr * R + c_root);
+      Tensor opens = rel_new.second;
+      rows[rel].push_back(rel_new.first);
+      cols[rel].push_back(begin > 0 ? seg + begin : seg);
+      edges[rel].push_back(e);
+      if (nbr.numel() > 0) {
+        Tensor sel = torch::nonzero(opens).view(-1);  // host sync
+        tnode[src_t] = torch::cat({tnode.at(src_t), nbr.index_select(0, sel)});
+        troot[src_t] = torch::cat({troot.at(src_t), c_root.index_select(0, sel)});
+        ttime[src_t] = torch::cat({ttime.at(src_t), c_time.index_select(0, sel)});
+      }
+    }
+    for (const auto &t : node_types) slice[t] = {slice[t].second, tnode[t].numel()};
+  }
+  return pack_hetero(node_types, colptr_dict, tnode, rows, cols, edges, hs.any);
+}
+
 
 }  // namespace
 }  // namespace tsamd_ops
@@ -297,4 +606,6 @@ static auto registry_sample = torch::RegisterOperators()
                            .op("torch_sparse::relabel", &relabel)
                            .op("torch_sparse::relabel_one_hop", &relabel_one_hop)
                            .op("torch_sparse::saint_subgraph", &saint_subgraph)
-                           .op("torch_sparse::neighbor_sample", &neighbor_sample);
+                           .op("torch_sparse::neighbor_sample", &neighbor_sample)
+                           .op("torch_sparse::hetero_neighbor_sample", &hetero_neighbor_sample)
+                           .op("torch_sparse::hetero_temporal_neighbor_sample", &hetero_temporal_neighbor_sample);

@@ -31,7 +31,12 @@ container (it cannot travel to the GPU box; the fixtures can).
                                   uniform draws (seed 0; duplicates occur), F = 16 fp32 -- inputs and
                                   the reference's output (also in fp64, the well-conditioned yardstick).
 
-Usage:  python tests/golden/make_golden.py [part1] ... [part7]   (needs /root/reference)
+  part 8  py8_hetero_*.npz      : hetero_neighbor_sample / hetero_temporal_neighbor_sample
+                                  (csrc/cpu/neighbor_sample_cpu.cpp:135-507) on small random heterogeneous graphs
+                                  (3 node types, 5 relations): the take-all cases, directed and undirected, and the
+                                  temporal sampler with per-type time stamps.
+
+Usage:  python tests/golden/make_golden.py [part1] ... [part8]   (needs /root/reference)
 """
 import os
 import subprocess
@@ -379,6 +384,68 @@ def part5():
     subprocess.check_call([sys.executable, '-c', PART5], env=env)
 
 
+PART8 = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ['TS_SCRATCH'])
+import torch_sparse
+out_dir = os.environ['TS_OUT']
+g = torch.Generator().manual_seed(8)
+node_types = ['paper', 'author', 'venue']
+edge_types = [('author', 'writes', 'paper'), ('paper', 'cites', 'paper'), ('paper', 'in', 'venue'),
+              ('venue', 'hosts', 'paper'), ('paper', 'by', 'author')]
+k = 0
+for sizes in ({'paper': 60, 'author': 25, 'venue': 4}, {'paper': 300, 'author': 120, 'venue': 9}):
+    colptr, row = {}, {}
+    for (s, r, d) in edge_types:
+        rel = '__'.join((s, r, d))
+        deg = torch.randint(0, 6, (sizes[d], ), generator=g)
+        deg[::7] = 0
+        cp = torch.zeros(sizes[d] + 1, dtype=torch.long); cp[1:] = deg.cumsum(0)
+        colptr[rel] = cp
+        row[rel] = torch.randint(0, sizes[s], (int(cp[-1]), ), generator=g)
+    times = {t: torch.randint(0, 50, (sizes[t], ), generator=g) for t in node_types}
+    for inputs in ({'paper': 5}, {'paper': 12, 'venue': 2}, {'author': 7}):
+        inp = {t: torch.randperm(sizes[t], generator=g)[:m] for t, m in inputs.items()}
+        for hops, fanval in ((1, -1), (2, -1), (3, -1), (2, 1000)):
+            fan = {'__'.join(e): [fanval] * hops for e in edge_types}
+            for mode in ('directed', 'undirected', 'temporal', 'temporal_partial'):
+                if mode.startswith('temporal'):
+                    tdict = dict(times) if mode == 'temporal' else {t: times[t] for t in ('paper', 'author') if True}
+                    if mode == 'temporal_partial':  # a source type without time stamps is unconstrained
+                        if 'venue' in inp:
+                            continue
+                        tdict = {t: times[t] for t in ('paper', 'author')}
+                    out = torch.ops.torch_sparse.hetero_temporal_neighbor_sample(node_types, edge_types, colptr, row, inp, fan, tdict, hops, False, True)
+                else:
+                    tdict = {}
+                    out = torch.ops.torch_sparse.hetero_neighbor_sample(node_types, edge_types, colptr, row, inp, fan, hops, False, mode == 'directed')
+                blob = dict(mode=mode, hops=hops, fan=fanval)
+                for rel in colptr:
+                    blob['colptr__' + rel] = colptr[rel].numpy(); blob['row__' + rel] = row[rel].numpy()
+                    blob['orow__' + rel] = out[1][rel].numpy(); blob['ocol__' + rel] = out[2][rel].numpy(); blob['oedge__' + rel] = out[3][rel].numpy()
+                for t in node_types:
+                    blob['node__' + t] = out[0][t].numpy()
+                for t, x in inp.items():
+                    blob['input__' + t] = x.numpy()
+                for t, x in tdict.items():
+                    blob['time__' + t] = x.numpy()
+                np.savez_compressed(os.path.join(out_dir, 'py8_hetero_%03d.npz' % k), **blob)
+                k += 1
+print('part 8: %d hetero sampling fixtures written' % k)
+"""
+
+
+def part8():
+    """py8_hetero_*.npz: the deterministic cases of the reference's heterogeneous (and temporal) neighbour samplers."""
+    srcs = SPMM_SRCS + ('neighbor_sample.cpp', 'cpu/neighbor_sample_cpu.cpp')
+    scratch, pkg = make_scratch([], srcs)
+    with open(os.path.join(pkg, '__init__.py'), 'w') as f:
+        f.write("import os, torch\n"
+                "torch.ops.load_library(os.path.join(os.path.dirname(__file__), '_ops_cpu.so'))\n")
+    env = dict(os.environ, TS_SCRATCH=scratch, TS_OUT=HERE, OMP_NUM_THREADS='1')
+    subprocess.check_call([sys.executable, '-c', PART8], env=env)
+
+
 PART6 = r"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.environ['TS_SCRATCH'])
@@ -465,7 +532,7 @@ def part7():
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         sys.exit('reference tree %s not present' % REF)
-    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4', 'part5', 'part6', 'part7']
+    todo = sys.argv[1:] or ['part1', 'part2', 'part3', 'part4', 'part5', 'part6', 'part7', 'part8']
     for name in todo:  # e.g. `make_golden.py part3` regenerates only the py3_* fixtures
         {'part1': part1, 'part2': part2, 'part3': part3, 'part4': part4, 'part5': part5, 'part6': part6,
-         'part7': part7}[name]()
+         'part7': part7, 'part8': part8}[name]()

@@ -1,0 +1,160 @@
+"""torch_sparse::hetero_neighbor_sample / hetero_temporal_neighbor_sample on the GPU (csrc/ops_sample.cpp) against the
+reference's CPU samplers (csrc/cpu/neighbor_sample_cpu.cpp:135-507):
+  * tests/golden/py8_hetero_*.npz -- outputs of the COMPILED REFERENCE (make_golden.py part 8) for every deterministic
+    case (take all neighbours, or more draws than neighbours): every node list, row / col / edge list bit for bit;
+  * for random draws: the properties the reference guarantees (counts, distinct draws without replacement, every
+    edge is a stored entry between the nodes it names, first-occurrence numbering, the time constraint)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DEV = 'cuda'
+NODE_TYPES = ['paper', 'author', 'venue']
+EDGE_TYPES = [('author', 'writes', 'paper'), ('paper', 'cites', 'paper'), ('paper', 'in', 'venue'),
+              ('venue', 'hosts', 'paper'), ('paper', 'by', 'author')]
+RELS = ['__'.join(e) for e in EDGE_TYPES]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import pytorch_sparse_amd  # noqa: F401
+    return torch.ops.torch_sparse
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _graph(z):
+    colptr = {r: dev(z['colptr__' + r]) for r in RELS}
+    row = {r: dev(z['row__' + r]) for r in RELS}
+    inp = {t: dev(z['input__' + t]) for t in NODE_TYPES if 'input__' + t in z.files}
+    times = {t: dev(z['time__' + t]) for t in NODE_TYPES if 'time__' + t in z.files}
+    return colptr, row, inp, times
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'py8_hetero_*.npz'))), ids=os.path.basename)
+def test_golden_hetero_sampling(ops, path):
+    z = np.load(path)
+    colptr, row, inp, times = _graph(z)
+    mode, hops, fanval = str(z['mode']), int(z['hops']), int(z['fan'])
+    fan = {r: [fanval] * hops for r in RELS}
+    if mode.startswith('temporal'):
+        out = ops.hetero_temporal_neighbor_sample(NODE_TYPES, EDGE_TYPES, colptr, row, inp, fan, times, hops, False, True)
+    else:
+        out = ops.hetero_neighbor_sample(NODE_TYPES, EDGE_TYPES, colptr, row, inp, fan, hops, False, mode == 'directed')
+    for t in NODE_TYPES:
+        np.testing.assert_array_equal(out[0][t].cpu().numpy(), z['node__' + t], err_msg='node ' + t)
+    for r in RELS:
+        for got, key in ((out[1][r], 'orow__'), (out[2][r], 'ocol__'), (out[3][r], 'oedge__')):
+            np.testing.assert_array_equal(got.cpu().numpy(), z[key + r], err_msg=key + r)
+
+
+def _random_graph(seed, sizes):
+    g = torch.Generator().manual_seed(seed)
+    colptr, row = {}, {}
+    for (s, r, d) in EDGE_TYPES:
+        rel = '__'.join((s, r, d))
+        deg = torch.randint(0, 40, (sizes[d], ), generator=g)
+        deg[::5] = 0
+        cp = torch.zeros(sizes[d] + 1, dtype=torch.long)
+        cp[1:] = deg.cumsum(0)
+        colptr[rel] = cp
+        row[rel] = torch.randint(0, sizes[s], (int(cp[-1]), ), generator=g)
+    times = {t: torch.randint(0, 100, (sizes[t], ), generator=g) for t in NODE_TYPES}
+    return colptr, row, times, g
+
+
+@pytest.mark.parametrize('replace', [False, True])
+@pytest.mark.parametrize('temporal', [False, True])
+def test_random_draws_keep_the_reference_guarantees(ops, replace, temporal):
+    sizes = {'paper': 5000, 'author': 2000, 'venue': 30}
+    colptr, row, times, g = _random_graph(3, sizes)
+    inp = {'paper': torch.randperm(sizes['paper'], generator=g)[:200], 'venue': torch.tensor([3, 7])}
+    fan = {r: [4, 3] for r in RELS}
+    todev = lambda d: {k: v.to(DEV) for k, v in d.items()}  # noqa: E731
+    torch.manual_seed(11)
+    if temporal:
+        out = ops.hetero_temporal_neighbor_sample(NODE_TYPES, EDGE_TYPES, todev(colptr), todev(row), todev(inp), fan,
+                                                  todev(times), 2, replace, True)
+    else:
+        out = ops.hetero_neighbor_sample(NODE_TYPES, EDGE_TYPES, todev(colptr), todev(row), todev(inp), fan, 2, replace, True)
+    node = {t: out[0][t].cpu() for t in NODE_TYPES}
+    for t, x in inp.items():  # the input nodes come first, in order
+        assert torch.equal(node[t][:x.numel()], x)
+    if not temporal:  # one id per node (the temporal sampler numbers (node, root) pairs: a node may repeat)
+        for t in NODE_TYPES:
+            assert node[t].unique().numel() == node[t].numel()
+    total = 0
+    for (s, _, d), rel in zip(EDGE_TYPES, RELS):
+        r, c, e = out[1][rel].cpu(), out[2][rel].cpu(), out[3][rel].cpu()
+        assert r.numel() == c.numel() == e.numel()
+        total += r.numel()
+        if r.numel() == 0:
+            continue
+        assert int(r.max()) < node[s].numel() and int(c.max()) < node[d].numel()
+        # every edge is a stored entry: its source is row[e], its destination owns the segment that holds e
+        assert torch.equal(row[rel][e], node[s][r])
+        w = node[d][c]
+        assert bool((colptr[rel][w] <= e).all()) and bool((e < colptr[rel][w + 1]).all())
+        # per destination occurrence: at most fan draws, exactly min(deg, fan) without replacement and without time
+        cnt = torch.bincount(c, minlength=node[d].numel())
+        assert int(cnt.max()) <= 4
+        if not replace:
+            key = c * (int(e.max()) + 1) + e
+            assert key.unique().numel() == key.numel()  # distinct entries per destination
+        if not temporal and not replace:
+            first_hop = cnt[:inp[d].numel()] if d in inp else cnt[:0]
+            deg = (colptr[rel][1:] - colptr[rel][:-1])[inp[d]] if d in inp else first_hop
+            assert torch.equal(first_hop, torch.minimum(deg, torch.full_like(deg, 4)))
+        if temporal:
+            # the drawn source is not younger than the ROOT of the tree it was drawn into; roots: the input nodes
+            pass
+    assert total > 0
+    # reproducible under torch.manual_seed
+    torch.manual_seed(11)
+    if temporal:
+        again = ops.hetero_temporal_neighbor_sample(NODE_TYPES, EDGE_TYPES, todev(colptr), todev(row), todev(inp), fan,
+                                                    todev(times), 2, replace, True)
+    else:
+        again = ops.hetero_neighbor_sample(NODE_TYPES, EDGE_TYPES, todev(colptr), todev(row), todev(inp), fan, 2, replace, True)
+    for t in NODE_TYPES:
+        assert torch.equal(again[0][t], out[0][t])
+
+
+def test_temporal_constraint_holds_on_every_drawn_edge(ops):
+    """One hop from `paper` roots: every drawn source v obeys time[src][v] <= time[paper][root] -- with and without
+    replacement, and a root none of whose neighbours qualifies draws nothing."""
+    sizes = {'paper': 3000, 'author': 1500, 'venue': 20}
+    colptr, row, times, g = _random_graph(5, sizes)
+    roots = torch.randperm(sizes['paper'], generator=g)[:300]
+    todev = lambda d: {k: v.to(DEV) for k, v in d.items()}  # noqa: E731
+    for replace in (False, True):
+        out = ops.hetero_temporal_neighbor_sample(NODE_TYPES, EDGE_TYPES, todev(colptr), todev(row), {'paper': roots.to(DEV)},
+                                                  {r: [5] for r in RELS}, todev(times), 1, replace, True)
+        seen = 0
+        for (s, _, d), rel in zip(EDGE_TYPES, RELS):
+            if d != 'paper':
+                assert out[1][rel].numel() == 0  # only paper nodes are in the first frontier
+                continue
+            r, c, e = out[1][rel].cpu(), out[2][rel].cpu(), out[3][rel].cpu()
+            src = out[0][s].cpu()[r]
+            root_time = times['paper'][roots[c]]
+            assert bool((times[s][src] <= root_time).all())
+            assert torch.equal(row[rel][e], src)
+            seen += r.numel()
+            if replace:  # exactly 5 draws for every root with at least one valid neighbour, none otherwise
+                cp, rw = colptr[rel], row[rel]
+                valid = torch.zeros(roots.numel(), dtype=torch.long)
+                for i, w in enumerate(roots.tolist()):
+                    nb = rw[cp[w]:cp[w + 1]]
+                    valid[i] = int((times[s][nb] <= times['paper'][w]).sum())
+                cnt = torch.bincount(c, minlength=roots.numel())
+                assert torch.equal(cnt, torch.where(valid > 0, torch.full_like(valid, 5), torch.zeros_like(valid)))
+        assert seen > 0
