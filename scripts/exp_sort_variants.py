@@ -27,7 +27,7 @@ if '--build' in sys.argv:
 import torch  # noqa: E402
 from pytorch_sparse_amd import synth  # noqa: E402
 dev = torch.device('cuda:0')
-m = n = 500000
+m = n = int(os.environ.get('MN', 500000))
 E = int(os.environ.get('E', 7500000))
 row, col = synth.uniform_edges(m, n, E, seed=0, device=dev)
 i64 = ctypes.c_int64
