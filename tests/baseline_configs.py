@@ -70,7 +70,7 @@ _PMC = None
 
 def pmc_traffic(workload, kernel_substr):
     """Counter-measured fabric bytes per call of one kernel (FETCH_SIZE x 2 + WRITE_SIZE, calibrated in
-    profiles/traffic_ns.json) from the committed builder-run profiles -- the newest of profiles/r04_pmc.json /
+    profiles/traffic_ns.json) from the committed builder-run profiles -- the newest of profiles/r05_pmc.json / r04_pmc.json /
     r03_pmc.json that holds the workload AND a kernel of that name -- NOT measured in this run (PMC passes need
     rocprofv3).  kernel_substr '*' = every kernel of the workload summed (a sort is build + passes).
     -> dict for a roofline's `traffic` fields, or {} when no file has it."""
@@ -78,7 +78,7 @@ def pmc_traffic(workload, kernel_substr):
     if _PMC is None:
         import json
         _PMC = []
-        for name in ('r04_pmc.json', 'r03_pmc.json'):
+        for name in ('r05_pmc.json', 'r04_pmc.json', 'r03_pmc.json'):
             path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', name)
             try:
                 _PMC.append((name, json.load(open(path))))
