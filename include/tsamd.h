@@ -284,6 +284,25 @@ int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const int64_t *co
                              void *grad_value, void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
                              int64_t E, void *workspace, size_t workspace_bytes, void *stream);
 
+/* min / max whose winners stay inside the caller (SparseTensor.matmul(x, 'min' | 'max') returns `out` only and
+ * keeps arg_out for its own backward, torch_sparse/matmul.py:60-77, csrc/spmm.cpp:183-203): the same entry ids as
+ * arg_out in 32-bit words -- half the bytes in the forward's store and in the backward's read of them (configs[2]:
+ * 1.07 -> 0.54 GB each way).  E < 2^31 ("no winner" = E as in tsamd_spmm).
+ *   tsamd_spmm_minmax_arg32: tsamd_spmm / tsamd_spmm_cached (cache == NULL: stateless) for reduce = MIN | MAX with
+ *     arg_out32 [B, M, K] int32; workspace = tsamd_spmm_workspace_bytes / tsamd_spmm_cached_workspace_bytes.
+ *   tsamd_spmm_minmax_bw_csc_arg32: tsamd_spmm_minmax_bw_csc on those ids; TSAMD_ERR_UNSUPPORTED when grad_value is
+ *     wanted and the rows are not 16-byte packets (or grad_mat is NULL): widen the ids and take
+ *     tsamd_spmm_minmax_bw / _csc instead. */
+int tsamd_spmm_minmax_arg32(int dtype, int reduce, const int64_t *rowptr, const int64_t *col, const void *value,
+                            const void *mat, void *out, int32_t *arg_out32, int64_t B, int64_t M, int64_t N,
+                            int64_t K, int64_t E, void *workspace, size_t workspace_bytes, void *cache,
+                            size_t cache_bytes, int cache_valid, void *stream);
+int tsamd_spmm_minmax_bw_csc_arg32(int dtype, const int64_t *rowptr, const int64_t *col, const void *value,
+                                   const void *mat, const void *grad_out, const int32_t *arg_out32,
+                                   const int64_t *colptr, const int64_t *csr2csc, const int64_t *row,
+                                   void *grad_value, void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
+                                   int64_t E, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * COO row ids <-> CSR row pointer.  Replace ind2ptr_cuda / ptr2ind_cuda
  * (csrc/cuda/convert_cuda.cu:26-67, csrc/cpu/convert_cpu.cpp:7-57).

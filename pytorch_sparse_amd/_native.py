@@ -18,6 +18,7 @@ SYMBOLS = [
     'tsamd_spmm_workspace_bytes', 'tsamd_spmm', 'tsamd_spmm_permuted', 'tsamd_spmm_profiled',
     'tsamd_spmm_partial_workspace_bytes', 'tsamd_spmm_partial',
     'tsamd_spmm_operand_cache_bytes', 'tsamd_spmm_cached_workspace_bytes', 'tsamd_spmm_cached',
+    'tsamd_spmm_minmax_arg32', 'tsamd_spmm_minmax_bw_csc_arg32',
     'tsamd_gather_rows', 'tsamd_relabel_ids', 'tsamd_spmm_relabelled_workspace_bytes', 'tsamd_spmm_relabelled',
     'tsamd_spmm_coo_small_supported', 'tsamd_spmm_coo_small',
     'tsamd_spmm_value_bw',
@@ -223,6 +224,29 @@ def spmm_minmax_bw(rowptr, col, value, mat, grad_out, arg_out, want_value=True, 
     return gv, gm
 
 
+def spmm_minmax_arg32(rowptr, col, value, mat, reduce):
+    """C-ABI ``tsamd_spmm_minmax_arg32`` (stateless): min / max with the winners as int32 ids -> (out, arg32)."""
+    require_gpu(rowptr, col, value, mat)
+    mat = mat.contiguous()
+    M, E = rowptr.numel() - 1, col.numel()
+    N, K = mat.size(-2), mat.size(-1)
+    B = mat.numel() // (N * K) if N * K > 0 else 1
+    red = REDUCES[reduce]
+    dt = dtype_code(mat.dtype)
+    out = torch.empty(list(mat.shape[:-2]) + [M, K], dtype=mat.dtype, device=mat.device)
+    arg = torch.empty(out.shape, dtype=torch.int32, device=mat.device)
+    L = lib()
+    nbytes = L.tsamd_spmm_workspace_bytes(dt, red, _i64(B), _i64(M), _i64(N), _i64(K), _i64(E))
+    ws = workspace(nbytes, mat.device)
+    with torch.cuda.device(mat.device):
+        st = L.tsamd_spmm_minmax_arg32(dt, red, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(out), _ptr(arg),
+                                       _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
+                                       ctypes.c_size_t(ws.numel()), None, ctypes.c_size_t(0), 0,
+                                       stream_ptr(mat.device))
+    check(st, 'tsamd_spmm_minmax_arg32')
+    return out, arg
+
+
 def spmm_minmax_bw_csc(rowptr, col, value, mat, grad_out, arg_out, colptr, csr2csc, row, want_value=True,
                        want_mat=True):
     """C-ABI ``tsamd_spmm_minmax_bw_csc`` (pull formulation over the CSC arrays, no atomics):
@@ -239,11 +263,12 @@ def spmm_minmax_bw_csc(rowptr, col, value, mat, grad_out, arg_out, colptr, csr2c
     L = lib()
     nb = L.tsamd_spmm_minmax_bw_csc_workspace_bytes(dt, _i64(B), _i64(M), _i64(N), _i64(K), _i64(E))
     ws = workspace(nb, mat.device)
+    fn = L.tsamd_spmm_minmax_bw_csc_arg32 if arg_out.dtype == torch.int32 else L.tsamd_spmm_minmax_bw_csc
     with torch.cuda.device(mat.device):
-        st = L.tsamd_spmm_minmax_bw_csc(dt, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(grad_out),
-                                        _ptr(arg_out), _ptr(colptr), _ptr(csr2csc), _ptr(row), _ptr(gv), _ptr(gm),
-                                        _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
-                                        ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
+        st = fn(dt, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(grad_out),
+                _ptr(arg_out), _ptr(colptr), _ptr(csr2csc), _ptr(row), _ptr(gv), _ptr(gm),
+                _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
+                ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
     check(st, 'tsamd_spmm_minmax_bw_csc')
     return gv, gm
 

@@ -205,9 +205,11 @@ Tensor csc_values(const Tensor &value, const Tensor &csr2csc) {
 }
 
 // Forward launch: mirrors the argument checks of spmm_cpu.cpp:12-24 / spmm_cuda.cu:96-109.
+// arg32: min / max winners as int32 ids (callers that keep them for their own backward only, tsamd.h)
 std::tuple<Tensor, OptTensor> spmm_fw(const Tensor &rowptr, const Tensor &col,
                                       const OptTensor &opt_value, Tensor mat,
-                                      const std::string &reduce, const OptTensor &opt_perm = std::nullopt) {
+                                      const std::string &reduce, const OptTensor &opt_perm = std::nullopt,
+                                      bool arg32 = false) {
   check_gpu(rowptr, "rowptr");
   check_gpu(col, "col");
   if (opt_value.has_value()) check_gpu(opt_value.value(), "value");
@@ -236,13 +238,23 @@ std::tuple<Tensor, OptTensor> spmm_fw(const Tensor &rowptr, const Tensor &col,
   const int red = reduce_code(reduce);
   OptTensor arg_out = std::nullopt;
   int64_t *arg_ptr = nullptr;
-  if (red == TSAMD_MIN || red == TSAMD_MAX) {
+  arg32 = arg32 && (red == TSAMD_MIN || red == TSAMD_MAX) && E < ((int64_t)1 << 31) && !opt_perm.has_value();
+  if (arg32) {
+    arg_out = torch::empty(sizes, rp.options().dtype(at::kInt));
+  } else if (red == TSAMD_MIN || red == TSAMD_MAX) {
     arg_out = torch::empty(sizes, rp.options());
     arg_ptr = arg_out.value().data_ptr<int64_t>();
   }
   const int dt = dtype_code(mat);
   const size_t need = tsamd_spmm_workspace_bytes(dt, red, B, M, N, K, E);
   Tensor ws = workspace(need, mat);
+  if (arg32) {
+    check_status(tsamd_spmm_minmax_arg32(dt, red, rp.data_ptr<int64_t>(), c.data_ptr<int64_t>(), ptr_or_null(value),
+                                         mat.data_ptr(), out.data_ptr(), arg_out.value().data_ptr<int32_t>(), B, M, N,
+                                         K, E, ws.data_ptr(), (size_t)ws.numel(), nullptr, 0, 0, current_stream(mat)),
+                 "tsamd_spmm_minmax_arg32");
+    return std::make_tuple(out, arg_out);
+  }
   if (opt_perm.has_value()) {  // entries through a permutation (the CSC view in the backward)
     check_index(opt_perm.value(), "perm");
     TORCH_CHECK(opt_perm.value().numel() == E, "Input mismatch");
@@ -263,7 +275,7 @@ std::tuple<Tensor, OptTensor> spmm_fw(const Tensor &rowptr, const Tensor &col,
 
 // the forward of the registered ops: tsamd_spmm, or tsamd_spmm_cached when this product copies its operand
 std::tuple<Tensor, OptTensor> spmm_fw_cached(const Tensor &rowptr, const Tensor &col, const OptTensor &opt_value,
-                                             const Tensor &mat_in, const std::string &reduce) {
+                                             const Tensor &mat_in, const std::string &reduce, bool arg32 = false) {
   OperandCache &oc = operand_cache_state();
   const int red = reduce_code(reduce);
   bool eligible = oc.enabled && mat_in.defined() && mat_in.device().is_cuda() && mat_in.dim() >= 2 &&
@@ -290,7 +302,7 @@ std::tuple<Tensor, OptTensor> spmm_fw_cached(const Tensor &rowptr, const Tensor 
     cache_bytes = tsamd_spmm_operand_cache_bytes(dt, red, B, M, N, K, E);
   }
   if (!eligible || cache_bytes == 0 || stream_is_capturing(current_stream(mat_in)))
-    return spmm_fw(rowptr, col, opt_value, mat_in, reduce);
+    return spmm_fw(rowptr, col, opt_value, mat_in, reduce, std::nullopt, arg32);
 
   // same checks as spmm_fw
   check_gpu(col, "col");
@@ -309,7 +321,10 @@ std::tuple<Tensor, OptTensor> spmm_fw_cached(const Tensor &rowptr, const Tensor 
   Tensor out = torch::empty(sizes, mat_in.options().requires_grad(false));
   OptTensor arg_out = std::nullopt;
   int64_t *arg_ptr = nullptr;
-  if (red == TSAMD_MIN || red == TSAMD_MAX) {
+  arg32 = arg32 && (red == TSAMD_MIN || red == TSAMD_MAX) && E < ((int64_t)1 << 31);
+  if (arg32) {
+    arg_out = torch::empty(sizes, rowptr.options().dtype(at::kInt));
+  } else if (red == TSAMD_MIN || red == TSAMD_MAX) {
     arg_out = torch::empty(sizes, rowptr.options());
     arg_ptr = arg_out.value().data_ptr<int64_t>();
   }
@@ -353,6 +368,15 @@ std::tuple<Tensor, OptTensor> spmm_fw_cached(const Tensor &rowptr, const Tensor 
     ++oc.hits;
   }
   Tensor ws = workspace(tsamd_spmm_cached_workspace_bytes(dt, red, B, M, N, K, E), mat_in);
+  if (arg32) {
+    check_status(tsamd_spmm_minmax_arg32(dt, red, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                                         ptr_or_null(value), mat_in.data_ptr(), out.data_ptr(),
+                                         arg_out.value().data_ptr<int32_t>(), B, M, N, K, E, ws.data_ptr(),
+                                         (size_t)ws.numel(), oc.buf.data_ptr(), (size_t)oc.buf.numel(), valid ? 1 : 0,
+                                         stream),
+                 "tsamd_spmm_minmax_arg32");
+    return std::make_tuple(out, arg_out);
+  }
   check_status(tsamd_spmm_cached(dt, red, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(), ptr_or_null(value),
                                  mat_in.data_ptr(), out.data_ptr(), arg_ptr, B, M, N, K, E, ws.data_ptr(),
                                  (size_t)ws.numel(), oc.buf.data_ptr(), (size_t)oc.buf.numel(), valid ? 1 : 0, stream),
@@ -459,9 +483,9 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
  public:
   static variable_list forward(AutogradContext *ctx, Tensor rowptr, Tensor col, Tensor value,
                                Tensor mat, bool has_value, bool is_max, OptTensor opt_colptr,
-                               OptTensor opt_csr2csc, OptTensor opt_row) {
+                               OptTensor opt_csr2csc, OptTensor opt_row, bool arg32) {
     OptTensor v = has_value ? OptTensor(value) : std::nullopt;
-    auto res = spmm_fw_cached(rowptr, col, v, mat, is_max ? "max" : "min");
+    auto res = spmm_fw_cached(rowptr, col, v, mat, is_max ? "max" : "min", arg32);
     Tensor out = std::get<0>(res), arg_out = std::get<1>(res).value();
     const bool has_csc = opt_colptr.has_value() && opt_csr2csc.has_value() && opt_row.has_value();
     if (has_csc) {
@@ -500,12 +524,27 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
       if (want_mat) grad_mat = torch::empty_like(mat, mat.options().requires_grad(false));
       const int dt = dtype_code(mat);
       int st = TSAMD_ERR_UNSUPPORTED;
-      // The pull is deterministic and 27 % faster for grad_mat alone (config 3: 1.8 vs 2.5 ms).  When
-      // grad_value is wanted as well the scatter kernel gets it nearly for free (fused, +0.1-0.3 ms) while the
-      // pull pays a masked SDDMM (+1.0 ms): 2.55 vs 2.85 ms -- so that case only takes the pull when
-      // torch.use_deterministic_algorithms(True) asks for reproducible gradients.
-      const bool pull = has_csc && want_mat && (!want_value || at::globalContext().deterministicAlgorithms());
-      if (pull) {
+      // The pull is deterministic and faster for grad_mat alone (configs[2]: 1.36 vs 2.47 ms).  With grad_value as
+      // well it pays a masked SDDMM where the scatter kernel gets the value gradient fused: WHICH of the two wins
+      // depends on the row size, and the front-end decides that BEFORE the forward -- it hands the CSC arrays over
+      // exactly when it wants the pull (pytorch_sparse_amd/tensor.py: storage_spmm; until round 5 this line asked
+      // for deterministic algorithms again and sent the with-values case down the scatter route although the
+      // front-end had built the CSC arrays for it).
+      const bool pull = has_csc && want_mat;
+      if (pull && arg_out.scalar_type() == at::kInt) {  // the winners were kept as 32-bit ids (forward, arg32)
+        Tensor colptr = s[5].contiguous(), csr2csc = s[6].contiguous(), row = s[7].contiguous();
+        Tensor ws = workspace(tsamd_spmm_minmax_bw_csc_workspace_bytes(dt, B, M, N, K, E), mat);
+        st = tsamd_spmm_minmax_bw_csc_arg32(dt, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                                            has_value ? value.data_ptr() : nullptr, mat.data_ptr(),
+                                            grad_out.data_ptr(), arg_out.data_ptr<int32_t>(),
+                                            colptr.data_ptr<int64_t>(), csr2csc.data_ptr<int64_t>(),
+                                            row.data_ptr<int64_t>(), want_value ? grad_value.data_ptr() : nullptr,
+                                            grad_mat.data_ptr(), B, M, N, K, E, ws.data_ptr(), (size_t)ws.numel(),
+                                            current_stream(mat));
+        if (st != TSAMD_ERR_UNSUPPORTED) check_status(st, "tsamd_spmm_minmax_bw_csc_arg32");
+      }
+      if (arg_out.scalar_type() == at::kInt && st == TSAMD_ERR_UNSUPPORTED) arg_out = arg_out.to(at::kLong);
+      if (pull && st == TSAMD_ERR_UNSUPPORTED) {
         Tensor colptr = s[5].contiguous(), csr2csc = s[6].contiguous(), row = s[7].contiguous();
         Tensor ws = workspace(tsamd_spmm_minmax_bw_csc_workspace_bytes(dt, B, M, N, K, E), mat);
         st = tsamd_spmm_minmax_bw_csc(dt, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
@@ -529,7 +568,7 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
             "tsamd_spmm_minmax_bw");
       }
     }
-    return {Tensor(), Tensor(), grad_value, grad_mat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {Tensor(), Tensor(), grad_value, grad_mat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -716,23 +755,25 @@ Tensor spmm_mean_owned(OptTensor opt_row, Tensor rowptr, Tensor col, OptTensor o
 
 std::tuple<Tensor, Tensor> spmm_min(Tensor rowptr, Tensor col, OptTensor opt_value, Tensor mat) {
   auto r = SpmmMinMaxFunction::apply(rowptr, col, opt_value.value_or(col), mat,
-                                     opt_value.has_value(), false, std::nullopt, std::nullopt, std::nullopt);
+                                     opt_value.has_value(), false, std::nullopt, std::nullopt, std::nullopt, false);
   return std::make_tuple(r[0], r[1]);
 }
 
 std::tuple<Tensor, Tensor> spmm_max(Tensor rowptr, Tensor col, OptTensor opt_value, Tensor mat) {
   auto r = SpmmMinMaxFunction::apply(rowptr, col, opt_value.value_or(col), mat,
-                                     opt_value.has_value(), true, std::nullopt, std::nullopt, std::nullopt);
+                                     opt_value.has_value(), true, std::nullopt, std::nullopt, std::nullopt, false);
   return std::make_tuple(r[0], r[1]);
 }
 
 // tsamd::spmm_minmax(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor? csr2csc, Tensor? row,
-//                    Tensor mat, bool is_max) -> (Tensor, Tensor)
+//                    Tensor mat, bool is_max, bool arg32) -> (Tensor, Tensor)
 // spmm_min / spmm_max with the CSC arrays of the matrix: same forward, atomic-free deterministic backward.
+// arg32: the second result holds the winners as int32 ids (for callers that only keep it for this backward:
+// SparseTensor.matmul returns `out` alone) -- half the bytes written by the forward and read by the backward.
 std::tuple<Tensor, Tensor> spmm_minmax(Tensor rowptr, Tensor col, OptTensor opt_value, OptTensor opt_colptr,
-                                       OptTensor opt_csr2csc, OptTensor opt_row, Tensor mat, bool is_max) {
+                                       OptTensor opt_csr2csc, OptTensor opt_row, Tensor mat, bool is_max, bool arg32) {
   auto r = SpmmMinMaxFunction::apply(rowptr, col, opt_value.value_or(col), mat, opt_value.has_value(), is_max,
-                                     opt_colptr, opt_csr2csc, opt_row);
+                                     opt_colptr, opt_csr2csc, opt_row, arg32);
   return std::make_tuple(r[0], r[1]);
 }
 

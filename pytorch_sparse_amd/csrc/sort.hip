@@ -374,8 +374,11 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
         const unsigned long long sw = sv[u];
         if ((sw & (0x3full << 56)) != ep || (sw >> 62) == 0) {  // not published yet (for this pass): poll again from here
           if (++spins > kSpinLimit) {
+            // ~1 s without the predecessor's status word: the dispatch-order assumption (design note above) does
+            // not hold on this machine.  The result would be a silently wrong permutation -- abort the launch
+            // instead (the HIP runtime reports the queue error), after leaving the reason in the header.
             hdr[kHdrError] = 1;
-            done = true;
+            __builtin_trap();
           }
           __builtin_amdgcn_s_sleep(1);
           break;

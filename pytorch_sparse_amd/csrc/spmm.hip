@@ -139,6 +139,9 @@ struct Workspace {
   const int64_t *arg_map;
   int64_t arg_none;
   const int64_t *deg_rowptr;
+  // min / max: the winners are stored as 32-bit entry ids (tsamd_spmm_minmax_arg32: callers that keep them only
+  // for their own backward -- half the bytes of the API's int64 arg_out in the forward store and the backward read)
+  int arg32;
 };
 
 // ---------------------------------------------------------------------------
@@ -641,13 +644,18 @@ __device__ __forceinline__ void write_row_partial(T *__restrict__ outk, int64_t 
   *reinterpret_cast<Pack<int64_t, VEC> *>(argk) = a;
 }
 
-template <typename T, int VEC, int RED>
-__device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restrict__ argk,
+// A32: the ids go out as int32 (tsamd_spmm_minmax_arg32) -- a compile-time variant: as a run-time branch the second
+// packet of ids spilled the fp32 min / max kernel (63 VGPRs at 8 waves per SIMD)
+template <typename T, int VEC, int RED, bool A32 = false>
+__device__ __forceinline__ void write_row(T *__restrict__ out_base, int64_t *__restrict__ arg_base, uint64_t arg_off,
                                           typename Traits<T>::acc_t (&val)[VEC],
                                           int64_t (&arg)[VEC], int64_t deg, bool mean,
                                           int64_t E, const Workspace &ws) {
   using A = typename Traits<T>::acc_t;
   Pack<T, VEC> o;
+  constexpr bool a32 = A32 && !kPartial && RED != RED_ADD;
+  int64_t *argk = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(arg_base) + (arg_off << (a32 ? 2 : 3)));
+  T *outk = out_base + arg_off;
   if constexpr (kPartial && RED != RED_ADD) {
     write_row_partial<T, VEC, RED>(outk, argk, val, arg, deg, ws);
     return;
@@ -699,7 +707,14 @@ __device__ __forceinline__ void write_row(T *__restrict__ outk, int64_t *__restr
     nt_store(outk, o);
 #endif
 #if !defined(TSAMD_EXP_NO_ARG_STORE)
-    nt_store(argk, a);
+    if constexpr (a32) {
+      Pack<int32_t, VEC> an;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) an.v[j] = (int32_t)a.v[j];
+      nt_store(reinterpret_cast<int32_t *>(argk), an);
+    } else {
+      nt_store(argk, a);
+    }
 #else
     asm volatile("" ::"v"(a.v[0]), "v"(a.v[VEC - 1]));
 #endif
@@ -739,7 +754,7 @@ template <int RED, bool SHORT, bool MASKED>
 constexpr int kMinWavesPerEU = kPartial ? ((RED == RED_ADD && !SHORT && !MASKED) ? 8 : 0)
                                         : ((RED != RED_ADD && !SHORT && !MASKED) ? TSAMD_MINMAX_WAVES : 0);
 
-template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false>
+template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false, bool A32 = false>
 __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, MASKED>)) void spmm_merge_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
     const T *__restrict__ value, const T *__restrict__ mat, T *__restrict__ out,
@@ -949,7 +964,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
       if constexpr (kPartial && RED == RED_ADD) {
         if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[r + g + 1] - ws.deg_rowptr[r + g];
       }
-      write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, deg_w, mean, E, ws);
+      write_row<T, VEC, RED, A32>(out, arg_out, o, val, arg64, deg_w, mean, E, ws);
     }
     init_acc<T, VEC, RED>(val, arg);
     const uint32_t done_rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, j + n - 1);
@@ -1010,7 +1025,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
           if constexpr (kPartial && RED == RED_ADD) {
             if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[r + 1] - ws.deg_rowptr[r];
           }
-          write_row<T, VEC, RED>(out + o, arg_out + o, val, arg64, deg_w, mean, E, ws);
+          write_row<T, VEC, RED, A32>(out, arg_out, o, val, arg64, deg_w, mean, E, ws);
         }
       }
       init_acc<T, VEC, RED>(val, arg);
@@ -1056,7 +1071,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
 //    row's degree, the head record and the FIRST tail record (a cut row always has one, in q-1) --
 //    is requested at once and waited for once.
 // ---------------------------------------------------------------------------
-template <typename T, int RED>
+template <typename T, int RED, bool A32 = false>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
     const int64_t *__restrict__ rowptr, T *__restrict__ out, int64_t *__restrict__ arg_out,
     int64_t M, uint32_t K, int64_t E, bool mean, Workspace ws) {
@@ -1189,7 +1204,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
       if constexpr (kPartial && RED == RED_ADD) {
         if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[R + 1] - ws.deg_rowptr[R];
       }
-      write_row<T, 1, RED>(out + o, arg_out + o, val, arg, deg_w, mean, E, ws);
+      write_row<T, 1, RED, A32>(out, arg_out, o, val, arg, deg_w, mean, E, ws);
     }
     kb += (uint32_t)(kCols * kWave);
     if (kb >= K) break;
@@ -1310,6 +1325,7 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.arg_map = nullptr;
   w.arg_none = 0;
   w.deg_rowptr = nullptr;
+  w.arg32 = 0;
   w.ohash_bits = 1;
   while (w.ohash_bits < 32 && ((uint64_t)1 << w.ohash_bits) < (uint64_t)(M > 1 ? M : 2)) ++w.ohash_bits;
   w.ohash_shift = w.ohash_bits > 1 ? w.ohash_bits / 2 : 1;
@@ -1382,6 +1398,10 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   TSAMD_LAUNCH_CHECK();
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[1], stream));
   const unsigned int gx = (unsigned int)ceil_div(ws.P, kWavesPerBlock);
+  // int32 winner ids (tsamd_spmm_minmax_arg32): min / max of the floating types (what autograd differentiates)
+  constexpr bool kArg32able = !kPartial && RED != RED_ADD &&
+                              (std::is_same<T, float>::value || std::is_same<T, double>::value ||
+                               std::is_same<T, f16_t>::value || std::is_same<T, bf16_t>::value);
   constexpr bool kMaskable = RED == RED_ADD && (std::is_same<T, float>::value || std::is_same<T, double>::value ||
                                                 std::is_same<T, f16_t>::value || std::is_same<T, bf16_t>::value);
   if (ws.wmask != nullptr) {
@@ -1391,6 +1411,19 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
                          ktiles, lgG, mean, ws);
     else
       return TSAMD_ERR_UNSUPPORTED;
+  } else if (kArg32able && ws.arg32) {
+    if constexpr (kArg32able) {
+      if (lgG >= 3)
+        hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, true, false, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                           dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N, (uint32_t)K, E,
+                           ktiles, lgG, mean, ws);
+      else
+        hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, false, false, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                           dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N, (uint32_t)K, E,
+                           ktiles, lgG, mean, ws);
+    }
+  } else if (ws.arg32) {
+    return TSAMD_ERR_UNSUPPORTED;
   } else if (lgG >= 3)
     hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
                        dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N,
@@ -1402,8 +1435,14 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   TSAMD_LAUNCH_CHECK();
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[2], stream));
   if (ws.P > 1) {
-    hipLaunchKernelGGL((spmm_fixup_kernel<T, RED>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
-                       stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+    if (kArg32able && ws.arg32) {
+      if constexpr (kArg32able)
+        hipLaunchKernelGGL((spmm_fixup_kernel<T, RED, true>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
+                           stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+    } else {
+      hipLaunchKernelGGL((spmm_fixup_kernel<T, RED>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
+                         stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+    }
     TSAMD_LAUNCH_CHECK();
   }
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[3], stream));
@@ -1479,7 +1518,7 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
                       size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev,
                       bool relabelled = false, const int64_t *perm = nullptr,
                       const uint32_t *wmask = nullptr, void *cache = nullptr, size_t cache_bytes = 0,
-                      int cache_valid = 0, const PartialOpts *partial = nullptr) {
+                      int cache_valid = 0, const PartialOpts *partial = nullptr, bool arg32 = false) {
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
@@ -1511,6 +1550,10 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
     ws.out_relabel = 1;
   }
   ws.perm = perm;
+  if (arg32) {  // E itself ("no winner") must fit a non-negative int32
+    if (!minmax || partial != nullptr || E >= (int64_t)1 << 31) return TSAMD_ERR_UNSUPPORTED;
+    ws.arg32 = 1;
+  }
   if (partial != nullptr) {
     if (reduce == TSAMD_MEAN && partial->deg_rowptr == nullptr) return TSAMD_ERR_INVALID;
     ws.partial = 1;
@@ -1530,7 +1573,7 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   int vec = es <= 2 ? 4 : (int)(16 / es);  // widest packet for the type (see dispatch_spmm)
   while (vec > 1 && !((K % vec) == 0 && ((uintptr_t)mat % (vec * es)) == 0 &&
                       ((uintptr_t)out % (vec * es)) == 0 &&
-                      (!minmax || ((uintptr_t)arg_out % (vec * 8)) == 0)))
+                      (!minmax || ((uintptr_t)arg_out % (vec * (arg32 ? 4 : 8))) == 0)))
     vec >>= 1;
 
 #if TSAMD_SPMM_PARTIAL_BUILD
@@ -1582,6 +1625,18 @@ extern "C" int tsamd_spmm_cached(int dtype, int reduce, const int64_t *rowptr, c
   return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, workspace,
                     workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, false, nullptr, nullptr,
                     cache, cache_bytes, cache_valid);
+}
+
+// min / max with the winners as 32-bit entry ids (include/tsamd.h); cache == nullptr: stateless
+extern "C" int tsamd_spmm_minmax_arg32(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
+                                       const void *value, const void *mat, void *out, int32_t *arg_out32, int64_t B,
+                                       int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
+                                       size_t workspace_bytes_given, void *cache, size_t cache_bytes, int cache_valid,
+                                       void *stream_) {
+  if (reduce != TSAMD_MIN && reduce != TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
+  return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, reinterpret_cast<int64_t *>(arg_out32), B, M, N, K,
+                    E, workspace, workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, false,
+                    nullptr, nullptr, cache, cache_bytes, cache_valid, nullptr, true);
 }
 
 // ---------------------------------------------------------------------------

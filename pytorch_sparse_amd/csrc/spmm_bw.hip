@@ -33,6 +33,42 @@ constexpr int kUnroll = 2;
 // ---------------------------------------------------------------------------
 // MASKED: only the features whose bit is set in the entry's winner record (spmm_internal.h) enter the
 // dot product -- grad_value of the min/max backward as an SDDMM, for callers that built the records.
+// Masked dot product of one 16-byte packet of 2-byte features (8 of them), fp32 accumulation: the winner bits are
+// widened to a 16-bit lane mask per dword (two v_bfe_i32 + one v_bfi), BOTH operands are ANDed with it (a feature
+// that did not win must not contribute at all: 0 * Inf would be a NaN) and gfx950's v_dot2c_f32_{bf16,f16} takes the
+// pair -- conversion, two multiplies and two adds in one instruction.  24 VALU instructions per packet instead of
+// ~45 (two conversions + select + FMA per element): the masked SDDMM ran at 0.94 of the VALU slots
+// (profiles/r04_sq_counters.md).  -DTSAMD_MASKED_DOT2=0 keeps the per-element form.
+#ifndef TSAMD_MASKED_DOT2
+#define TSAMD_MASKED_DOT2 1
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ float masked_dot8(const u32x4_t &x, const u32x4_t &y, uint32_t bits, float acc) {
+  static_assert(sizeof(T) == 2, "2-byte features");
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * d, 1);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * d + 1, 1);
+    const uint32_t m = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
+    const uint32_t xm = x[d] & m, ym = y[d] & m;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      bf16x2_t a, b;
+      __builtin_memcpy(&a, &xm, 4);
+      __builtin_memcpy(&b, &ym, 4);
+      acc = __builtin_amdgcn_fdot2_f32_bf16(a, b, acc, false);
+    } else {
+      typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+      f16x2_t a, b;
+      __builtin_memcpy(&a, &xm, 4);
+      __builtin_memcpy(&b, &ym, 4);
+      acc = __builtin_amdgcn_fdot2(a, b, acc, false);
+    }
+  }
+  return acc;
+}
+
 template <typename T, int VEC, bool MASKED = false>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_value_bw_kernel(
     const int64_t *__restrict__ row, const int64_t *__restrict__ rowptr,
@@ -116,6 +152,12 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_value_bw_kernel(
               __builtin_memcpy(&xb, &x, 16);
               __builtin_memcpy(&yb, &y, 16);
               asm volatile("" : "+v"(xb), "+v"(yb));
+#if TSAMD_MASKED_DOT2
+              if constexpr (sizeof(T) == 2 && VEC == 8 && std::is_same<A, float>::value) {
+                acc[u] = masked_dot8<T>(xb, yb, bits, acc[u]);
+                continue;
+              }
+#endif
               __builtin_memcpy(&x, &xb, 16);
               __builtin_memcpy(&y, &yb, 16);
             }
@@ -169,6 +211,134 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_value_bw_kernel(
     if (mean) mine = mine / (A)deg_l;
     out[base + lane] = Traits<T>::from_acc(mine);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Masked SDDMM, pipelined (round 5): grad_value of the min / max pull backward from the winner records.
+// The kernel above takes a step as "record word -> (wait) -> the two 16-byte gathers -> (wait) -> dot product": two
+// dependent round trips per step and lane group, and with the skip branches in between the compiler cannot overlap
+// consecutive steps -- at configs[2] a wave spent ~1.4 us per step, i.e. it was bound by those latencies (halving
+// the VALU work of the dot product with v_dot2c moved the op by 2 %: 2.24 -> 2.20 ms).  Here a lane fetches the
+// record words of kMaskedChunk steps in ONE round trip, then takes the steps in pairs: both steps' gathers are
+// issued before the first dot product.  Same arithmetic as the kernel above (fp32 / fp64 accumulation, masked
+// elements contribute nothing), one packet per lane and step, so it needs K / VEC <= 64 packets per row
+// (K <= 512 two-byte, 256 fp32, 128 fp64 features); wider rows keep the kernel above.
+// Sum over a group of lpr consecutive lanes, result in every lane of the group: DPP inside a row of 16 lanes
+// (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror), ds_bpermute above.
+// ---------------------------------------------------------------------------
+constexpr int kMaskedChunk = 8;
+
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+  if (lpr >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  if (lpr >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  if (lpr >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if (lpr >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); // row_mirror
+  if (lpr >= 32) v += lane_xor(v, 16);
+  if (lpr >= 64) v += lane_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ double group_sum(double v, int lpr) {
+  for (int off = lpr >> 1; off > 0; off >>= 1) v += lane_xor(v, off);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_value_bw_masked_kernel(
+    const int64_t *__restrict__ row, const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
+    const T *__restrict__ mat, const T *__restrict__ grad, T *__restrict__ out, int64_t B, int64_t M, int64_t N,
+    uint32_t K, int64_t E, int lgG, const uint32_t *__restrict__ rec, uint32_t rec_stride) {
+  using A = typename Traits<T>::acc_t;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  using P = Pack<T, VEC>;
+  const int lane = (int)(threadIdx.x & 63);
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wib) * kWave;
+  if (base >= E) return;
+  const int64_t rem = E - base;
+  const int n = rem < kWave ? (int)rem : kWave;
+  uint32_t c_l = 0, r_l = 0;
+  if (lane < n) {
+    const int64_t e = base + lane;
+    c_l = (uint32_t)col[e];
+    int64_t r;
+    if (row != nullptr) {
+      r = row[e];
+    } else {  // last r with rowptr[r] <= e
+      int64_t lo = 0, hi = M;
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= e) lo = mid; else hi = mid;
+      }
+      r = lo;
+    }
+    r_l = (uint32_t)r;
+  }
+  const int G = 1 << lgG, lpr = 64 >> lgG;
+  const int g = lane >> (6 - lgG), kl = lane & (lpr - 1);
+  const uint32_t slots = K / VEC;  // the launcher guarantees K % VEC == 0 and slots <= lpr
+  const bool slot_ok = (uint32_t)kl < slots;
+  const uint32_t f0 = (uint32_t)kl * VEC;
+  const uint32_t wsel = f0 >> 5, sh = f0 & 31u;
+  constexpr uint32_t kBitsMask = VEC >= 32 ? 0xFFFFFFFFu : ((1u << (VEC & 31)) - 1u);
+  const int nsteps = (n + G - 1) >> lgG;
+  const int owner_step = lane >> lgG, owner_src = (lane & (G - 1)) << (6 - lgG);
+  A mine = A(0);  // result of the edge owned by this lane
+  for (int64_t b = 0; b < B; ++b) {
+    const T *mat_b = mat + (uint64_t)b * (uint64_t)N * K + f0;
+    const T *grad_b = grad + (uint64_t)b * (uint64_t)M * K + f0;
+    const uint32_t *rec_b = rec + ((uint64_t)b * (uint64_t)E + (uint64_t)base) * rec_stride + wsel;
+    for (int t0 = 0; t0 < nsteps; t0 += kMaskedChunk) {
+      uint32_t bits[kMaskedChunk];
+#pragma unroll
+      for (int u = 0; u < kMaskedChunk; ++u) {  // the chunk's record words: one round trip
+        const int idx = ((t0 + u) << lgG) + g;
+        uint32_t w = 0;
+        if (slot_ok && idx < n) w = rec_b[(uint32_t)idx * rec_stride];
+        bits[u] = w;
+      }
+#pragma unroll
+      for (int u = 0; u < kMaskedChunk; ++u) bits[u] = (bits[u] >> sh) & kBitsMask;
+#pragma unroll
+      for (int u = 0; u < kMaskedChunk; u += 2) {
+        if (t0 + u >= nsteps) break;                                           // wave-uniform
+        if (__ballot((bits[u] | bits[u + 1]) != 0u) == 0ull) continue;         // no winner in either step: adds nothing
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 xb[2], yb[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int idx = ((t0 + u + v) << lgG) + g;
+          const int src = idx < n ? idx : n - 1;
+          const uint32_t c = lane_read(c_l, src);
+          const uint32_t r = lane_read(r_l, src);
+          xb[v] = u32x4{0u, 0u, 0u, 0u};
+          yb[v] = u32x4{0u, 0u, 0u, 0u};
+          if (bits[u + v] != 0u) {
+            xb[v] = *reinterpret_cast<const u32x4 *>(mat_b + (uint64_t)c * K);
+            yb[v] = *reinterpret_cast<const u32x4 *>(grad_b + (uint64_t)r * K);
+          }
+        }
+        asm volatile("" : "+v"(xb[0]), "+v"(yb[0]), "+v"(xb[1]), "+v"(yb[1]));  // all four gathers in flight, whole
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          A acc = A(0);
+          if constexpr (sizeof(T) == 2 && std::is_same<A, float>::value) {
+            acc = masked_dot8<T>(xb[v], yb[v], bits[u + v], acc);
+          } else {
+            P x, y;
+            __builtin_memcpy(&x, &xb[v], 16);
+            __builtin_memcpy(&y, &yb[v], 16);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+              acc += ((bits[u + v] >> j) & 1u) ? Traits<T>::to_acc(x.v[j]) * Traits<T>::to_acc(y.v[j]) : A(0);
+          }
+          acc = group_sum(acc, lpr);
+          const A got = lane_read(acc, owner_src);
+          if (owner_step == t0 + u + v) mine += got;
+        }
+      }
+    }
+  }
+  if (lane < n) out[base + lane] = Traits<T>::from_acc(mine);
 }
 
 // ---------------------------------------------------------------------------
@@ -406,9 +576,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_minmax_bw_kernel(
 // global atomics.  A winner is only trusted to lie inside the chunk (LDS bounds); a foreign arg_out
 // gives a wrong mask, never a wild store.
 // ---------------------------------------------------------------------------
-template <typename T>
+// ARG = int64_t (the API's arg_out) or int32_t (tsamd_spmm_minmax_arg32: the same ids in half the bytes)
+template <typename T, typename ARG>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
-    const int64_t *__restrict__ row, const T *__restrict__ value, const int64_t *__restrict__ arg_out,
+    const int64_t *__restrict__ row, const T *__restrict__ value, const ARG *__restrict__ arg_out,
     uint32_t *__restrict__ rec, int64_t B, int64_t M, uint32_t K, int64_t E, uint32_t W, uint32_t S) {
   using A = typename Traits<T>::acc_t;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -440,7 +611,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
   }
   const uint32_t bit = 1u << (lane & 31), half = (uint32_t)lane >> 5;
   for (int64_t b = 0; b < B; ++b) {
-    const int64_t *a_b = arg_out + (uint64_t)b * M * K;
+    const ARG *a_b = arg_out + (uint64_t)b * M * K;
     uint32_t *rec_l = rec + ((uint64_t)b * (uint64_t)E + (uint64_t)(e0 + lane)) * S;
     uint32_t z = 0;  // bit s: mask word s of this entry is non-zero (words 0..31; the masked sum skips the others' segments)
     for (uint32_t t0 = 0; t0 < ntiles; t0 += 2) {
@@ -458,10 +629,10 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
         const uint64_t ra = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_l, p0) * K;
         const uint64_t rb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_l, p1) * K;
         int64_t a00 = -1, a01 = -1, a10 = -1, a11 = -1;
-        if (k0 < K) a00 = a_b[ra + k0];
-        if (k1 < K) a01 = a_b[ra + k1];
-        if (two && k0 < K) a10 = a_b[rb + k0];
-        if (two && k1 < K) a11 = a_b[rb + k1];
+        if (k0 < K) a00 = (int64_t)a_b[ra + k0];
+        if (k1 < K) a01 = (int64_t)a_b[ra + k1];
+        if (two && k0 < K) a10 = (int64_t)a_b[rb + k0];
+        if (two && k1 < K) a11 = (int64_t)a_b[rb + k1];
         const int64_t r00 = a00 - e0, r01 = a01 - e0, r10 = a10 - e0, r11 = a11 - e0;
         if (a00 >= 0 && r00 >= 0 && r00 < n) atomicOr(tile + (uint32_t)r00 * 4 + half, bit);
         if (a01 >= 0 && r01 >= 0 && r01 < n) atomicOr(tile + (uint32_t)r01 * 4 + 2 + half, bit);
@@ -537,9 +708,16 @@ int launch_value_bw_masked(const int64_t *row, const int64_t *rowptr, const int6
   const uint32_t lpr = slots >= 64 ? 64u : (1u << ilog2_ceil(slots));
   const int lgG = 6 - ilog2_ceil(lpr);
   const unsigned int blocks = (unsigned int)ceil_div(ceil_div(E, kWave), kWavesPerBlock);
-  hipLaunchKernelGGL((spmm_value_bw_kernel<T, VEC, true>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0,
-                     stream, row, rowptr, col, mat, grad, out, B, M, N, (uint32_t)K, E, lgG, false, rec,
-                     rec_stride);
+  const char *env_pipe = getenv("TSAMD_MASKED_SDDMM_PIPE");  // experiments: 0 = the round-4 kernel
+  const bool pipelined = !(env_pipe != nullptr && env_pipe[0] == '0');
+  if (pipelined && slots <= 64u && K % VEC == 0 && (uint64_t)kWave * rec_stride < (1ull << 32)) {
+    hipLaunchKernelGGL((spmm_value_bw_masked_kernel<T>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, stream, row,
+                       rowptr, col, mat, grad, out, B, M, N, (uint32_t)K, E, lgG, rec, rec_stride);
+  } else {
+    hipLaunchKernelGGL((spmm_value_bw_kernel<T, VEC, true>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0,
+                       stream, row, rowptr, col, mat, grad, out, B, M, N, (uint32_t)K, E, lgG, false, rec,
+                       rec_stride);
+  }
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }
@@ -732,13 +910,16 @@ extern "C" size_t tsamd_spmm_minmax_bw_csc_workspace_bytes(int dtype, int64_t B,
   return masked > lists ? masked : lists;
 }
 
-extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const int64_t *col,
-                                        const void *value, const void *mat, const void *grad_out,
-                                        const int64_t *arg_out, const int64_t *colptr,
-                                        const int64_t *csr2csc, const int64_t *row, void *grad_value,
-                                        void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
-                                        int64_t E, void *workspace, size_t workspace_bytes, void *stream_) {
+// arg32: arg_any holds int32 ids (tsamd_spmm_minmax_arg32); only the record route reads them in that width
+static int minmax_bw_csc_impl(int dtype, const int64_t *rowptr, const int64_t *col, const void *value,
+                              const void *mat, const void *grad_out, const void *arg_any, bool arg32,
+                              const int64_t *colptr, const int64_t *csr2csc, const int64_t *row, void *grad_value,
+                              void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
+                              size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int64_t *arg_out = arg32 ? nullptr : reinterpret_cast<const int64_t *>(arg_any);
+  if (arg32 && arg_any == nullptr && B * M * K > 0) return TSAMD_ERR_INVALID;
+  if (arg32) arg_out = reinterpret_cast<const int64_t *>(arg_any);  // (never dereferenced at this width below)
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (dtype != TSAMD_F32 && dtype != TSAMD_F64 && dtype != TSAMD_F16 && dtype != TSAMD_BF16)
     return TSAMD_ERR_UNSUPPORTED;
@@ -749,6 +930,7 @@ extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const 
   if (grad_mat && E > 0 && (!colptr || !csr2csc || !row)) return TSAMD_ERR_INVALID;
   const size_t es = dtype_size(dtype);
   if (grad_mat && total > 0 && E > 0 && B * N * K > 0 && use_lists(dtype, B, M, N, K, E)) {
+    if (arg32) return TSAMD_ERR_UNSUPPORTED;  // the (opt-in) list route reads int64 ids: the caller widens them
     if (!workspace || workspace_bytes < minmax_bw_lists_workspace_bytes(dtype, B, M, N, K, E) ||
         (uintptr_t)workspace % 256 != 0)
       return TSAMD_ERR_WORKSPACE;
@@ -764,6 +946,7 @@ extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const 
   const bool sddmm_ok = grad_value && row && (K * (int64_t)es) % 16 == 0 && ((uintptr_t)mat % 16) == 0 &&
                         ((uintptr_t)grad_out % 16) == 0;
   if (grad_value && !(sddmm_ok && grad_mat)) {
+    if (arg32) return TSAMD_ERR_UNSUPPORTED;  // the row-parallel kernel reads int64 ids: the caller widens them
     int st = tsamd_spmm_minmax_bw(dtype, rowptr, col, value, mat, grad_out, arg_out, grad_value, nullptr, B, M, N,
                                   K, E, nullptr, 0, stream_);
     if (st != TSAMD_OK) return st;
@@ -785,8 +968,14 @@ extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const 
     if constexpr (std::is_integral<scalar_t>::value) {
       return (int)TSAMD_ERR_UNSUPPORTED;
     } else {
-      hipLaunchKernelGGL((minmax_winrec_kernel<scalar_t>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, stream,
-                         row, reinterpret_cast<const scalar_t *>(value), arg_out, rec, B, M, (uint32_t)K, E, W, S);
+      if (arg32)
+        hipLaunchKernelGGL((minmax_winrec_kernel<scalar_t, int32_t>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0,
+                           stream, row, reinterpret_cast<const scalar_t *>(value),
+                           reinterpret_cast<const int32_t *>(arg_any), rec, B, M, (uint32_t)K, E, W, S);
+      else
+        hipLaunchKernelGGL((minmax_winrec_kernel<scalar_t, int64_t>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0,
+                           stream, row, reinterpret_cast<const scalar_t *>(value), arg_out, rec, B, M, (uint32_t)K, E,
+                           W, S);
       TSAMD_LAUNCH_CHECK();
       if (grad_value && sddmm_ok)
         return launch_value_bw_masked<scalar_t>(row, rowptr, col, reinterpret_cast<const scalar_t *>(mat),
@@ -799,4 +988,25 @@ extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const 
   // grad_mat = masked (A^T) * grad_out: rows of A^T = columns of A, entries through csr2csc
   return spmm_masked_sum(dtype, colptr, value != nullptr, csr2csc, rec, grad_out, grad_mat, B, N, M, K, E,
                          reinterpret_cast<char *>(workspace) + rec_b, workspace_bytes - rec_b, stream);
+}
+
+extern "C" int tsamd_spmm_minmax_bw_csc(int dtype, const int64_t *rowptr, const int64_t *col,
+                                        const void *value, const void *mat, const void *grad_out,
+                                        const int64_t *arg_out, const int64_t *colptr,
+                                        const int64_t *csr2csc, const int64_t *row, void *grad_value,
+                                        void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
+                                        int64_t E, void *workspace, size_t workspace_bytes, void *stream_) {
+  return minmax_bw_csc_impl(dtype, rowptr, col, value, mat, grad_out, arg_out, false, colptr, csr2csc, row,
+                            grad_value, grad_mat, B, M, N, K, E, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int tsamd_spmm_minmax_bw_csc_arg32(int dtype, const int64_t *rowptr, const int64_t *col,
+                                              const void *value, const void *mat, const void *grad_out,
+                                              const int32_t *arg_out32, const int64_t *colptr,
+                                              const int64_t *csr2csc, const int64_t *row, void *grad_value,
+                                              void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
+                                              int64_t E, void *workspace, size_t workspace_bytes, void *stream_) {
+  if (E >= (int64_t)1 << 31) return TSAMD_ERR_UNSUPPORTED;
+  return minmax_bw_csc_impl(dtype, rowptr, col, value, mat, grad_out, arg_out32, true, colptr, csr2csc, row,
+                            grad_value, grad_mat, B, M, N, K, E, workspace, workspace_bytes, stream_);
 }

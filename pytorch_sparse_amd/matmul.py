@@ -36,7 +36,7 @@ def spmm_max(src: SparseTensor, other: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 def spmm(src: SparseTensor, other: Tensor, reduce: str = 'sum') -> Tensor:
-    return storage_spmm(src.storage, other, reduce)[0]
+    return storage_spmm(src.storage, other, reduce, False)[0]
 
 
 def spspmm_sum(src: SparseTensor, other: SparseTensor) -> SparseTensor:

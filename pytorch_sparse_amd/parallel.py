@@ -602,7 +602,10 @@ class PipelinedHaloSpMM(object):
 
     def __init__(self, rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
                  group=None, spmm_fn: Optional[Callable] = None, chunks: int = 4,
-                 spmm_into_fn: Optional[Callable] = None):
+                 spmm_into_fn: Optional[Callable] = None, agree: str = 'always'):
+        assert agree in ('always', 'once')
+        self.agree = agree      # how the ranks settle the autograd path of a call (see __call__)
+        self.agreements = 0     # collectives spent on it so far
         self.group = group
         # with the product kernels the pieces write into one preallocated result (no torch.cat); an
         # injected spmm_fn (CPU tests) gets the concatenating path unless it brings its own writer
@@ -668,25 +671,30 @@ class PipelinedHaloSpMM(object):
     def __call__(self, x_local: Tensor, reduce: str = 'sum', differentiable: Optional[bool] = None) -> Tensor:
         """`differentiable`: take the autograd-recording path (its backward issues collectives, so EVERY rank
         must take the same path).  None (default) = any rank needs a gradient: the local verdict (grad mode,
-        requires_grad of X / the values) is agreed on with one all_reduce the FIRST time this plan sees a local
-        state and remembered per state (`_agreed`), so that a rank whose inputs happen not to require grad cannot
-        leave its peers waiting in a backward collective and later calls pay neither the collective nor the
-        read-back.  Ranks that change state out of step with each other must pass True / False explicitly."""
+        requires_grad of X / the values) is agreed on with one all_reduce, so that a rank whose inputs happen not
+        to require grad cannot leave its peers waiting in a backward collective.  ``agree='always'`` (default)
+        does that on EVERY call -- correct for any program, at the price of a collective and a read-back in front
+        of the pipelined exchange.  ``agree='once'`` does it the first time the plan sees a local state and
+        remembers the verdict per state: only for SPMD programs whose ranks change grad mode / requires_grad in
+        lockstep (a rank that meets a new state alone would pair its all_reduce with its peers' next all_to_all).
+        Loops that know their path pass True / False and pay nothing (bench.py does)."""
         if self.world == 1:
             p = self.pieces[0]
             return self.spmm_fn(p['rowptr'], p['col'], p['value'], x_local, reduce)
         if differentiable is None:
             needs_grad = torch.is_grad_enabled() and (
                 x_local.requires_grad or any(p['value'] is not None and p['value'].requires_grad for p in self.pieces))
-            # the agreement (a collective + a read-back, which would serialise the pipelined exchange) is made ONCE
-            # per local state and remembered: ranks of an SPMD program change grad mode / requires_grad in lockstep
+            # agree == 'once': the agreement (a collective + a read-back, which serialise the pipelined exchange) is
+            # made once per local state and remembered
             key = (torch.is_grad_enabled(), needs_grad)
-            verdict = self._agreed.get(key)
+            verdict = self._agreed.get(key) if self.agree == 'once' else None
             if verdict is None:
                 flag = torch.tensor([1 if needs_grad else 0], dtype=torch.int32, device=x_local.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                self.agreements += 1
                 verdict = bool(int(flag))
-                self._agreed[key] = verdict
+                if self.agree == 'once':
+                    self._agreed[key] = verdict
             differentiable = verdict
         if differentiable:
             return self._differentiable(x_local, reduce)

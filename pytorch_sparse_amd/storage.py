@@ -95,6 +95,11 @@ class SparseStorage(object):
         assert col.dim() == 1, 'col must be 1-D'
         col = col.contiguous()
         nnz = col.numel()
+        if value is not None:  # before anything (the sort below) hands `value` to a kernel under col's device guard
+            assert value.device == col.device
+            assert value.size(0) == nnz
+        if row is not None:
+            assert row.device == col.device
 
         # sizes: given, or inferred.  On the GPU everything the constructor may have to read back -- the order
         # probe of sort-on-construct and the two maxima of the range check / size inference -- comes from ONE

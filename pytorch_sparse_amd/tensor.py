@@ -20,7 +20,8 @@ from torch import Tensor
 from .storage import SparseStorage, get_layout
 
 
-def storage_spmm(st: SparseStorage, other: Tensor, reduce: str) -> Tuple[Tensor, Optional[Tensor]]:
+def storage_spmm(st: SparseStorage, other: Tensor, reduce: str,
+                 want_arg: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
     """``A @ other`` on a storage -> (out, arg_out for min / max).  Collects the cached arrays the
     reference front-end hands to its ops (torch_sparse/matmul.py:12-28, 38-56, 60-77): the CSC-side
     caches are only filled when a gradient w.r.t. `other` will be asked for."""
@@ -28,21 +29,31 @@ def storage_spmm(st: SparseStorage, other: Tensor, reduce: str) -> Tuple[Tensor,
     if value is not None:
         value = value.to(other.dtype)
     if reduce == 'min' or reduce == 'max':
-        # the CSC arrays (a radix sort on first use) are only built when the pull backward will really run:
-        # a gradient w.r.t. `other` is being recorded, and either the values need none, or deterministic
-        # algorithms are asked for, or the rows are 2-byte types of >= 128 features -- there the pull (winner
-        # records + masked SDDMM + masked sum that skips segments without winners) beats the fused scatter
-        # kernel also WITH grad_value since round 4 (configs[2]: 2.38 vs 2.54 ms; fp32 F = 128: 3.30 vs 2.97,
-        # bf16 F = 64: 1.98 vs 1.33 -- those keep the scatter; profiles/r04_minmax_bw_wave_skip.log)
+        # The CSC arrays (a radix sort on first use) are only built when the pull backward will really run: a
+        # gradient w.r.t. `other` is being recorded and the rows are wide enough for the pull (winner records +
+        # masked sum that skips segments without winners [+ masked SDDMM for grad_value]) to beat the scatter kernel
+        # (packed atomics, grad_value fused), or deterministic algorithms are asked for.  Same-box table, 2^20-row
+        # R-MAT graph, ms pull / scatter (profiles/r05_minmax_bw_route_rule.md):
+        #   value-less   bf16 K = 32: 1.52 / 0.77   64: 1.28 / 1.42   128: 1.37 / 2.47   256: 2.27 / 4.19
+        #                fp32 K = 32: 1.57 / 0.93   64: 1.32 / 1.70   128: 1.60 / 2.83   256: 2.81 / 5.30
+        #   + grad_value bf16 K = 32: 1.71 / 1.47   64: 1.52 / 1.57   128: 1.81 / 2.5-2.9  256: 2.96 / 4.76
+        #                fp32 K = 32: 1.77 / 1.66   64: 1.69 / 1.85   128: 2.22 / 2.97   256: 3.87 / 5.90
+        # (f16 K = 64 with grad_value: 1.66 / 1.34 -- two-byte rows take the pull from 128 features on.)
         pull = other.requires_grad and torch.is_grad_enabled()
-        if pull and value is not None and value.requires_grad:
+        if pull and not torch.ops.tsamd.deterministic():
+            k = other.size(-1)
             narrow = other.dtype == torch.bfloat16 or other.dtype == torch.float16
-            pull = torch.ops.tsamd.deterministic() or (narrow and other.size(-1) >= 128)
+            if value is not None and value.requires_grad and narrow:
+                pull = k >= 128
+            else:
+                pull = k >= 64
         if pull:
             # training: hand the CSC arrays over (cached in the storage, as for sum) so that grad_mat is
             # pulled column by column instead of scattered with atomics (tsamd_spmm_minmax_bw_csc)
+            # want_arg False (matmul / spmm return `out` alone): the winners stay inside the autograd node, as
+            # 32-bit ids -- half the bytes in the forward's store and in the backward's read (include/tsamd.h)
             out, arg = torch.ops.tsamd.spmm_minmax(rowptr, col, value, st.colptr(), st.csr2csc(), st.row(),
-                                                   other, reduce == 'max')
+                                                   other, reduce == 'max', not want_arg)
             return out, arg
         if reduce == 'min':
             out, arg = torch.ops.torch_sparse.spmm_min(rowptr, col, value, other)
@@ -189,10 +200,10 @@ class SparseTensor(object):
     # ---- products (dense operand; the Python-level ``matmul`` / ``@`` attached by matmul.py also take a
     #      SparseTensor) -- real methods, so that scripted code can call ``adj.matmul(x, reduce)`` ------
     def spmm(self, other: Tensor, reduce: str = 'sum') -> Tensor:
-        return storage_spmm(self.storage, other, reduce)[0]
+        return storage_spmm(self.storage, other, reduce, False)[0]
 
     def matmul(self, other: Tensor, reduce: str = 'sum') -> Tensor:
-        return storage_spmm(self.storage, other, reduce)[0]
+        return storage_spmm(self.storage, other, reduce, False)[0]
 
     # ---- sizes -------------------------------------------------------------------------------
     def sparse_sizes(self) -> Tuple[int, int]:

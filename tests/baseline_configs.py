@@ -410,6 +410,26 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     finally:
         torch.use_deterministic_algorithms(False)
     same_as_op = bool(torch.equal(xr.grad.view(torch.int16), gmat.view(torch.int16)))
+    # the drop-in training step, as a caller of the reference writes it: adj.matmul(x, 'max') and .backward(g).  Since
+    # round 5 the node keeps its winners as int32 ids (tsamd_spmm_minmax_arg32) and takes the pull with grad_value too
+    xt = x.clone().requires_grad_()
+
+    def train_fw():
+        return A.matmul(xt, 'max')
+
+    def train_step():
+        xt.grad = None
+        if vr is not None:
+            vr.grad = None
+        A.matmul(xt, 'max').backward(g)
+
+    with operand_cache(False):
+        train_fw_ms = gpu_ms(train_fw, iters=iters)
+        train_step_ms = gpu_ms(train_step, iters=iters)
+    train_step()
+    train_same = bool(torch.equal(xt.grad.view(torch.int16), gmat.view(torch.int16)))
+    if vr is not None:
+        train_same = train_same and bool(torch.equal(vr.grad.view(torch.int16), gval.view(torch.int16)))
     # ... and the bare reference op (no CSC arrays) the scatter route
     xr2 = x.clone().requires_grad_()
     o3, _ = op(rp, c, v, xr2)
@@ -420,6 +440,7 @@ def run_c3(dev, has_value, cpu=True, iters=10):
                workload='configs[2]: CSR SpMM-max + backward, 2^20 R-MAT (E=%d), F=128 bf16, %s' % (
                    E, 'with values' if has_value else 'value-less'),
                dtype='bf16', fw_ms=round(fw_ms, 4), fw_ms_back_to_back=round(fw_b2b, 4), bw_ms=round(bw_ms, 4), gedges_per_s_fw=round(E / fw_ms / 1e6, 3),
+               matmul_fw_ms=round(train_fw_ms, 4), matmul_fw_bw_ms=round(train_step_ms, 4),
                roofline=dict(bound='hbm', algorithmic_bytes=ba_fw, achieved=round(ba_fw / fw_ms / 1e6, 1),
                              peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ba_fw / fw_ms / 1e6 / HBM_PEAK_GBS, 4),
                              scope='forward, whole op', **pmc_traffic('c3_max_fw_bf16_F128', 'spmm_merge_kernel')),
@@ -447,6 +468,7 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     par['grad_mat_bare_op_autograd_max_err_over_bound'] = float(((xr2.grad.double() - exact).abs() / bound).max())
     par['grad_mat_pull_deterministic'] = deterministic
     par['grad_mat_autograd_bit_identical_to_c_abi'] = same_as_op
+    par['matmul_step_int32_ids_bit_identical_to_c_abi'] = train_same
     del exact, bound, err
     if has_value:
         invalid = arg == E
@@ -475,6 +497,7 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     par['ok'] = bool(par.get('arg_out_mismatches', 0) == 0 and par.get('out_bit_mismatches', 0) == 0 and
                      par['grad_mat_max_err_over_bound'] <= 1.0 and par['grad_mat_autograd_equal_bound'] <= 1.0 and
                      par['grad_mat_atomic_route_max_err_over_bound'] <= 1.0 and deterministic and same_as_op and
+                     train_same and
                      par['grad_mat_bare_op_autograd_max_err_over_bound'] <= 1.0 and
                      par.get('grad_value_max_err_over_bound', 0.0) <= 1.0 and
                      par.get('grad_value_autograd_max_err_over_bound', 0.0) <= 1.0)

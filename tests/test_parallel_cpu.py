@@ -79,8 +79,15 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
                 continue
             out_local = op(x_local, reduce)
             res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]))
-        if hasattr(op, '_agreed'):  # pipelined halo: the four calls above shared ONE agreement on the autograd path
-            assert len(op._agreed) == 1 and list(op._agreed.values()) == [False], op._agreed
+        if hasattr(op, '_agreed'):  # pipelined halo: by default every call settles its autograd path with one collective;
+            assert op.agree == 'always' and op.agreements == 4 and not op._agreed  # agree='once' remembers it per state
+            op.agree = 'once'
+            for _ in range(3):
+                assert np.array_equal(op(x_local, 'sum').numpy(), oc.spmm(oc.F32, 'sum', rp.numpy(), c.numpy(), v.numpy(),
+                                                                            x.numpy())[0][s:e])
+            assert op.agreements == 5 and list(op._agreed.values()) == [False], (op.agreements, op._agreed)
+            op.agree = 'always'
+
         # backward: the gradient of x is a partial sum on every rank and has to reach the owning rank
         # (reduce-scatter / reverse all_to_all), for sum and -- across ranks -- for min / max; the value
         # gradient is local

@@ -353,6 +353,103 @@ def test_minmax_bw_csc_pull(dev, dtype, reduce, pull_route):
                 assert bits_equal(vr.grad, gv)
 
 
+@pytest.mark.parametrize('dtype', FLOAT_DTYPES)
+def test_minmax_arg32_forward_and_pull(dev, dtype):
+    """tsamd_spmm_minmax_arg32 / tsamd_spmm_minmax_bw_csc_arg32 (the ids SparseTensor.matmul keeps for its own backward):
+    the int32 ids equal the API's int64 arg_out, `out` is bit-identical, and the pull on them gives the same bits as on
+    the int64 ids; every packet width of the forward (K = 1, 2, 6, 64, 128), cut rows, batches, empty rows."""
+    rp, c = synth.rmat_csr(10, 16, seed=2)  # max degree > 128-item partitions => cut rows (fix-up kernel)
+    n, E = 1 << 10, c.numel()
+    colptr, perm, row = _csc_arrays(rp, c, n)
+    for reduce in ('min', 'max'):
+        for K, batch, has_value in ((1, (), True), (2, (), False), (6, (2, ), True), (64, (), True), (128, (), False),
+                                    (128, (2, ), True)):
+            v, x = make_inputs(rp, c, n, K, dtype, has_value, batch)
+            vd = None if v is None else v.to(dev)
+            out, arg = run_gpu(dev, rp, c, v, x, reduce)
+            out32, arg32 = nat.spmm_minmax_arg32(rp.to(dev), c.to(dev), vd, x.to(dev), reduce)
+            assert arg32.dtype == torch.int32 and bits_equal(out, out32), (reduce, K)
+            assert torch.equal(arg32.long(), arg), (reduce, K)
+            gout = synth.features(n, K, seed=9, dtype=dtype, batch=batch).to(dev)
+            sddmm = has_value and (K * x.element_size()) % 16 == 0
+            a = (rp.to(dev), c.to(dev), vd, x.to(dev), gout)
+            b = (colptr.to(dev), perm.to(dev), row.to(dev))
+            gv, gm = nat.spmm_minmax_bw_csc(*a, arg, *b, want_value=sddmm, want_mat=True)
+            gv32, gm32 = nat.spmm_minmax_bw_csc(*a, arg32, *b, want_value=sddmm, want_mat=True)
+            assert bits_equal(gm, gm32), (reduce, K)
+            if sddmm:
+                assert bits_equal(gv, gv32), (reduce, K)
+    # rows that are not 16-byte packets + grad_value: the int32 entry says so (the torch glue then widens the ids)
+    v, x = make_inputs(rp, c, n, 6, dtype, True, ())
+    out32, arg32 = nat.spmm_minmax_arg32(rp.to(dev), c.to(dev), v.to(dev), x.to(dev), 'max')
+    gout = synth.features(n, 6, seed=9, dtype=dtype).to(dev)
+    if (6 * x.element_size()) % 16 != 0:
+        with pytest.raises(nat.TsamdError):
+            nat.spmm_minmax_bw_csc(rp.to(dev), c.to(dev), v.to(dev), x.to(dev), gout, arg32, colptr.to(dev),
+                                   perm.to(dev), row.to(dev), want_value=True, want_mat=True)
+
+
+@pytest.mark.parametrize('dtype', FLOAT_DTYPES)
+def test_masked_sddmm_pipelined_against_round4_kernel(dev, dtype):
+    """grad_value of the pull backward: the pipelined masked SDDMM (record words of 8 steps in one round trip, the
+    gathers of two steps in flight, v_dot2c for 2-byte types) against the round-4 kernel (TSAMD_MASKED_SDDMM_PIPE=0)
+    for every lane-group width (1 ... 64 packets per row, also counts that are not powers of two), batches, a chunk
+    that ends inside a wave (E % 64 != 0), and against the fp64 formula."""
+    import os
+    rp, c = synth.rmat_csr(10, 12, seed=4)
+    n, E = 1 << 10, c.numel()
+    assert E % 64 != 0
+    colptr, perm, row = _csc_arrays(rp, c, n)
+    vec = 16 // torch.empty(0, dtype=dtype).element_size()
+    u = {torch.float32: 2.0 ** -24, torch.float64: 2.0 ** -53, torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
+    for slots, batch in ((1, ()), (2, (2, )), (3, ()), (4, ()), (8, ()), (16, ()), (24, ()), (32, (2, )), (64, ())):
+        K = slots * vec
+        v, x = make_inputs(rp, c, n, K, dtype, True, batch)
+        gout = synth.features(n, K, seed=9, dtype=dtype, batch=batch)
+        out, arg = run_gpu(dev, rp, c, v, x, 'max')
+        args = (rp.to(dev), c.to(dev), v.to(dev), x.to(dev), gout.to(dev), arg, colptr.to(dev), perm.to(dev), row.to(dev))
+        gv, gm = nat.spmm_minmax_bw_csc(*args, want_value=True, want_mat=True)
+        os.environ['TSAMD_MASKED_SDDMM_PIPE'] = '0'
+        try:
+            gv_old, gm_old = nat.spmm_minmax_bw_csc(*args, want_value=True, want_mat=True)
+        finally:
+            os.environ.pop('TSAMD_MASKED_SDDMM_PIPE', None)
+        assert bits_equal(gm, gm_old)
+        egv, _ = oc.spmm_minmax_bw(oc.F64, c.numpy(), v.double().numpy(), x.double().numpy(), gout.double().numpy(),
+                                   arg.cpu().numpy(), want_value=True)
+        l1, _ = oc.spmm_minmax_bw(oc.F64, c.numpy(), v.double().numpy(), x.double().abs().numpy(),
+                                  gout.double().abs().numpy(), arg.cpu().numpy(), want_value=True)
+        acc_u = 2.0 ** -53 if dtype == torch.float64 else 2.0 ** -24
+        bound = (K * len(batch or (1, )) * 2 + 2) * acc_u * l1 + u * np.abs(egv) * 1.01 + 1e-30
+        for got in (gv, gv_old):
+            err = np.abs(got.cpu().double().numpy() - egv)
+            assert (err <= bound).all(), (slots, batch, float((err / bound).max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+def test_masked_sddmm_non_winners_contribute_nothing(dev, dtype):
+    """An Inf (or NaN) of grad_out in a feature an entry did NOT win must not reach that entry's grad_value (the
+    reference only ever touches the winner, spmm.cpp:222-231): the dot2 form masks BOTH operands."""
+    K = 16
+    rp = torch.tensor([0, 2])
+    c = torch.tensor([0, 1])
+    x = torch.ones(2, K, dtype=dtype)
+    x[0, 1::2] = 9.0   # entry 0 wins the odd features, entry 1 the even ones
+    x[1, 0::2] = 5.0
+    g = torch.full((1, K), 0.5, dtype=dtype)
+    g[0, 0] = float('inf')
+    g[0, 2] = float('nan')
+    v = torch.tensor([1.0, 1.0], dtype=dtype)
+    colptr, perm, row = _csc_arrays(rp, c, 2)
+    out, arg = nat.spmm(rp.to(dev), c.to(dev), v.to(dev), x.to(dev), 'max')
+    assert arg[0, 0].item() == 1 and arg[0, 1].item() == 0
+    gv, gm = nat.spmm_minmax_bw_csc(rp.to(dev), c.to(dev), v.to(dev), x.to(dev), g.to(dev), arg, colptr.to(dev),
+                                    perm.to(dev), row.to(dev), want_value=True, want_mat=True)
+    gv = gv.float().cpu()
+    assert torch.isfinite(gv[0]) and abs(float(gv[0]) - 9.0 * 0.5 * (K // 2)) < 0.26, gv  # 8 odd features
+    assert not torch.isfinite(gv[1])  # entry 1 did win the Inf / NaN features
+
+
 def test_minmax_bw_csc_no_winner_and_empty(dev):
     """Rows without entries and elements without a winner (arg == E) contribute nothing; columns without
     entries get zeros (every element of grad_mat is written)."""
