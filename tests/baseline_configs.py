@@ -401,8 +401,8 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     deterministic = bool(torch.equal(bw()[1].view(torch.int16), gmat.view(torch.int16)))
     # autograd wiring of the drop-in front-end: adj.matmul(x, 'max').backward(g) takes the pull route
     xr = x.clone().requires_grad_()
-    # grad_value too: the pull only on request (deterministic algorithms, asked for BEFORE the forward: that is when
-    # the front-end decides whether to build and hand over the CSC arrays), else the fused scatter
+    # (128 two-byte features: the front-end takes the pull with and without grad_value; asking for deterministic
+    # algorithms -- BEFORE the forward, when the CSC arrays are handed over -- pins it whatever the rule says)
     torch.use_deterministic_algorithms(has_value)
     try:
         o2 = A.matmul(xr, 'max')

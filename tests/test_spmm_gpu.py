@@ -338,10 +338,10 @@ def test_minmax_bw_csc_pull(dev, dtype, reduce, pull_route):
             vr = None if v is None else v.to(dev).requires_grad_()
             A = ts.SparseTensor(rowptr=rp.to(dev), col=c.to(dev), value=vr, sparse_sizes=(n, n), is_sorted=True,
                                 trust_data=True)
-            # grad_mat alone always takes the pull; with grad_value as well only when reproducible gradients are asked
-            # for -- before the forward, which is when the front-end builds and hands over the CSC arrays (the scatter
-            # kernel gets grad_value fused: ops_spmm.cpp)
-            torch.use_deterministic_algorithms(has_value)
+            # the front-end takes the pull for rows of >= 64 features (>= 128 for 2-byte rows with grad_value) and
+            # whenever reproducible gradients are asked for -- BEFORE the forward, which is when it builds and hands
+            # over the CSC arrays (test_minmax_backward_route_rule pins the rule itself)
+            torch.use_deterministic_algorithms(True)
             try:
                 o = A.matmul(xr, reduce)
                 o.backward(gout.to(dev))
@@ -448,6 +448,49 @@ def test_masked_sddmm_non_winners_contribute_nothing(dev, dtype):
     gv = gv.float().cpu()
     assert torch.isfinite(gv[0]) and abs(float(gv[0]) - 9.0 * 0.5 * (K // 2)) < 0.26, gv  # 8 odd features
     assert not torch.isfinite(gv[1])  # entry 1 did win the Inf / NaN features
+
+
+def test_minmax_backward_route_rule(dev):
+    """Which backward SparseTensor.matmul(x, 'max') prepares (pytorch_sparse_amd/tensor.py: storage_spmm, table in
+    profiles/r05_minmax_bw_route_rule.md): the pull needs the CSC arrays, so a storage that has them after the forward
+    took it.  Either way the gradient stays within the scatter kernel's bound of the fp64 formulas."""
+    import pytorch_sparse_amd as ts
+    rp, c = synth.rmat_csr(9, 10, seed=6)
+    n = 1 << 9
+    for dtype, K, with_value, det, want_pull in ((torch.float32, 32, False, False, False),
+                                                 (torch.float32, 64, False, False, True),
+                                                 (torch.bfloat16, 64, False, False, True),
+                                                 (torch.bfloat16, 64, True, False, False),
+                                                 (torch.bfloat16, 128, True, False, True),
+                                                 (torch.float32, 64, True, False, True),
+                                                 (torch.float32, 16, True, True, True)):
+        v, x = make_inputs(rp, c, n, K, dtype, True)
+        xr = x.to(dev).requires_grad_()
+        vr = v.to(dev).requires_grad_(with_value)
+        A = ts.SparseTensor(rowptr=rp.to(dev), col=c.to(dev), value=vr, sparse_sizes=(n, n), is_sorted=True,
+                            trust_data=True)
+        gout = synth.features(n, K, seed=9, dtype=dtype)
+        torch.use_deterministic_algorithms(det)
+        try:
+            o = A.matmul(xr, 'max')
+            assert A.storage.has_csr2csc() == want_pull, (dtype, K, with_value, det)
+            o.backward(gout.to(dev))
+        finally:
+            torch.use_deterministic_algorithms(False)
+        arg = nat.spmm(rp.to(dev), c.to(dev), v.to(dev), x.to(dev), 'max')[1]
+        egv, egm = oc.spmm_minmax_bw(oc.F64, c.numpy(), v.double().numpy(), x.double().numpy(), gout.double().numpy(),
+                                     arg.cpu().numpy(), want_value=True)
+        _, l1 = oc.spmm_minmax_bw(oc.F64, c.numpy(), v.double().abs().numpy(), x.double().numpy(),
+                                  gout.double().abs().numpy(), arg.cpu().numpy(), want_value=False)
+        _, cnt = oc.spmm_minmax_bw(oc.F64, c.numpy(), None, x.double().numpy(), np.ones_like(gout.double().numpy()),
+                                   arg.cpu().numpy(), want_value=False)
+        u = 2.0 ** -24 if dtype == torch.float32 else 2.0 ** -8
+        bound = (cnt + 2) * u * l1 * 1.01 + 1e-30
+        err = np.abs(xr.grad.cpu().double().numpy() - egm)
+        assert (err <= bound).all(), (dtype, K, float((err / bound).max()))
+        if with_value:
+            tol = 1e-5 if dtype == torch.float32 else 3e-2
+            assert np.allclose(vr.grad.cpu().double().numpy(), egv, rtol=tol, atol=tol * max(1.0, float(np.abs(egv).max())))
 
 
 def test_minmax_bw_csc_no_winner_and_empty(dev):
