@@ -15,11 +15,31 @@ from .segment import segment_reduce
 _OPS = ('add', 'sum', 'mean', 'min', 'max')
 
 
-def sorted_unique(row: Tensor, col: Tensor, m: int, n: int):
-    """-> (row_u, col_u, perm or None, seg_ptr or None, nnz_u): the distinct (row, col) pairs in
-    row-major order plus what is needed to reduce the values of duplicates.  seg_ptr is None when
-    the input had no duplicates (then perm alone reorders the values)."""
+def _rides(value: Optional[Tensor], nnz: int) -> bool:
+    """Plain 4- / 8-byte numbers without a gradient travel with their entries through the sort (4-byte ones through
+    every pass, 8-byte ones gathered by the last pass: csrc/sort.hip) instead of being read through the permutation."""
+    return (value is not None and value.dim() == 1 and value.size(0) == nnz and value.is_cuda and
+            value.element_size() in (4, 8) and not value.requires_grad and not value.is_complex())
+
+
+def sorted_unique(row: Tensor, col: Tensor, m: int, n: int, value: Optional[Tensor] = None):
+    """-> (row_u, col_u, perm or None, seg_ptr or None, nnz_u[, value in sorted order or None]): the distinct
+    (row, col) pairs in row-major order plus what is needed to reduce the values of duplicates.  seg_ptr is None
+    when the input had no duplicates (then perm alone reorders the values).  With `value` (see _rides) the sixth
+    result holds the values in sorted order (perm then need not be applied to them)."""
     nnz = col.numel()
+    if value is not None:
+        if nnz <= 1 or not _rides(value, nnz):
+            return sorted_unique(row, col, m, n) + (None, )
+        row_s, col_s, perm, counts, value_s = torch.ops.tsamd.sort_coo_values(row, col, m, n, 1, None, value)
+        row_u, col_u, seg_ptr, n_dev = torch.ops.tsamd.coalesce_index(row_s, col_s)
+        descents, n_u = torch.cat([counts[:1], n_dev]).tolist()  # the one host sync
+        perm_opt: Optional[Tensor] = perm if descents > 0 else None
+        if descents == 0:
+            row_s, col_s, value_s = row, col, value
+        if n_u == nnz:
+            return row_s, col_s, perm_opt, None, nnz, value_s
+        return row_u[:n_u], col_u[:n_u], perm_opt, seg_ptr, n_u, value_s
     if nnz <= 1:
         return row, col, None, None, nnz
     # everything is enqueued without looking at the data -- order probe, a radix sort that returns at once when
@@ -42,8 +62,13 @@ def coalesce(index: Tensor, value: Optional[Tensor], m: int, n: int,
     ([nnz, *], any supported dtype) with `op` in add | sum | mean | min | max."""
     if op not in _OPS:
         raise ValueError(op)
-    row, col, perm, seg_ptr, n_u = sorted_unique(index[0], index[1], m, n)
-    if value is not None:
+    row, col, perm, seg_ptr, n_u, value_s = sorted_unique(index[0], index[1], m, n, value) if value is not None else (
+        sorted_unique(index[0], index[1], m, n) + (None, ))
+    if value_s is not None:  # the values came out of the sort in order: a streamed reduction, no gather
+        value = value_s
+        if seg_ptr is not None:
+            value = segment_reduce(value_s, None, seg_ptr, n_u, op, balanced=index.size(1) > 8 * max(n_u, 1))
+    elif value is not None:
         if seg_ptr is not None:
             # differentiable, like segment_csr; long runs of duplicates go the entry-balanced way
             value = segment_reduce(value, perm, seg_ptr, n_u, op, balanced=index.size(1) > 8 * max(n_u, 1))

@@ -29,6 +29,8 @@
 #include "common.h"
 #include "sort.h"
 
+#include <cstdlib>
+
 namespace tsamd {
 namespace {
 
@@ -43,8 +45,10 @@ constexpr int kSortThreads = 256;
 #ifndef TSAMD_SORT_ITEMS_PAIRS
 #define TSAMD_SORT_ITEMS_PAIRS 24
 #endif
-template <bool PACKED>
-constexpr int kItemsOf = PACKED ? TSAMD_SORT_ITEMS : TSAMD_SORT_ITEMS_PAIRS;
+// (a 32-bit payload beside the words -- the position of pairs mode, or a 4-byte VALUE riding along with packed words,
+// round 5 -- makes an entry 12 bytes in LDS)
+template <bool PACKED, bool VAL = false>
+constexpr int kItemsOf = (PACKED && !VAL) ? TSAMD_SORT_ITEMS : TSAMD_SORT_ITEMS_PAIRS;
 constexpr int kMinTile = kSortThreads * (TSAMD_SORT_ITEMS < TSAMD_SORT_ITEMS_PAIRS ? TSAMD_SORT_ITEMS : TSAMD_SORT_ITEMS_PAIRS);
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
@@ -220,7 +224,11 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
 // ---------------------------------------------------------------------------
 // one pass = one kernel
 // ---------------------------------------------------------------------------
-template <bool PACKED, bool LAST>
+// VAL (packed words only, round 5): a 4-byte value rides along with its entry through EVERY pass as a 32-bit payload --
+// the first pass reads it in input order (`gather_src[e]`: the entry at position e of the first pass IS entry e), the
+// last pass stores it next to the decoded ids -- instead of being gathered through the permutation by the last pass
+// (7.5 M random 4-byte reads: +125 us, against +12 bytes per entry and pass of streamed traffic).
+template <bool PACKED, bool LAST, bool VAL = false>
 __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
     const unsigned long long *__restrict__ in, const unsigned int *__restrict__ idx_in,
     unsigned long long *__restrict__ out, unsigned int *__restrict__ idx_out, int64_t *__restrict__ row_out,
@@ -229,7 +237,9 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
     unsigned long long *__restrict__ hdr, unsigned int epoch, const int64_t *__restrict__ todo,
     const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t *__restrict__ counts_out,
     const void *__restrict__ gather_src, void *__restrict__ gather_dst, int gather_bytes, int check4) {
-  constexpr int kSortItems = kItemsOf<PACKED>;
+  static_assert(!VAL || PACKED, "a riding value needs the position inside the word");
+  constexpr bool kPayload = !PACKED || VAL;  // a 32-bit word travels beside the 64-bit one
+  constexpr int kSortItems = kItemsOf<PACKED, VAL>;
   constexpr int kSortTile = kSortThreads * kSortItems;
   if constexpr (LAST) {  // the probe's counters travel with the last pass (no separate kernel)
     if (counts_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
     return;
   }
   __shared__ unsigned long long sword[kSortTile];
-  __shared__ unsigned int sidx[PACKED ? 1 : kSortTile];
+  __shared__ unsigned int sidx[kPayload ? kSortTile : 1];
   __shared__ unsigned int cnt[4][kRadix];
   __shared__ unsigned int dig_off[kRadix];
   __shared__ long long goff[kRadix];
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
   const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
 
   unsigned long long word[kSortItems];
-  unsigned int idx[PACKED ? 1 : kSortItems];
+  unsigned int idx[kPayload ? kSortItems : 1];
   unsigned int dig[kSortItems], lrank[kSortItems];
   bool valid[kSortItems];
 #pragma unroll
@@ -289,7 +299,8 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
     const int64_t e = base + i * 64 + lane;
     valid[i] = e < n;
     word[i] = valid[i] ? in[e] : 0ull;
-    if constexpr (!PACKED) idx[i] = valid[i] ? (idx_in ? idx_in[e] : (unsigned int)e) : 0u;
+    if constexpr (VAL) idx[i] = valid[i] ? (idx_in ? idx_in[e] : reinterpret_cast<const uint32_t *>(gather_src)[e]) : 0u;
+    else if constexpr (!PACKED) idx[i] = valid[i] ? (idx_in ? idx_in[e] : (unsigned int)e) : 0u;
     dig[i] = (unsigned int)(word[i] >> shift) & (kRadix - 1);
   }
   // rank of every entry among the equal digits of its wave, in input order
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
     if (valid[i]) {
       const unsigned int pos = dig_off[dig[i]] + cnt[w][dig[i]] + lrank[i];
       sword[pos] = word[i];
-      if constexpr (!PACKED) sidx[pos] = idx[i];
+      if constexpr (kPayload) sidx[pos] = idx[i];
     }
   }
   // ... then look back: the entries with my digit in the tiles before this one
@@ -419,7 +430,11 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
           e[k] = sidx[ok[k] ? j : 0];
         }
       }
-      if (gather_dst != nullptr) {
+      if constexpr (VAL) {  // the value came along: a coalesced store, no read
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+          if (ok[k]) reinterpret_cast<uint32_t *>(gather_dst)[o[k]] = sidx[(k0 + k) * kSortThreads + tid];
+      } else if (gather_dst != nullptr) {
         if (gather_bytes == 4) {
           uint32_t v[kBatch];
 #pragma unroll
@@ -453,7 +468,7 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
       const unsigned int d = (unsigned int)(wd >> shift) & (kRadix - 1);
       const int64_t o = goff[d] + j;
       out[o] = wd;
-      if constexpr (!PACKED) idx_out[o] = sidx[j];
+      if constexpr (kPayload) idx_out[o] = sidx[j];
     }
   }
 }
@@ -541,7 +556,13 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
     return TSAMD_OK;
   }
   TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes, stream));
-  const int64_t ntiles = ceil_div(E, kSortThreads * (L.packed ? kItemsOf<true> : kItemsOf<false>));
+  // a 4-byte value array rides through the passes of a packed sort (TSAMD_SORT_VALUE_RIDE=0: gathered by the last pass)
+  bool ride = L.packed && gather_dst != nullptr && gather_bytes == 4 && L.passes >= 2;
+  if (ride) {
+    const char *env = getenv("TSAMD_SORT_VALUE_RIDE");
+    if (env != nullptr && env[0] == '0') ride = false;
+  }
+  const int64_t ntiles = ceil_div(E, kSortThreads * (L.packed ? (ride ? kItemsOf<true, true> : kItemsOf<true>) : kItemsOf<false>));
   {
     const int64_t nb = ceil_div(E, kBuildThreads * 4);
     hipLaunchKernelGGL(sort_build_kernel, dim3((unsigned int)(nb < 512 ? nb : 512)), dim3(kBuildThreads), 0, stream,
@@ -563,7 +584,17 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
                      ws.tile_state, ws.hdr, (unsigned int)(pass + 1), pass_todo, row, col,                          \
                      (last && probe) ? counts_out : (int64_t *)nullptr, gather_src, gather_dst, gather_bytes,          \
                      check4 ? 1 : 0)
-    if (L.packed) {
+    if (ride) {
+#define TSAMD_SORT_PASS_VAL(LST)                                                                                      \
+  hipLaunchKernelGGL((onesweep_pass_kernel<true, LST, true>), dim3((unsigned int)ntiles), dim3(kSortThreads), 0,      \
+                     stream, src, isrc, dst, idst, row_out, col_out, perm_out, E, shift, L, ws.hist + pass * kRadix,  \
+                     ws.tile_state, ws.hdr, (unsigned int)(pass + 1), pass_todo, row, col,                           \
+                     (last && probe) ? counts_out : (int64_t *)nullptr, gather_src, gather_dst, gather_bytes,           \
+                     check4 ? 1 : 0)
+      if (last) TSAMD_SORT_PASS_VAL(true);
+      else TSAMD_SORT_PASS_VAL(false);
+#undef TSAMD_SORT_PASS_VAL
+    } else if (L.packed) {
       if (last) TSAMD_SORT_PASS(true, true);
       else TSAMD_SORT_PASS(true, false);
     } else {
