@@ -434,7 +434,16 @@ __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, cons
     }
     __syncthreads();
     const int total = sc.off[64];
-    int lo_prev = 0;
+    // LONG_B: the A entry of the thread's previous product stays in REGISTERS (its product range, the start of its B
+    // row, its value): a hit costs no LDS access at all -- the hist / bin kernels of the large rows are bound by the
+    // CU's LDS pipe (occupancy 4 -> 8 moved them by 5-18 %, more loads in flight by nothing), and the round-4 form
+    // read five LDS words per product even on a hit.
+#ifndef TSAMD_SPSPMM_REG_ENTRY
+#define TSAMD_SPSPMM_REG_ENTRY 1
+#endif
+    int c_off = 0, c_end = 0;  // [c_off, c_end): products of the cached entry (empty: nothing cached for this chunk)
+    int64_t c_bs = 0;
+    A c_av = A(1);
     for (int q0 = tid; q0 < total; q0 += BLOCK * kExpandBatch) {
       int64_t src[kExpandBatch];
       A a[kExpandBatch];
@@ -442,22 +451,35 @@ __device__ __forceinline__ int expand_row(const int64_t *__restrict__ colA, cons
       for (int u = 0; u < kExpandBatch; ++u) {
         const int qq = q0 + u * BLOCK;
         const int q = qq < total ? qq : total - 1;
-        int lo = 0, hi = 64;  // last entry whose offset is <= q (zero-length entries are skipped)
-        bool hit = false;
         if constexpr (LONG_B) {
-          hit = sc.off[lo_prev] <= q && q < sc.off[lo_prev + 1];
-          if (hit) lo = lo_prev;
-        }
-        if (!hit) {
+#if TSAMD_SPSPMM_REG_ENTRY
+          if (!(c_off <= q && q < c_end)) {
+#else
+          {  // (A/B builds: search and read LDS for every product)
+#endif
+            int lo = 0, hi = 64;  // last entry whose offset is <= q (zero-length entries are skipped)
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+              const int mid = (lo + hi) >> 1;
+              if (sc.off[mid] <= q) lo = mid; else hi = mid;
+            }
+            c_off = sc.off[lo];
+            c_end = sc.off[lo + 1];
+            c_bs = sc.bs[lo];
+            if (WITH_VAL) c_av = sc.av[lo];
+          }
+          src[u] = c_bs + (q - c_off);
+          a[u] = WITH_VAL ? c_av : A(1);
+        } else {
+          int lo = 0, hi = 64;  // last entry whose offset is <= q (zero-length entries are skipped)
 #pragma unroll
           for (int step = 0; step < 6; ++step) {
             const int mid = (lo + hi) >> 1;
             if (sc.off[mid] <= q) lo = mid; else hi = mid;
           }
+          src[u] = sc.bs[lo] + (q - sc.off[lo]);
+          a[u] = WITH_VAL ? sc.av[lo] : A(1);
         }
-        if constexpr (LONG_B) lo_prev = lo;
-        src[u] = sc.bs[lo] + (q - sc.off[lo]);
-        a[u] = WITH_VAL ? sc.av[lo] : A(1);
       }
       uint32_t c[kExpandBatch];
       A b[kExpandBatch];
@@ -1159,7 +1181,10 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
     const int64_t *__restrict__ rowptrB, const uint32_t *__restrict__ colB,
     const int64_t *__restrict__ rows, int lg_range, int nr, int sub, int64_t *__restrict__ hist) {
-  __shared__ int cnt[kMaxRanges];
+  // nr * sub counters, sized at launch (round 5): a static kMaxRanges array (32 KB for the 256 counters a 2^19-column
+  // operand uses) held the kernel at 4 workgroups per CU, and at ~250-500 ns per product and thread the expansion is
+  // bound by loads in flight (4 per thread), not by bytes -- see large_counter_bytes()
+  extern __shared__ int cnt[];
   __shared__ ExpandScratch<float> sc;
   const int tid = (int)threadIdx.x;
   const int64_t i = rows[blockIdx.x];
@@ -1176,7 +1201,7 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_hist_kernel(
   expand_row<float, kLargeThreads, false, true>(colA, nullptr, rowptrB, colB, nullptr, rowptrA[i], rowptrA[i + 1], sc,
                                                 [&](int, uint32_t c, float) {
     const int q = (int)(c >> lg_range);
-    const int qprev = lane_read(q, lane > 0 ? lane - 1 : 0);
+    const int qprev = __builtin_amdgcn_update_dpp(0, q, 0x138, 0xF, 0xF, false);  // wave_shr:1 -- VALU, not the LDS pipe
     const bool head = lane == 0 || q != qprev;
     const unsigned long long hm = __ballot(head), act = __ballot(true);
     if (head) {
@@ -1203,7 +1228,7 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
     const int64_t *__restrict__ rows, int lg_range, int nr, int sub, const int64_t *__restrict__ sub_off,
     uint32_t *__restrict__ bcol, T *__restrict__ bval) {
   using A = typename Traits<T>::acc_t;
-  __shared__ int cursor[kMaxRanges];
+  extern __shared__ int cursor[];  // nr * sub cursors, sized at launch (see the hist kernel)
   __shared__ ExpandScratch<A> sc;
   const int tid = (int)threadIdx.x;
   const int64_t i = rows[blockIdx.x];
@@ -1220,7 +1245,7 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
     // positions, so their stores are contiguous.  (Grouping ALL lanes of equal range instead needs one
     // dependent atomic per group: 11.8 -> 23.3 ms; per-product atomics put 64 lanes on one cursor.)
     const int q = (int)(c >> lg_range);
-    const int qprev = lane_read(q, lane > 0 ? lane - 1 : 0);
+    const int qprev = __builtin_amdgcn_update_dpp(0, q, 0x138, 0xF, 0xF, false);  // wave_shr:1 -- VALU, not the LDS pipe
     const bool head = lane == 0 || q != qprev;
     const unsigned long long hm = __ballot(head), act = __ballot(true);
     const int leader = 63 - (int)__builtin_clzll(hm & ((2ull << lane) - 1ull));
@@ -1848,6 +1873,17 @@ unsigned int persistent_blocks() {
   return (unsigned int)cus * TSAMD_SPSPMM_ACCUM_WGS;
 }
 
+// dynamic LDS of the hist / bin kernels: their nr * sub counters (TSAMD_SPSPMM_STATIC_COUNTERS=1 in the environment asks
+// for the round-4 footprint of kMaxRanges counters: same-box A/B runs of the occupancy effect)
+static size_t large_counter_bytes(int nr, int sub) {
+  static const bool fat = [] {
+    const char *e = getenv("TSAMD_SPSPMM_STATIC_COUNTERS");
+    return e != nullptr && e[0] == '1';
+  }();
+  const size_t n = fat ? (size_t)kMaxRanges : (size_t)nr * (size_t)sub;
+  return (n * sizeof(int) + 255) / 256 * 256;
+}
+
 // valA / valB given (either may be NULL): the products are binned WITH their values, so that the numeric
 // stage does not have to expand the large rows a third time.
 template <typename T>
@@ -1859,7 +1895,8 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const void *valA
   LargeWs w;
   carve_large(workspace, n_large, P_large, N, esize, &w);
   if (w.nr > kMaxRanges) return TSAMD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(spspmm_large_hist_kernel, dim3((unsigned int)n_large), dim3(kLargeThreads), 0, stream,
+  hipLaunchKernelGGL(spspmm_large_hist_kernel, dim3((unsigned int)n_large), dim3(kLargeThreads),
+                     large_counter_bytes(w.nr, w.sub), stream,
                      rowptrA, colA, rowptrB, colB, rows, w.lg_range, w.nr, w.sub, w.hist);
   TSAMD_LAUNCH_CHECK();
   TSAMD_HIP_TRY(hipMemsetAsync(w.hist + w.ntask * w.sub, 0, 8, stream));
@@ -1869,12 +1906,12 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const void *valA
                      (const int64_t *)w.hist, w.sub, w.ntask, w.bin_off);
   TSAMD_LAUNCH_CHECK();
   if (with_values)
-    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
+    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), large_counter_bytes(w.nr, w.sub),
                        stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
                        reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, w.sub, (const int64_t *)w.hist,
                        w.bcol, reinterpret_cast<T *>(w.bval));
   else
-    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, false>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
+    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, false>), dim3((unsigned int)n_large), dim3(kLargeThreads), large_counter_bytes(w.nr, w.sub),
                        stream, rowptrA, colA, (const T *)nullptr, rowptrB, colB, (const T *)nullptr, rows,
                        w.lg_range, w.nr, w.sub, (const int64_t *)w.hist, w.bcol, (T *)nullptr);
   TSAMD_LAUNCH_CHECK();
@@ -1907,7 +1944,7 @@ int numeric_large(const int64_t *rowptrA, const int64_t *colA, const void *valA,
   if (w.nr > kMaxRanges) return TSAMD_ERR_UNSUPPORTED;
   T *bv = reinterpret_cast<T *>(w.bval);
   if (valC != nullptr && !values_binned) {  // the symbolic stage binned the columns only; the values follow the same offsets
-    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), 0,
+    hipLaunchKernelGGL((spspmm_large_bin_kernel<T, true>), dim3((unsigned int)n_large), dim3(kLargeThreads), large_counter_bytes(w.nr, w.sub),
                        stream, rowptrA, colA, reinterpret_cast<const T *>(valA), rowptrB, colB,
                        reinterpret_cast<const T *>(valB), rows, w.lg_range, w.nr, w.sub, (const int64_t *)w.hist,
                        w.bcol, bv);
