@@ -110,6 +110,21 @@ if hasattr(nat, 'spmm_minmax_bw_csc'):
         edges=E, algorithmic_bytes=n * 128 * (8 + 2 * 2) + 2 * n * 128 * 2)
     run('c3_value_bw_plain_bf16_F128', lambda: nat.spmm_value_bw(row, rp, c, xb, gb, 'sum'), edges=E,
         algorithmic_bytes=E * (16 + 128 * 2 + 2) + n * 128 * 2)
+    if not which or 'c3_matmul_step_val_bf16_F128' in which:
+        # round 5: the drop-in training step (int32 winner ids inside the node, pull with grad_value)
+        _vm = vb.clone().requires_grad_()
+        _Am = ts.SparseTensor(rowptr=rp, col=c, value=_vm, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+        _Am.storage.colptr(), _Am.storage.csr2csc(), _Am.storage.row()
+        _xm = xb.clone().requires_grad_()
+
+        def _mstep():
+            _xm.grad = None
+            _vm.grad = None
+            _Am.matmul(_xm, 'max').backward(gb)
+        _mstep()
+        run('c3_matmul_step_val_bf16_F128', _mstep, edges=E,
+            algorithmic_bytes=balg(E, n, 128, 2, True, True) + n * 128 * (8 + 2 * 2) + 2 * n * 128 * 2)
+        del _Am, _vm, _xm
     del A, colptr, perm, vb, argv
 del rp, c, row, x, g, xb, gb, arg
 torch.cuda.empty_cache()
