@@ -98,6 +98,41 @@ __device__ inline bool keep_entry(int pred, const int64_t *row, const int64_t *c
   }
 }
 
+// The same predicate with `pred` known at compile time: inside an unrolled loop the run-time switch above puts every
+// entry's loads into their own basic block -- load, wait, compare, next entry: one round trip PER ENTRY and thread
+// (scripts/scan_serial_loads.py: 64 of the count kernel's 80 loads and 96 of the write kernel's 112 were waited for
+// alone).  The tile kernels dispatch on `pred` ONCE and run a straight-line body whose loads are issued together.
+template <int PRED>
+__device__ __forceinline__ bool keep_entry_t(const int64_t *row, const int64_t *col, const uint8_t *mask,
+                                             const int64_t *map, int64_t i, int64_t a, int64_t b) {
+  if constexpr (PRED == TSAMD_KEEP_COL_RANGE) {
+    const int64_t c = col[i];
+    return c >= a && c < a + b;
+  } else if constexpr (PRED == TSAMD_KEEP_OFF_DIAG) {
+    return row[i] != col[i] - a;
+  } else if constexpr (PRED == TSAMD_KEEP_MASK) {
+    return mask[i] != 0;
+  } else if constexpr (PRED == TSAMD_KEEP_MASK_ROW) {
+    return mask[row[i]] != 0;
+  } else if constexpr (PRED == TSAMD_KEEP_MASK_COL) {
+    return mask[col[i]] != 0;
+  } else if constexpr (PRED == TSAMD_KEEP_COL_MAPPED) {
+    return map[col[i]] >= 0;
+  } else {
+    return false;
+  }
+}
+#define TSAMD_FILTER_DISPATCH(pred, BODY)                                 \
+  switch (pred) {                                                         \
+    case TSAMD_KEEP_COL_RANGE: BODY(TSAMD_KEEP_COL_RANGE); break;         \
+    case TSAMD_KEEP_OFF_DIAG: BODY(TSAMD_KEEP_OFF_DIAG); break;           \
+    case TSAMD_KEEP_MASK: BODY(TSAMD_KEEP_MASK); break;                   \
+    case TSAMD_KEEP_MASK_ROW: BODY(TSAMD_KEEP_MASK_ROW); break;           \
+    case TSAMD_KEEP_MASK_COL: BODY(TSAMD_KEEP_MASK_COL); break;           \
+    case TSAMD_KEEP_COL_MAPPED: BODY(TSAMD_KEEP_COL_MAPPED); break;       \
+    default: break;                                                       \
+  }
+
 __global__ void filter_flags_kernel(int pred, const int64_t *__restrict__ row,
                                     const int64_t *__restrict__ col,
                                     const uint8_t *__restrict__ mask,
@@ -256,11 +291,16 @@ __global__ __launch_bounds__(256) void filter_count_kernel(int pred, const int64
   __shared__ int wsum[4];
   const int64_t base = (int64_t)blockIdx.x * kFilterTile;
   int c = 0;
-#pragma unroll
-  for (int j = 0; j < kFilterSlices; ++j) {
-    const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
-    c += (i < n && keep_entry(pred, row, col, mask, map, i, a, b)) ? 1 : 0;
+#define TSAMD_COUNT_BODY(P)                                                                    \
+  _Pragma("unroll") for (int j = 0; j < kFilterSlices; ++j) {                                  \
+    const int64_t i = base + (int64_t)j * 256 + threadIdx.x;                                   \
+    const int64_t ic = i < n ? i : n - 1; /* the loads of all slices are issued unconditionally */ \
+    c += (keep_entry_t<P>(row, col, mask, map, ic, a, b) && i < n) ? 1 : 0;                    \
   }
+  if (n > 0) {
+    TSAMD_FILTER_DISPATCH(pred, TSAMD_COUNT_BODY)
+  }
+#undef TSAMD_COUNT_BODY
   for (int off = 32; off > 0; off >>= 1) c += lane_xor(c, off);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -279,15 +319,43 @@ __global__ __launch_bounds__(256) void filter_write_kernel(
   bool keep[kFilterSlices];
   int before[kFilterSlices];  // kept entries of this wave's slice part in lower lanes
 #pragma unroll
+  for (int j = 0; j < kFilterSlices; ++j) keep[j] = false;
+#define TSAMD_KEEP_BODY(P)                                                     \
+  _Pragma("unroll") for (int j = 0; j < kFilterSlices; ++j) {                  \
+    const int64_t i = base + (int64_t)j * 256 + threadIdx.x;                   \
+    const int64_t ic = i < n ? i : n - 1;                                      \
+    keep[j] = keep_entry_t<P>(row, col, mask, map, ic, a, b) && i < n;         \
+  }
+  if (n > 0) {
+    TSAMD_FILTER_DISPATCH(pred, TSAMD_KEEP_BODY)
+  }
+#undef TSAMD_KEEP_BODY
+#pragma unroll
   for (int j = 0; j < kFilterSlices; ++j) {
-    const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
-    keep[j] = i < n && keep_entry(pred, row, col, mask, map, i, a, b);
     const unsigned long long m = __ballot(keep[j]);
     before[j] = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) wcnt[j][wave] = __popcll(m);
   }
   __syncthreads();
   int64_t run = tile_off[blockIdx.x];
+  // the ids of all slices first (unconditional loads of a clamped position: issued together), then the maps, then the
+  // stores -- per slice inside `if (keep[j])` every id was a round trip of its own, and its map entry another one
+  int64_t rv[kFilterSlices], cv[kFilterSlices];
+#pragma unroll
+  for (int j = 0; j < kFilterSlices; ++j) {
+    const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
+    const int64_t ic = (i < n ? i : n - 1);
+    rv[j] = (row_out && n > 0) ? row[ic] : 0;
+    cv[j] = (col_out && n > 0) ? col[ic] : 0;
+  }
+  if (row_map != nullptr && row_out != nullptr && n > 0) {
+#pragma unroll
+    for (int j = 0; j < kFilterSlices; ++j) rv[j] = row_map[rv[j]];
+  }
+  if (col_map != nullptr && col_out != nullptr && n > 0) {
+#pragma unroll
+    for (int j = 0; j < kFilterSlices; ++j) cv[j] = col_map[cv[j]];
+  }
 #pragma unroll
   for (int j = 0; j < kFilterSlices; ++j) {
     int wbase = 0, total = 0;
@@ -300,14 +368,8 @@ __global__ __launch_bounds__(256) void filter_write_kernel(
     if (keep[j]) {
       const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
       const int64_t p = run + wbase + before[j];
-      if (row_out) {
-        const int64_t r = row[i];
-        row_out[p] = (row_map ? row_map[r] : r) - row_shift;
-      }
-      if (col_out) {
-        const int64_t c = col[i];
-        col_out[p] = (col_map ? col_map[c] : c) - col_shift;
-      }
+      if (row_out) row_out[p] = rv[j] - row_shift;
+      if (col_out) col_out[p] = cv[j] - col_shift;
       if (src_out) src_out[p] = i;
     }
     run += total;
