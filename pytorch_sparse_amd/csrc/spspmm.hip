@@ -730,6 +730,12 @@ __global__ __launch_bounds__(64) void spspmm_symbolic_small_kernel(
 // (v_min / v_max on registers), the others exchange with lane ^ mask through DPP (masks 1, 2, 3,
 // 7, 15), ds_swizzle (4, 8, 16, 31) or ds_bpermute (32, 63) -- none of which allocates LDS.
 // ---------------------------------------------------------------------------
+#ifndef TSAMD_SPSPMM_DPP_XOR8
+#define TSAMD_SPSPMM_DPP_XOR8 1
+#endif
+#ifndef TSAMD_SPSPMM_DPP_XOR4
+#define TSAMD_SPSPMM_DPP_XOR4 0
+#endif
 template <int MASK>
 __device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane) {
   if constexpr (MASK == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
@@ -737,6 +743,19 @@ __device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane) {
   else if constexpr (MASK == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, true);
   else if constexpr (MASK == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
   else if constexpr (MASK == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+#if TSAMD_SPSPMM_DPP_XOR8
+  // lane ^ 8 inside a row of 16 lanes is a rotation by 8: row_ror:8 -- a VALU move instead of an LDS-pipe ds_swizzle
+  // (12 of the 32 LDS-pipe exchanges of a 256-key sort; the pipe is shared by every wave of the CU)
+  else if constexpr (MASK == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);
+#endif
+#if TSAMD_SPSPMM_DPP_XOR4
+  // lane ^ 4: banks 0 / 2 of a row read four lanes up (row_shl:4), banks 1 / 3 four lanes down (row_shr:4): two DPP
+  // moves under bank masks instead of one ds_swizzle
+  else if constexpr (MASK == 4) {
+    const int up = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(up, (int)v, 0x114, 0xF, 0xA, false);
+  }
+#endif
   else if constexpr (MASK < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (MASK << 10) | 0x1F);
   else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, (int)v);
 }
