@@ -51,10 +51,21 @@ namespace {
 #define TSAMD_SPMM_PARTIAL_BUILD 0
 #endif
 constexpr bool kPartial = TSAMD_SPMM_PARTIAL_BUILD != 0;
+// ... and its ~200 merge-kernel instantiations are split over two translation units that compile in parallel (176 s
+// in one): TSAMD_SPMM_TU 1 = this file (sum / mean and the masked sum, every entry point; min / max are launched through
+// spmm_min_bridge / spmm_max_bridge), 2 / 3 = spmm_min.hip / spmm_max.hip (the min / the max instantiations and their
+// bridge), 0 = everything in one unit (the partial build).
+#ifndef TSAMD_SPMM_TU
+#if TSAMD_SPMM_PARTIAL_BUILD
+#define TSAMD_SPMM_TU 0
+#else
+#define TSAMD_SPMM_TU 1
+#endif
+#endif
 
-constexpr int RED_ADD = 0;  // sum and mean
-constexpr int RED_MIN = 1;
-constexpr int RED_MAX = 2;
+[[maybe_unused]] constexpr int RED_ADD = 0;  // sum and mean
+[[maybe_unused]] constexpr int RED_MIN = 1;
+[[maybe_unused]] constexpr int RED_MAX = 2;
 
 // tuning knobs (overridable with -D for A/B experiments, see scripts/variants.py)
 #ifndef TSAMD_UNROLL
@@ -1454,11 +1465,19 @@ int dispatch_reduce(int reduce, const int64_t *rowptr, const int64_t *col, const
                     T *o, int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
                     Workspace ws, hipStream_t stream, hipEvent_t *ev) {
   const bool mean = reduce == TSAMD_MEAN;
+#if TSAMD_SPMM_TU == 0 || TSAMD_SPMM_TU == 2
   if (reduce == TSAMD_MIN)
     return launch_spmm<T, VEC, RED_MIN>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev);
+#endif
+#if TSAMD_SPMM_TU == 0 || TSAMD_SPMM_TU == 3
   if (reduce == TSAMD_MAX)
     return launch_spmm<T, VEC, RED_MAX>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev);
-  return launch_spmm<T, VEC, RED_ADD>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev);
+#endif
+#if TSAMD_SPMM_TU <= 1
+  if (reduce == TSAMD_SUM || reduce == TSAMD_MEAN)
+    return launch_spmm<T, VEC, RED_ADD>(rowptr, col, v, x, o, arg_out, B, M, N, K, E, mean, ws, stream, ev);
+#endif
+  return TSAMD_ERR_UNSUPPORTED;  // (the other translation unit's reductions: spmm_entry never sends them here)
 }
 
 // `vec` = elements per lane packet, chosen by the caller: the largest power of two <= kMaxVec<T>
@@ -1492,8 +1511,35 @@ int dispatch_spmm(int reduce, int vec, const int64_t *rowptr, const int64_t *col
 }
 
 }  // namespace
+
+// min / max launches of the other translation units (spmm_min.hip / spmm_max.hip); `ws` = the caller's Workspace, byte
+// for byte
+#define TSAMD_BRIDGE_ARGS                                                                                             \
+  int dtype, int reduce, int vec, const int64_t *rowptr, const int64_t *col, const void *value, const void *mat,      \
+      void *out, int64_t *arg_out, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E, const void *ws_blob,        \
+      size_t ws_bytes, hipStream_t stream, hipEvent_t *ev
+int spmm_min_bridge(TSAMD_BRIDGE_ARGS);
+int spmm_max_bridge(TSAMD_BRIDGE_ARGS);
+#if TSAMD_SPMM_TU >= 2
+#if TSAMD_SPMM_TU == 2
+int spmm_min_bridge(TSAMD_BRIDGE_ARGS) {
+  if (reduce != TSAMD_MIN) return TSAMD_ERR_INVALID;
+#else
+int spmm_max_bridge(TSAMD_BRIDGE_ARGS) {
+  if (reduce != TSAMD_MAX) return TSAMD_ERR_INVALID;
+#endif
+  if (ws_bytes != sizeof(Workspace)) return TSAMD_ERR_INVALID;
+  Workspace ws;
+  __builtin_memcpy(&ws, ws_blob, sizeof(Workspace));
+  return TSAMD_DISPATCH_DTYPE_ALL(dtype, [&]() -> int {
+    return dispatch_spmm<scalar_t>(reduce, vec, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, ws, stream, ev);
+  });
+}
+#endif
+#undef TSAMD_BRIDGE_ARGS
 }  // namespace tsamd
 
+#if TSAMD_SPMM_TU <= 1  // every entry point lives in the main unit
 using namespace tsamd;
 
 #if !TSAMD_SPMM_PARTIAL_BUILD
@@ -1579,6 +1625,14 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
 #if TSAMD_SPMM_PARTIAL_BUILD
   // partial products are the stages of the sharded SpMM over dense FEATURE matrices: floating point only
   if (dtype != TSAMD_F32 && dtype != TSAMD_F64 && dtype != TSAMD_F16 && dtype != TSAMD_BF16) return TSAMD_ERR_UNSUPPORTED;
+#endif
+#if TSAMD_SPMM_TU == 1
+  if (reduce == TSAMD_MIN)  // instantiated in spmm_min.hip / spmm_max.hip
+    return tsamd::spmm_min_bridge(dtype, reduce, vec, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, &ws,
+                                  sizeof(ws), stream, ev);
+  if (reduce == TSAMD_MAX)
+    return tsamd::spmm_max_bridge(dtype, reduce, vec, rowptr, col, value, mat, out, arg_out, B, M, N, K, E, &ws,
+                                  sizeof(ws), stream, ev);
 #endif
   return TSAMD_DISPATCH_DTYPE_ALL(dtype, [&]() -> int {
 #if TSAMD_SPMM_PARTIAL_BUILD
@@ -1821,3 +1875,4 @@ extern "C" int tsamd_spmm_profiled(int dtype, int reduce, const int64_t *rowptr,
   return st;
 }
 #endif  // !TSAMD_SPMM_PARTIAL_BUILD
+#endif  // TSAMD_SPMM_TU <= 1

@@ -61,6 +61,30 @@ def test_onesweep_sort_power_law_and_hot_digits(dev, ops):
     _check(ops, row, col, 100, 100, dev)
 
 
+@pytest.mark.parametrize('E,m,n', [(75000000, 1 << 22, 1 << 22),   # 44-bit keys + 27-bit positions: pairs, 6 passes
+                                   (7500000, 500000, 500000)])        # configs[3]'s input: packed, 5 passes
+def test_onesweep_sort_full_size_properties(dev, ops, E, m, n):
+    """The BASELINE-size sorts through size-independent properties, all evaluated on the device: keys non-decreasing,
+    equal keys in input order (stable), `perm` a permutation, outputs = inputs gathered through it -- and the values that
+    ride along (4-byte: through every pass of a packed sort; otherwise gathered by the last pass) equal value[perm]."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    row = torch.randint(0, m, (E, ), generator=g, device=dev)
+    col = torch.randint(0, n, (E, ), generator=g, device=dev)
+    val = torch.rand(E, generator=g, device=dev)
+    rs, cs, perm, _, vs = ops.sort_coo_values(row, col, m, n, 0, None, val)
+    key = rs * n + cs
+    d = key[1:] - key[:-1]
+    assert bool((d >= 0).all())
+    assert bool((perm[1:][d == 0] > perm[:-1][d == 0]).all()), 'equal keys out of input order'
+    seen = torch.zeros(E, dtype=torch.bool, device=dev)
+    seen[perm] = True
+    assert bool(seen.all()), 'perm is not a permutation'
+    assert torch.equal(rs, row[perm]) and torch.equal(cs, col[perm])
+    assert torch.equal(vs, val[perm])
+    v8 = val.double()
+    assert torch.equal(ops.sort_coo_values(row, col, m, n, 0, None, v8)[4], v8[perm])  # 8-byte values: last-pass gather
+
+
 def test_device_decided_sort_and_probe(dev, ops):
     E, m, n = 300000, 4000, 5000
     g = torch.Generator().manual_seed(2)
