@@ -576,6 +576,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_minmax_bw_kernel(
 // global atomics.  A winner is only trusted to lie inside the chunk (LDS bounds); a foreign arg_out
 // gives a wrong mask, never a wild store.
 // ---------------------------------------------------------------------------
+#ifndef TSAMD_WINREC_ROWS
+#define TSAMD_WINREC_ROWS 2
+#endif
 // ARG = int64_t (the API's arg_out) or int32_t (tsamd_spmm_minmax_arg32: the same ids in half the bytes)
 template <typename T, typename ARG>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
@@ -620,28 +623,37 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
       __builtin_amdgcn_wave_barrier();
       const uint32_t k0 = t0 * 64u + (uint32_t)lane, k1 = k0 + 64u;
       unsigned long long todo = heads;
-      while (todo != 0) {  // two rows per step: their loads are independent
-        const int p0 = (int)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        const bool two = todo != 0;
-        const int p1 = two ? (int)__builtin_ctzll(todo) : p0;
-        if (two) todo &= todo - 1;
-        const uint64_t ra = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_l, p0) * K;
-        const uint64_t rb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_l, p1) * K;
-        // (the ids stay in their own width until all four loads are issued: a widening inside the predicated blocks
-        // made the compiler wait for every int32 load on its own -- four round trips instead of one, 0.31 -> 0.40 ms)
-        ARG l00 = -1, l01 = -1, l10 = -1, l11 = -1;
-        if (k0 < K) l00 = a_b[ra + k0];
-        if (k1 < K) l01 = a_b[ra + k1];
-        if (two && k0 < K) l10 = a_b[rb + k0];
-        if (two && k1 < K) l11 = a_b[rb + k1];
-        asm volatile("" : "+v"(l00), "+v"(l01), "+v"(l10), "+v"(l11));
-        const int64_t a00 = (int64_t)l00, a01 = (int64_t)l01, a10 = (int64_t)l10, a11 = (int64_t)l11;
-        const int64_t r00 = a00 - e0, r01 = a01 - e0, r10 = a10 - e0, r11 = a11 - e0;
-        if (a00 >= 0 && r00 >= 0 && r00 < n) atomicOr(tile + (uint32_t)r00 * 4 + half, bit);
-        if (a01 >= 0 && r01 >= 0 && r01 < n) atomicOr(tile + (uint32_t)r01 * 4 + 2 + half, bit);
-        if (a10 >= 0 && r10 >= 0 && r10 < n) atomicOr(tile + (uint32_t)r10 * 4 + half, bit);
-        if (a11 >= 0 && r11 >= 0 && r11 < n) atomicOr(tile + (uint32_t)r11 * 4 + 2 + half, bit);
+      while (todo != 0) {  // up to kRows rows per step: their loads are independent -- one round trip for all of them
+        // (TSAMD_WINREC_ROWS = 2 / 4 / 8 rows per step measured within 0.5 %: profiles/r05_ab_winrec_rows.log -- the kernel does not wait for these loads)
+        constexpr int kRows = TSAMD_WINREC_ROWS;
+        uint64_t rbase[kRows];
+        bool have[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+          have[u] = todo != 0;
+          const int p = have[u] ? (int)__builtin_ctzll(todo) : 0;
+          if (have[u]) todo &= todo - 1;
+          rbase[u] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_l, p) * K;
+        }
+        // (the ids stay in their own width until all loads are issued: a widening inside the predicated blocks made
+        // the compiler wait for every int32 load on its own -- four round trips instead of one, 0.31 -> 0.40 ms)
+        ARG l0[kRows], l1[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+          l0[u] = -1;
+          l1[u] = -1;
+          if (have[u] && k0 < K) l0[u] = a_b[rbase[u] + k0];
+          if (have[u] && k1 < K) l1[u] = a_b[rbase[u] + k1];
+        }
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) asm volatile("" : "+v"(l0[u]), "+v"(l1[u]));
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+          const int64_t a0 = (int64_t)l0[u], a1 = (int64_t)l1[u];
+          const int64_t r0 = a0 - e0, r1 = a1 - e0;
+          if (a0 >= 0 && r0 >= 0 && r0 < n) atomicOr(tile + (uint32_t)r0 * 4 + half, bit);
+          if (a1 >= 0 && r1 >= 0 && r1 < n) atomicOr(tile + (uint32_t)r1 * 4 + 2 + half, bit);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
