@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kCheckThreads) void order_check_kernel(const int64_
     for (int u = 0; u < kB; ++u) {
       const int64_t i = base + u * kCheckThreads + threadIdx.x;
       // the entry before: the neighbour lane's registers, except for lane 0 (one cached load per wave)
-      int64_t pr = lane_read(r[u], lane > 0 ? lane - 1 : 0), pc = lane_read(c[u], lane > 0 ? lane - 1 : 0);
+      int64_t pr = lane_below(r[u]), pc = lane_below(c[u]);  // (DPP: as ds_bpermute these were four LDS-pipe round trips per entry)
       if (i < n) {
         if (lane == 0 && i > 0) {
           pr = row[i - 1];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void coalesce_compact_kernel(
 #pragma unroll
   for (int i = 0; i < kCompactItems; ++i) {
     const int64_t e = tile0 + i * 256 + tid;
-    int64_t pr = lane_read(r[i], lane > 0 ? lane - 1 : 0), pc = lane_read(c[i], lane > 0 ? lane - 1 : 0);
+    int64_t pr = lane_below(r[i]), pc = lane_below(c[i]);
     bool h = false;
     if (e < n) {
       if (lane == 0 && e > 0) {

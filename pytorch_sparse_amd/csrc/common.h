@@ -315,6 +315,16 @@ __device__ __forceinline__ double lane_down(double v) {
   return __longlong_as_double(lane_down<OFF>((int64_t)__double_as_longlong(v)));
 }
 
+// Value held by lane - 1 (wave_shr:1 on the DPP network: VALU data movement, no LDS-pipe round trip like ds_bpermute).
+// Lane 0 -- and a lane whose lower neighbour is disabled -- gets 0.
+__device__ __forceinline__ uint32_t lane_below_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int64_t lane_below(int64_t v) {
+  const uint32_t lo = lane_below_u32((uint32_t)(uint64_t)v), hi = lane_below_u32((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // A 16-byte (or narrower) packet of VEC elements; alignment lets the compiler
 // emit one global_load_dwordx4 / global_store_dwordx4 per lane.
 template <typename T, int VEC>

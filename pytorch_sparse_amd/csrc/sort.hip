@@ -126,9 +126,9 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
       // the entry before: the neighbour lane's registers (exchanged with every lane active: a disabled source lane
       // reads as 0), except for lane 0 (one cached load per wave)
       int64_t pr = 0, pc = 0;
-      if (probe) {
-        pr = lane_read(r[u], lane > 0 ? lane - 1 : 0);
-        pc = lane_read(c[u], lane > 0 ? lane - 1 : 0);
+      if (probe) {  // wave_shr:1 on the DPP network (VALU) -- as ds_bpermute these were four LDS-pipe round trips per entry
+        pr = lane_below(r[u]);
+        pc = lane_below(c[u]);
       }
       if (ok[u]) {
         words[i] = L.packed ? ((key << L.idx_bits) | (unsigned long long)i) : key;

@@ -1155,6 +1155,9 @@ __global__ __launch_bounds__(BLOCK) void spspmm_numeric_pairs_kernel(
 #ifndef TSAMD_SPSPMM_ACCUM_WGS
 #define TSAMD_SPSPMM_ACCUM_WGS 4
 #endif
+#ifndef TSAMD_SPSPMM_COUNT_WGS
+#define TSAMD_SPSPMM_COUNT_WGS 8
+#endif
 constexpr int kLargeThreads = 256;   // hist / bin kernels: one workgroup per large row
 constexpr int kAccumThreads = TSAMD_SPSPMM_ACCUM_THREADS;  // count / accum kernels (persistent, LDS-bound occupancy)
 constexpr int kBinBatch = 4;         // bin entries fetched per thread before they are consumed
@@ -1301,6 +1304,14 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
 // pipeline: while bin k is processed, thread 0 draws the ticket of bin k+2 and fetches the descriptor of
 // bin k+1 in three steps spread over the phases of bin k; the finished descriptor (task, segment, output
 // position or row) waits in LDS for the next iteration.
+#ifndef TSAMD_SPSPMM_TICKET_CHUNK
+#define TSAMD_SPSPMM_TICKET_CHUNK 8
+#endif
+#ifndef TSAMD_SPSPMM_TICKET_CHUNK_ACCUM
+#define TSAMD_SPSPMM_TICKET_CHUNK_ACCUM 2
+#endif
+constexpr int kTicketChunk = TSAMD_SPSPMM_TICKET_CHUNK;             // count kernel (256-thread workgroups)
+constexpr int kTicketChunkAccum = TSAMD_SPSPMM_TICKET_CHUNK_ACCUM;  // accumulation (one wave per bin: coarser chunks unbalance it)
 struct BinFeed {
   unsigned long long *queue;
   const int64_t *list;
@@ -1309,10 +1320,23 @@ struct BinFeed {
   int nr;
   // thread 0 only
   int64_t t_next = 0, t_next2 = 0, task = -1, b0 = 0, b1 = 0, row = 0, pref = 0;
+  // Tickets are drawn kTicketChunk at a time: the counter is ONE hot address, ~12 ns per returning atomic and fully
+  // serialised (NOTES.md, hardware facts) -- 300 k big bins of the stress product were 3.6 ms of queueing in EACH of the
+  // count and the accumulation kernels, whatever the number of workgroups (8 instead of 4 per CU changed nothing).
+  int chunk = kTicketChunk;
+  int64_t t_chunk = 0;
+  int t_left = 0;
+  __device__ __forceinline__ int64_t draw() {
+    if (t_left == 0) {
+      t_chunk = (int64_t)atomicAdd(queue, (unsigned long long)chunk);
+      t_left = chunk;
+    }
+    return t_chunk + (chunk - t_left--);
+  }
 
   __device__ __forceinline__ void step_a() {  // top of an iteration
     if (threadIdx.x != 0) return;
-    t_next2 = (int64_t)atomicAdd(queue, 1ull);
+    t_next2 = draw();
     task = t_next < n ? list[t_next] : -1;
   }
   __device__ __forceinline__ void step_b() {  // middle of an iteration
@@ -1333,8 +1357,8 @@ struct BinFeed {
   }
   __device__ __forceinline__ void start(int64_t *desc) {  // descriptor of the first bin, ticket of the second
     if (threadIdx.x == 0) {
-      t_next = (int64_t)atomicAdd(queue, 1ull);
-      t_next2 = (int64_t)atomicAdd(queue, 1ull);
+      t_next = draw();
+      t_next2 = draw();
       task = t_next < n ? list[t_next] : -1;
     }
     step_b();
@@ -1412,6 +1436,7 @@ __global__ __launch_bounds__(kAccumThreads) void spspmm_large_accum_kernel(
   __shared__ int64_t s_desc[2][4];
   for (int w = tid; w < kWords; w += kAccumThreads) bits[w] = 0;
   BinFeed feed{queue, big, *n_big, bin_off, rows, bin_pref, rowptrC, nr};
+  feed.chunk = kTicketChunkAccum;
   feed.start(s_desc[0]);
   for (int cur = 0;; cur ^= 1) {
     const int64_t task = s_desc[cur][0];
@@ -1510,6 +1535,7 @@ __global__ __launch_bounds__(64) void spspmm_large_accum_wave_kernel(
   for (int c = lane; c < kCols; c += 64) acc[c] = A(0);
   for (int w = lane; w < kWords; w += 64) bits[w] = 0;
   BinFeed feed{queue, big, *n_big, bin_off, rows, bin_pref, rowptrC, nr};
+  feed.chunk = kTicketChunkAccum;
   feed.start(s_desc[0]);
   for (int cur = 0;; cur ^= 1) {
     const int64_t task = s_desc[cur][0];
@@ -1945,7 +1971,10 @@ int symbolic_large(const int64_t *rowptrA, const int64_t *colA, const void *valA
                      (const uint32_t *)w.bcol, kPairs<T> ? 2 : 1, w.bin_cnt,
                      reinterpret_cast<unsigned long long *>(nnzC));
   TSAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(spspmm_large_count_kernel, dim3(persistent_blocks()), dim3(kAccumThreads), 0, stream, rows,
+  // (the count kernel's footprint is its 4 KB bitmap: 8 persistent workgroups per CU instead of the accumulation's 4 --
+  // a bin costs ~8 us of dependent round trips and barriers whatever its size, so bins in flight are what it needs:
+  // SQ counters, profiles/r05_sq_counters.md: VALU pipe 0.12, waiting 0.92)
+  hipLaunchKernelGGL(spspmm_large_count_kernel, dim3(persistent_blocks() / TSAMD_SPSPMM_ACCUM_WGS * TSAMD_SPSPMM_COUNT_WGS), dim3(kAccumThreads), 0, stream, rows,
                      w.nr, (const int64_t *)(w.lists + w.ntask), (const int64_t *)(w.counts + 1),
                      (const int64_t *)w.bin_off, (const uint32_t *)w.bcol, kPairs<T> ? 2 : 1, (1 << w.lg_range) / 32, w.bin_cnt,
                      reinterpret_cast<unsigned long long *>(nnzC), w.queue);
