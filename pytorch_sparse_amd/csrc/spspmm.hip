@@ -101,17 +101,41 @@ __global__ __launch_bounds__(256) void spspmm_bin_kernel(const int64_t *__restri
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t p = i < M ? prod[i] : 0;
   const int b = p <= kSmallCap ? -1 : (p <= kMediumCap ? 0 : 1);
+  // one returning atomic per WORKGROUP and list (the two list counters are hot words, ~12 ns per atomic: a wave-level
+  // reservation was 16 k serialised atomics on the stress product)
+  __shared__ int s_cnt[2][4];
+  __shared__ unsigned long long s_base[2];
+  const int wid = (int)(threadIdx.x >> 6);
+  unsigned long long m2[2];
   for (int bin = 0; bin < 2; ++bin) {
-    const unsigned long long m = __ballot(b == bin);
-    if (m == 0) continue;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&stats[ST_NMEDIUM + bin], (unsigned long long)__popcll(m));
-    base = (unsigned long long)lane_read((int64_t)base, 0);
-    if (b == bin) bins[(int64_t)bin * M + (int64_t)base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    m2[bin] = __ballot(b == bin);
+    if (lane == 0) s_cnt[bin][wid] = __popcll(m2[bin]);
   }
-  if (b == 1) {  // few rows: per-row atomics are fine
-    atomicAdd(&stats[ST_PLARGE], (unsigned long long)p);
-    atomicMax(&stats[ST_PMAX], (unsigned long long)p);  // largest row: the (row, range) counters are 32-bit
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int tot = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+    s_base[threadIdx.x] = tot ? atomicAdd(&stats[ST_NMEDIUM + threadIdx.x], (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
+  for (int bin = 0; bin < 2; ++bin) {
+    if (b != bin) continue;
+    unsigned long long base = s_base[bin];
+    for (int w = 0; w < wid; ++w) base += (unsigned long long)s_cnt[bin][w];
+    bins[(int64_t)bin * M + (int64_t)base + __popcll(m2[bin] & ((1ull << lane) - 1ull))] = i;
+  }
+  // products of the large rows and the largest one: reduced over the wave first -- the two words are hot addresses (77 k
+  // large rows of the stress product were 154 k atomics on them: 0.35 ms for a kernel that moves 4 MB)
+  unsigned long long ps = b == 1 ? (unsigned long long)p : 0ull, pm = ps;
+  if (__ballot(b == 1) != 0ull) {  // wave-uniform
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long os = (unsigned long long)lane_xor((int64_t)ps, off), om = (unsigned long long)lane_xor((int64_t)pm, off);
+      ps += os;
+      pm = om > pm ? om : pm;
+    }
+    if (lane == 0) {
+      atomicAdd(&stats[ST_PLARGE], ps);
+      atomicMax(&stats[ST_PMAX], pm);  // largest row: the (row, range) counters are 32-bit
+    }
   }
 }
 
