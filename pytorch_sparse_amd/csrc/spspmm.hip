@@ -63,6 +63,7 @@ enum { ST_NMEDIUM = 2, ST_NLARGE = 3, ST_PLARGE = 4, ST_PMAX = 5 };
 // products(i) = sum over the entries k of row i of A of |B_k|.  8 lanes per row (32 rows per
 // 256-thread workgroup): rows of a few dozen entries keep most lanes busy, hub rows just loop.
 constexpr int kCountLanes = 8;
+constexpr int kCountLong = 512;  // entries of a row of A beyond which the whole wave counts it
 
 __global__ __launch_bounds__(256) void spspmm_count_kernel(
     const int64_t *__restrict__ rowptrA, const int64_t *__restrict__ colA,
@@ -70,8 +71,16 @@ __global__ __launch_bounds__(256) void spspmm_count_kernel(
   const int sub = (int)(threadIdx.x & (kCountLanes - 1));
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / kCountLanes;
   int64_t p = 0;
+  int64_t s = 0, e = 0;
   if (i < M) {
-    const int64_t s = rowptrA[i], e = rowptrA[i + 1];
+    s = rowptrA[i];
+    e = rowptrA[i + 1];
+  }
+  // Rows beyond kCountLong entries are left to the whole wave below: with 8 lanes a hub row is a chain of
+  // (entries / 8) x 2 dependent round trips -- the 14 911-entry row of the R-MAT stress operand kept ONE lane group busy
+  // for 0.9 ms, which was the kernel's whole time (0.97 ms for 4 M entries).
+  const bool is_long = e - s > kCountLong;
+  if (!is_long) {
     for (int64_t k = s + sub; k < e; k += kCountLanes) {
       const int64_t c = colA[k];
       p += rowptrB[c + 1] - rowptrB[c];
@@ -79,7 +88,33 @@ __global__ __launch_bounds__(256) void spspmm_count_kernel(
   }
 #pragma unroll
   for (int off = kCountLanes / 2; off > 0; off >>= 1) p += lane_xor(p, off);
-  if (i < M && sub == 0) prod[i] = p;
+  if (i < M && sub == 0 && !is_long) prod[i] = p;
+  unsigned long long todo = __ballot(is_long && sub == 0);
+  const int lane = (int)(threadIdx.x & 63);
+  while (todo != 0ull) {  // (wave-uniform) one long row at a time, 64 lanes x 4 entries in flight
+    const int lead = (int)__builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const int64_t rs = lane_read(s, lead), re = lane_read(e, lead), ri = lane_read(i, lead);
+    int64_t acc = 0;
+    for (int64_t k0 = rs + lane; k0 < re; k0 += 64 * 4) {
+      int64_t c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t k = k0 + 64 * u;
+        c[u] = colA[k < re ? k : re - 1];
+      }
+      int64_t lo[4], hi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        lo[u] = rowptrB[c[u]];
+        hi[u] = rowptrB[c[u] + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += (k0 + 64 * u < re) ? hi[u] - lo[u] : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += lane_xor(acc, off);
+    if (lane == 0) prod[ri] = acc;
+  }
 }
 
 // Column ids of B as 32-bit words (N < 2^32 - 1): the expansion gathers short B rows from all over the

@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out/r5aj
+R=$PWD
+python -m pytest tests/test_api_gpu.py tests/test_configs_gpu.py tests/test_random_cases_gpu.py -q -m gpu -k "spspmm or random" 2>&1 | tail -2
+for rep in 1 2 3; do VARIANT=shipped python scripts/ab_spspmm_r5.py stress c4 2>&1 | grep -v amdgpu.ids | tail -1 >> gpurun_out/r5aj/ab.jsonl; done
+cat gpurun_out/r5aj/ab.jsonl
+cd /tmp && export TMPDIR=/tmp
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r5aj/prof -o stress -- python $R/scripts/ab_spspmm_r5.py stress > $R/gpurun_out/r5aj/prof.log 2>&1
+f=$(find $R/gpurun_out/r5aj/prof -name '*kernel_stats.csv' | head -1); python $R/scripts/kstats.py $f --tsamd | head -14
