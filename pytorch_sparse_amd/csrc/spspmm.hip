@@ -1773,6 +1773,47 @@ __global__ __launch_bounds__(256) void spspmm_large_classify_kernel(const int64_
 
 constexpr int kSmallBinWaves = 8192;  // resident waves of the small-bin kernels (grid-stride over the list)
 
+// The descriptor of a small group is a chain of two dependent round trips (list entry -> the two bin offsets) in front
+// of its first product.  The grid-stride kernels below take it through a two-deep pipeline in registers: while group
+// t is processed, the entry of group t + 2 * grid and the offsets of group t + grid are on their way.
+struct GroupFeed {
+  const int64_t *small, *bin_off;
+  int64_t ns, stride;
+  int64_t e_nxt = -1, e_nn = -1;   // list entries of the next two groups of this wave (-1: none)
+  int64_t task = 0, b0 = 0, b1 = 0;  // current group
+  int nb = 0;
+  int64_t n_task = 0, n_b0 = 0, n_b1 = 0;
+  int n_nb = 0;
+  __device__ __forceinline__ static void decode(int64_t entry, int64_t &task, int &nb) {
+    task = entry & (((int64_t)1 << 40) - 1);
+    nb = (int)(entry >> 40);
+  }
+  __device__ __forceinline__ bool start(int64_t t) {  // -> false: nothing for this wave
+    if (t >= ns) return false;
+    const int64_t e = small[t];
+    e_nxt = t + stride < ns ? small[t + stride] : -1;
+    decode(e, task, nb);
+    b0 = bin_off[task];
+    b1 = bin_off[task + nb];
+    return true;
+  }
+  __device__ __forceinline__ void prefetch(int64_t t) {  // issue the loads of the groups behind group t
+    e_nn = t + 2 * stride < ns ? small[t + 2 * stride] : -1;
+    if (e_nxt >= 0) {
+      decode(e_nxt, n_task, n_nb);
+      n_b0 = bin_off[n_task];
+      n_b1 = bin_off[n_task + n_nb];
+    }
+  }
+  __device__ __forceinline__ void advance() {
+    task = n_task;
+    nb = n_nb;
+    b0 = n_b0;
+    b1 = n_b1;
+    e_nxt = e_nn;
+  }
+};
+
 // symbolic, small groups: distinct columns among the group's products -- an LDS hash set (the columns of a
 // merged group span several ranges, a bitmap of them would not fit), one wave per group
 constexpr int kGroupLogT = kSmallBinCap <= 512 ? 10 : (kSmallBinCap <= 1024 ? 11 : 12);
@@ -1786,23 +1827,27 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_count_kernel(
   const int lane = (int)threadIdx.x;
   for (int w = lane; w < kT; w += 64) tab[w] = kEmptyKey;
   const int64_t ns = (int64_t)*n_small;
-  for (int64_t t = blockIdx.x; t < ns; t += gridDim.x) {
-    const int64_t entry = small[t];
-    const int64_t task = entry & (((int64_t)1 << kGroupShift) - 1);
-    const int nb = (int)(entry >> kGroupShift);
-    const int64_t b0 = bin_off[task];
-    const int n = (int)(bin_off[task + nb] - b0);
+  static_assert(kGroupShift == 40, "GroupFeed::decode");
+  GroupFeed feed{small, bin_off, ns, (int64_t)gridDim.x};
+  if (!feed.start(blockIdx.x)) return;
+  for (int64_t t = blockIdx.x; t < ns; t += gridDim.x, feed.advance()) {
+    feed.prefetch(t);
+    const int64_t task = feed.task;
+    const int64_t b0 = feed.b0;
+    const int n = (int)(feed.b1 - b0);
     __syncthreads();  // (one wave: orders the table resets of the previous group)
     int fresh = 0;
-    for (int q0 = 0; q0 < n; q0 += 64 * 4) {
-      uint32_t c[4];
+    constexpr int kCU = 8;  // columns per lane in flight (a group of 1024 products: two round trips instead of four)
+    for (int q0 = 0; q0 < n; q0 += 64 * kCU) {
+      uint32_t c[kCU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kCU; ++u) {
         const int q = q0 + u * 64 + lane;
-        c[u] = q < n ? bcol[(b0 + q) * bstride] : kEmptyKey;
+        c[u] = bcol[(b0 + (q < n ? q : n - 1)) * bstride];
+        if (q >= n) c[u] = kEmptyKey;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kCU; ++u) {
         if (c[u] == kEmptyKey) continue;
         uint32_t h = (c[u] * 0x9E3779B1u) >> (32 - kGroupLogT);
         for (;;) {
@@ -1839,25 +1884,42 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
   __shared__ int sscan[8];
   const int lane = (int)threadIdx.x;
   const int64_t ns = (int64_t)*n_small;
-  for (int64_t t = blockIdx.x; t < ns; t += gridDim.x) {
-    const int64_t entry = small[t];
-    const int64_t task = entry & (((int64_t)1 << kGroupShift) - 1);
-    const int nb = (int)(entry >> kGroupShift);
-    const int64_t b0 = bin_off[task];
-    const int p = (int)(bin_off[task + nb] - b0);
+  GroupFeed feed{small, bin_off, ns, (int64_t)gridDim.x};
+  if (!feed.start(blockIdx.x)) return;
+  for (int64_t t = blockIdx.x; t < ns; t += gridDim.x, feed.advance()) {
+    feed.prefetch(t);
+    const int64_t task = feed.task;
+    const int64_t b0 = feed.b0;
+    const int p = (int)(feed.b1 - b0);
     const uint32_t col_base = (uint32_t)((task % nr) << kLgRange<T>);
     const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : (p <= 512 ? 8 : (p <= 1024 ? 16 : 32))));
-    for (int q = lane; q < 64 * items; q += 64) {
-      uint32_t k = kEmptyKey;
-      if (q < p) {
-        uint32_t cq;
-        A vq;
-        bin_load<T>(bcol, bval, b0 + q, valC != nullptr, cq, vq);
-        k = ((cq - col_base) << kBinIdxBits) | (uint32_t)q;
-        if (valC != nullptr) sval[q] = vq;
+    // where the group's output goes: asked for NOW (three dependent loads that used to start after the sort)
+    const int64_t r = task / nr;
+    const int64_t out_row = rows[r];
+    const int64_t pref_t = bin_pref[task], pref_r = bin_pref[r * nr];
+    // the group's products, four per lane in flight (one load per loop iteration was one round trip per 64 products:
+    // 16 in a row for a full group)
+    for (int q0 = lane; q0 < 64 * items; q0 += 64 * 4) {
+      uint32_t cq[4];
+      A vq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + 64 * u;
+        bin_load<T>(bcol, bval, b0 + (q < p ? q : p - 1), valC != nullptr, cq[u], vq[u]);
       }
-      skey[q] = k;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + 64 * u;
+        if (q >= 64 * items) continue;
+        uint32_t k = kEmptyKey;
+        if (q < p) {
+          k = ((cq[u] - col_base) << kBinIdxBits) | (uint32_t)q;
+          if (valC != nullptr) sval[q] = vq[u];
+        }
+        skey[q] = k;
+      }
     }
+    const int64_t row_c = rowptrC[out_row];  // (on its way while the group is sorted)
     __syncthreads();
     if (items == 1) sort_lds_keys<1>(skey, lane);
     else if (items == 2) sort_lds_keys<2>(skey, lane);
@@ -1866,8 +1928,7 @@ __global__ __launch_bounds__(64) void spspmm_smallbin_accum_kernel(
     else if (items == 16) sort_lds_keys<16>(skey, lane);
     else if constexpr (kSmallBinCap > 1024) sort_lds_keys<32>(skey, lane);
     __syncthreads();
-    const int64_t r = task / nr;
-    const int64_t out0 = rowptrC[rows[r]] + (bin_pref[task] - bin_pref[r * nr]);
+    const int64_t out0 = row_c + (pref_t - pref_r);
     const uint32_t col0 = col_base;
     compress_and_store<T, 64>(
         p, out0, colC, valC, sscan, [&](int idx) { return col0 + (skey[idx] >> kBinIdxBits); },
