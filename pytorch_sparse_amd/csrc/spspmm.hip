@@ -1221,6 +1221,7 @@ constexpr int kLargeThreads = 256;   // hist / bin kernels: one workgroup per la
 constexpr int kAccumThreads = TSAMD_SPSPMM_ACCUM_THREADS;  // count / accum kernels (persistent, LDS-bound occupancy)
 constexpr int kBinBatch = 4;         // bin entries fetched per thread before they are consumed
 constexpr int kMaxRanges = 8192;         // LDS counters / cursors of the hist and bin kernels
+constexpr int kOffLdsMax = 4096;         // ... up to this many, the bin kernel keeps their segment offsets in LDS as well
 
 template <typename T>
 constexpr int kLgRange = sizeof(typename Traits<T>::acc_t) == 4 ? TSAMD_SPSPMM_LG_RANGE : TSAMD_SPSPMM_LG_RANGE - 1;  // fp32 / fp64 columns per range
@@ -1309,14 +1310,22 @@ __global__ __launch_bounds__(kLargeThreads) void spspmm_large_bin_kernel(
     const int64_t *__restrict__ rows, int lg_range, int nr, int sub, const int64_t *__restrict__ sub_off,
     uint32_t *__restrict__ bcol, T *__restrict__ bval) {
   using A = typename Traits<T>::acc_t;
-  extern __shared__ int cursor[];  // nr * sub cursors, sized at launch (see the hist kernel)
+  extern __shared__ int cursor[];  // nr * sub cursors, sized at launch (see the hist kernel) | the segments' offsets
   __shared__ ExpandScratch<A> sc;
   const int tid = (int)threadIdx.x;
   const int64_t i = rows[blockIdx.x];
   const int nc = nr * sub;
-  for (int q = tid; q < nc; q += kLargeThreads) cursor[q] = 0;
+  // the segment offsets of this row in LDS too: read from global memory inside the emit they were a dependent load
+  // between the cursor atomic and the store of every product
+  // (up to kOffLdsMax counters: 48 KB; beyond that they stay in global memory)
+  const bool off_lds = nc <= kOffLdsMax;
+  int64_t *off_s = reinterpret_cast<int64_t *>(cursor + ((nc + 1) & ~1));
+  for (int q = tid; q < nc; q += kLargeThreads) {
+    cursor[q] = 0;
+    if (off_lds) off_s[q] = sub_off[(int64_t)blockIdx.x * nc + q];
+  }
   __syncthreads();
-  const int64_t *off = sub_off + (int64_t)blockIdx.x * nc;
+  const int64_t *off = off_lds ? off_s : sub_off + (int64_t)blockIdx.x * nc;
   const int lane = tid & 63;
   const int wsel = sub == 1 ? 0 : (tid >> 6);  // this wave's segment of every bin (see the hist kernel)
   expand_row<T, kLargeThreads, WITH_VAL, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
@@ -2046,7 +2055,10 @@ static size_t large_counter_bytes(int nr, int sub) {
     return e != nullptr && e[0] == '1';
   }();
   const size_t n = fat ? (size_t)kMaxRanges : (size_t)nr * (size_t)sub;
-  return (n * sizeof(int) + 255) / 256 * 256;
+  // (the bin kernel keeps an int64 offset beside every cursor when there are at most kOffLdsMax of them; the hist kernel
+  // uses the first part only)
+  const size_t off_bytes = n <= (size_t)kOffLdsMax ? n * sizeof(int64_t) : 0;
+  return (((n + 1) & ~(size_t)1) * sizeof(int) + off_bytes + 255) / 256 * 256;
 }
 
 // valA / valB given (either may be NULL): the products are binned WITH their values, so that the numeric
