@@ -584,18 +584,22 @@ __global__ __launch_bounds__(BLOCK) void spspmm_symbolic_kernel(
   __shared__ ExpandScratch<float> sc;
   __shared__ int s_cnt[BLOCK / 64];
   const int tid = (int)threadIdx.x;
-  int64_t i;
+  int64_t i, as_i, ae_i;
   if constexpr (BLOCK == 64) {  // small rows: every row in natural order, the others are skipped
     i = blockIdx.x;
     const int64_t p = prod[i];
+    as_i = rowptrA[i];  // (requested together with the product count: one round trip, not two)
+    ae_i = rowptrA[i + 1];
     if (p == 0 || p > kSmallCap) return;
   } else {
     i = rows[blockIdx.x];
+    as_i = rowptrA[i];
+    ae_i = rowptrA[i + 1];
   }
   for (int t = tid; t < kT; t += BLOCK) tab[t] = kEmptyKey;
   __syncthreads();
   int fresh = 0;
-  expand_row<float, BLOCK, false>(colA, nullptr, rowptrB, colB, nullptr, rowptrA[i], rowptrA[i + 1], sc,
+  expand_row<float, BLOCK, false>(colA, nullptr, rowptrB, colB, nullptr, as_i, ae_i, sc,
                                   [&](int, uint32_t c, float) {
     uint32_t h = hash_slot<LOG_T>(c, NARROW);
     for (;;) {
@@ -984,8 +988,11 @@ __global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
   __shared__ int sscan[8];
   const int lane = (int)threadIdx.x;
   const int64_t i = blockIdx.x;
-  if (prod[i] == 0 || prod[i] > kSmallCap) return;
-  const int p = (int)prod[i];
+  // everything the row needs that depends on nothing but `i`, requested at once: the product count, the row of A and
+  // the output position (which used to be asked for after the sort)
+  const int64_t p64 = prod[i], as_i = rowptrA[i], ae_i = rowptrA[i + 1], out_i = rowptrC[i];
+  if (p64 == 0 || p64 > kSmallCap) return;
+  const int p = (int)p64;
   const bool with_val = valC != nullptr;
   const int items = p <= 64 ? 1 : (p <= 128 ? 2 : (p <= 256 ? 4 : 8));  // keys per lane
   for (int q = p + lane; q < 64 * items; q += 64) skey[q] = kEmptyKey;   // padding sorts last
@@ -1017,10 +1024,10 @@ __global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
     }
   };
   if (with_val)
-    expand_row_wave<T, true>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+    expand_row_wave<T, true>(colA, valA, rowptrB, colB, valB, as_i, ae_i, sc,
                              [&](int q0, int n, const uint32_t (&c)[4], const A (&v)[4]) { put4(std::true_type{}, q0, n, c, v); });
   else
-    expand_row_wave<T, false>(colA, valA, rowptrB, colB, valB, rowptrA[i], rowptrA[i + 1], sc,
+    expand_row_wave<T, false>(colA, valA, rowptrB, colB, valB, as_i, ae_i, sc,
                               [&](int q0, int n, const uint32_t (&c)[4], const A (&v)[4]) { put4(std::false_type{}, q0, n, c, v); });
 #else
   if (with_val) {
@@ -1041,7 +1048,7 @@ __global__ __launch_bounds__(64) void spspmm_numeric_small_kernel(
   else sort_lds_keys<8>(skey, lane);
   __syncthreads();
   compress_and_store<T, 64>(
-      p, rowptrC[i], colC, valC, sscan, [&](int idx) { return skey[idx] >> kIdxBits; },
+      p, out_i, colC, valC, sscan, [&](int idx) { return skey[idx] >> kIdxBits; },
       [&](int idx) { return sval[skey[idx] & (uint32_t)(kSmallCap - 1)]; });
 }
 
