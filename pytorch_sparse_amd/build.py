@@ -97,8 +97,9 @@ def build_kernels(verbose=True, force=False):
     return lib
 
 
-def build_ops(verbose=True, force=False):
-    """torch_sparse::* operator library (host-only C++, compiled with g++)."""
+def build_ops(verbose=True, force=False, kernels_done=None):
+    """torch_sparse::* operator library (host-only C++, compiled with g++).  kernels_done: a future of
+    build_kernels() to wait for before linking (build_all compiles the two libraries side by side)."""
     import torch
     from torch.utils import cpp_extension as ce
     os.makedirs(OBJDIR, exist_ok=True)
@@ -126,6 +127,8 @@ def build_ops(verbose=True, force=False):
             for out in ex.map(_run, jobs):
                 if out.strip() and verbose:
                     print(out)
+    if kernels_done is not None:
+        kernels_done.result()  # libtsamd.so is linked (or its build raised)
     if force or _newer(lib, objs + [os.path.join(LIBDIR, 'libtsamd.so')]):
         _run(['g++', '-shared', '-fPIC', '-o', lib] + objs +
              ['-L' + LIBDIR, '-ltsamd', '-L' + tlib, '-ltorch', '-ltorch_cpu', '-lc10',
@@ -136,9 +139,12 @@ def build_ops(verbose=True, force=False):
 
 
 def build_all(verbose=True, force=False):
-    k = build_kernels(verbose, force)
-    o = build_ops(verbose, force)
-    return k, o
+    """Both libraries.  The g++ translation units of the operator glue (~1 min of torch headers each) are compiled
+    WHILE hipcc works on the kernels; only the glue's link step waits for libtsamd.so."""
+    with cf.ThreadPoolExecutor(max_workers=2) as ex:
+        fk = ex.submit(build_kernels, verbose, force)
+        fo = ex.submit(build_ops, verbose, force, fk)
+        return fk.result(), fo.result()
 
 
 if __name__ == '__main__':
