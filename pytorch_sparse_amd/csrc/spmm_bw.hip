@@ -576,6 +576,9 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_minmax_bw_kernel(
 // global atomics.  A winner is only trusted to lie inside the chunk (LDS bounds); a foreign arg_out
 // gives a wrong mask, never a wild store.
 // ---------------------------------------------------------------------------
+#ifndef TSAMD_WINREC_LINE_STORES
+#define TSAMD_WINREC_LINE_STORES 1
+#endif
 #ifndef TSAMD_WINREC_ROWS
 #define TSAMD_WINREC_ROWS 2
 #endif
@@ -587,12 +590,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
   using A = typename Traits<T>::acc_t;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   __shared__ uint32_t tile_[kWavesPerBlock][kWave * 4];
+  __shared__ uint32_t meta_[kWavesPerBlock][kWave * 4];
   const int lane = (int)(threadIdx.x & 63);
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t *tile = tile_[wib];
+  uint32_t *meta = meta_[wib];
   const int64_t e0 = ((int64_t)blockIdx.x * kWavesPerBlock + wib) * kWave;
   if (e0 >= E) return;
   const int n = (int)(E - e0 < kWave ? E - e0 : kWave);
+  const bool whole32 = TSAMD_WINREC_LINE_STORES && W == 4u && S == 8u && n == kWave;  // wave-uniform
   const uint32_t ntiles = (K + 63u) >> 6;
   const bool mine = lane < n;
   const uint32_t m_l = mine ? (uint32_t)row[e0 + lane] : 0xFFFFFFFFu;
@@ -657,7 +663,24 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (mine) {
+      if (whole32) {
+        // 32-byte records (K <= 128: four mask words + row id, value, segment bitmap), a full chunk: the chunk's 2 KB go out
+        // as two instructions of 64 x 16 CONTIGUOUS bytes (lane j of half h writes the j-th 16-byte piece of that half:
+        // the mask or the meta part of entry (64 h + j) / 2, read back from LDS).  As two 16-byte stores per lane at a
+        // 32-byte pitch every instruction touched all 32 segments of the block half-filled -- twice the segment touches.
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + lane * 4);
+        z = (v.x != 0u ? 1u : 0u) | (v.y != 0u ? 2u : 0u) | (v.z != 0u ? 4u : 0u) | (v.w != 0u ? 8u : 0u);
+        *reinterpret_cast<u32x4 *>(meta + lane * 4) = u32x4{m_l, vlo, vhi, z};
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *blk = rec + ((uint64_t)b * (uint64_t)E + (uint64_t)e0) * 8u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = h * 64 + lane, ent = j >> 1;
+          const u32x4 piece = *reinterpret_cast<const u32x4 *>(((j & 1) ? meta : tile) + ent * 4);
+          *reinterpret_cast<u32x4 *>(blk + j * 4) = piece;
+        }
+      } else if (mine) {
         const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + lane * 4);
         if (2u * t0 < 32u)  // (words past W stay zero in the tile)
           z |= ((v.x != 0u ? 1u : 0u) | (v.y != 0u ? 2u : 0u) | (v.z != 0u ? 4u : 0u) | (v.w != 0u ? 8u : 0u)) << (2u * t0);
@@ -674,7 +697,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void minmax_winrec_kernel(
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    if (mine) {  // the entry's row id and value behind its mask
+    if (mine && !whole32) {  // the entry's row id and value behind its mask
       if ((W & 3u) == 0) {
         *reinterpret_cast<u32x4 *>(rec_l + W) = u32x4{m_l, vlo, vhi, z};
       } else {
