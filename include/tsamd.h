@@ -337,7 +337,8 @@ int tsamd_segment_reduce_balanced(int dtype, int reduce, const void *value, cons
  *                        adjacent duplicates, key = row * N + col.  counts_out is
  *                        a DEVICE int64[2]; reading it is the caller's one sync.
  *   tsamd_sort_coo       sort-on-construct (storage.py:149-162, utils.py:14-21):
- *                        stable one-sweep radix sort by (row, col) -- the order of row * N + col;
+ *                        stable radix sort by (row, col) -- the order of row * N + col (one most-significant-digit
+ *                        scatter + one in-LDS sort per bucket, or one-sweep LSD passes when a bucket overflows);
  *                        E < 2^32 and bits(M) + bits(N) <= 64, else TSAMD_ERR_UNSUPPORTED; writes the sorted
  *                        row / col (either may be NULL) and the permutation.
  *                        Called with (col, row, E, N, M, NULL, NULL, perm) it
@@ -382,6 +383,14 @@ int tsamd_sort_coo_values(int mode, const int64_t *row, const int64_t *col, int6
                           int64_t *row_out, int64_t *col_out, int64_t *perm_out, int64_t *counts,
                           const void *value, void *value_out, int64_t value_bytes, void *workspace,
                           size_t workspace_bytes, void *stream);
+/* How the radix kernels rank equal digits (what makes the sorts STABLE, i.e. what fixes the permutation the
+ * reference gets from its sort in torch_sparse/storage.py:152-162, 407-416 and the order in which coalesce,
+ * storage.py:431-466, reduces duplicates): 0 = one returning LDS atomic per entry -- a stable rank as long as the
+ * LDS unit serves the lanes of one instruction in ascending order, which a device-side self-test checks the first
+ * time a sort runs in the process -- 1 = ballot matching, independent of that order (slower).  set: -1 = query (runs
+ * the self-test if no sort has run yet: one synchronising round trip of 4 bytes; call it once before capturing a
+ * stream), 0 / 1 = force a mode, 2 = forget the decision and run the self-test again.  Returns the mode in force. */
+int tsamd_sort_rank_mode(int set);
 size_t tsamd_sort_coo_workspace_bytes(int64_t E);
 int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
                    int64_t N, int64_t *row_out, int64_t *col_out, int64_t *perm_out,

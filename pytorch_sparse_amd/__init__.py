@@ -45,6 +45,10 @@ def load_ops():
 
 load_ops()
 hip_version = torch.ops.torch_sparse.cuda_version()
+if torch.cuda.is_available():
+    # the radix sorts rank equal digits by returning LDS atomics when the device serves the lanes of one instruction in
+    # ascending order; the self-test behind this query decides it once, here, so that no later sort synchronises
+    sort_rank_mode = int(torch.ops.tsamd.sort_rank_mode(-1))
 
 from .storage import SparseStorage  # noqa: E402
 from .tensor import SparseTensor  # noqa: E402

@@ -442,6 +442,12 @@ using namespace tsamd;
 
 extern "C" size_t tsamd_sort_coo_workspace_bytes(int64_t E) { return sort_coo_workspace_bytes(E); }
 
+extern "C" int tsamd_sort_rank_mode(int set) {
+  if (set == 0 || set == 1) sort_set_rank_mode(set);
+  else if (set == 2) sort_set_rank_mode(-1);
+  return sort_rank_mode(nullptr);
+}
+
 extern "C" int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
                               int64_t N, int64_t *row_out, int64_t *col_out, int64_t *perm_out,
                               void *workspace, size_t workspace_bytes, void *stream_) {

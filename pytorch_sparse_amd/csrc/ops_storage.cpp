@@ -524,6 +524,9 @@ std::tuple<Tensor, Tensor, Tensor> set_diag_pattern(Tensor row, Tensor col, int6
 
 
 }  // namespace
+
+// tsamd_sort_rank_mode (include/tsamd.h): -1 query / 0, 1 force / 2 re-run the device self-test; returns the mode
+int64_t sort_rank_mode(int64_t set) { return (int64_t)tsamd_sort_rank_mode((int)set); }
 }  // namespace tsamd_ops
 
 using namespace tsamd_ops;
@@ -535,6 +538,7 @@ static auto registry_storage = torch::RegisterOperators()
                            .op("tsamd::sort_coo_values", &sort_coo_values)
                            .op("tsamd::sort_coo_auto", &sort_coo_auto)
                            .op("tsamd::sort_coo_probed", &sort_coo_probed)
+                           .op("tsamd::sort_rank_mode", &sort_rank_mode)
                            .op("tsamd::coalesce_index", &coalesce_index)
                            .op("tsamd::segment_reduce", &segment_reduce)
                            .op("tsamd::spspmm", &spspmm)

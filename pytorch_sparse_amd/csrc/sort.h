@@ -11,6 +11,12 @@ namespace tsamd {
 //   gather_src / gather_dst (nullable): gather_dst[o] = gather_src[perm_out[o]] for arrays of 4- or 8-byte elements,
 //     written by the last pass (the values of the entries ride along instead of a gather through perm_out later).
 // Inputs are not modified; outputs must not alias them.  E < 2^32, bits(M) + bits(N) <= 64.
+// Ranking used by the radix kernels: 0 = one returning LDS atomic per entry (stable when the LDS unit serves the lanes
+// of one instruction in ascending order -- checked on the device by a self-test the first time this is called),
+// 1 = ballot matching (independent of that order).  sort_set_rank_mode(-1) forgets the decision (the next sort runs the
+// self-test again), 0 / 1 force a mode (tests).
+int sort_rank_mode(hipStream_t stream);
+void sort_set_rank_mode(int mode);
 size_t sort_coo_workspace_bytes(int64_t E);
 bool sort_coo_supported(int64_t E, int64_t M, int64_t N);
 int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_out,

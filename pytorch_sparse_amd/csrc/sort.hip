@@ -29,7 +29,8 @@
 #include "common.h"
 #include "sort.h"
 
-#include <cstdlib>
+#include <atomic>
+#include <mutex>
 
 namespace tsamd {
 namespace {
@@ -53,9 +54,6 @@ constexpr int kMinTile = kSortThreads * (TSAMD_SORT_ITEMS < TSAMD_SORT_ITEMS_PAI
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 constexpr int kMaxPasses = 8;
-#ifndef TSAMD_SORT_ATOMIC_RANK
-#define TSAMD_SORT_ATOMIC_RANK 1
-#endif
 #ifndef TSAMD_SORT_TICKET
 #define TSAMD_SORT_TICKET 0
 #endif
@@ -65,6 +63,7 @@ constexpr int kMaxPasses = 8;
 
 // workspace header (zeroed by the one memset of a sort): 64 words
 constexpr int kHdrDescents = 0, kHdrDups = 1, kHdrError = 2, kHdrMaxRow = 3, kHdrMaxCol = 4;
+constexpr int kHdrFast = 5;  // 1 = the bucket path sorts this input (decided by the build kernel's last workgroup)
 [[maybe_unused]] constexpr int kHdrTicket = 8;  // ticket[kMaxPasses], -DTSAMD_SORT_TICKET=1 only
 constexpr int kHdrWords = 64;
 
@@ -93,17 +92,52 @@ int bits_for(int64_t n) {  // bits needed for ids in [0, n)
 }
 
 // ---------------------------------------------------------------------------
+// Bucket path (round 6): ONE most-significant-digit scatter + ONE sort of every bucket inside LDS, instead of
+// ceil(bits / 8) global passes.  The packed word (key << idx_bits | position) is unique per entry, so sorting the
+// words IS the stable sort by key -- the result does not depend on the order in which the scatter fills a bucket.
+//   bucket = word >> shift (the top `bits` bits of the word space that the sizes M, N, E can populate); the build
+//   kernel histograms the buckets beside the pass digits, its last workgroup scans the histogram into the bucket
+//   offsets and DECIDES: every bucket <= the LDS capacity -> hdr[kHdrFast] = 1 and the scatter + bucket-sort kernels
+//   run while the one-sweep passes return at once; otherwise (power-law rows, heavy duplication over few keys, ...)
+//   the two bucket kernels return at once and the one-sweep passes sort as before.  No host sync either way.
+// ---------------------------------------------------------------------------
+constexpr int kBkMaxBits = 11;
+constexpr int kBkMaxBuckets = 1 << kBkMaxBits;
+constexpr int kBkHistCopies = 32;
+#ifndef TSAMD_BK_MIN_ENTRIES
+#define TSAMD_BK_MIN_ENTRIES (1 << 17)  // below: the one-sweep passes (a handful of tiles; the bucket kernels' fixed costs win nothing)
+#endif
+struct BucketPlan {
+  int on;     // 0: the build kernel takes no bucket histogram and never raises kHdrFast
+  int bits;   // log2(#buckets)
+  int shift;  // bucket = word >> shift; the bucket sort orders the `shift` bits below
+  int nb;     // 1 << bits
+  int cap;    // largest bucket the bucket-sort kernel of this launch holds in LDS
+};
+// the bits the bucket sort runs its 8-bit LSD passes over: up to two ranges of the word
+struct SortBits {
+  int n;      // passes that cover every bit below the bucket id, low digit first
+  int n_top;  // the last n_top of them cover the bits from `lo` up: sorted first, the rest settled by the finish step
+  int lo;
+  unsigned char shift[12], width[12];
+};
+
+// ---------------------------------------------------------------------------
 // build: words (or keys) + every pass's digit histogram (+ the order probe) in one read of (row, col)
 // ---------------------------------------------------------------------------
 constexpr int kBuildThreads = 1024;
 __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
     const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t n, KeyLayout L,
     unsigned long long *__restrict__ words, unsigned long long *__restrict__ hist /* [passes][256] */,
-    unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo, int probe) {
+    unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo, int probe, BucketPlan B,
+    unsigned int *__restrict__ bhist) {
   if (todo != nullptr && *todo == 0) return;
   __shared__ unsigned int cnt[kMaxPasses][kRadix];
+  __shared__ unsigned int bcnt[kBkMaxBuckets];
   for (int p = 0; p < L.passes; ++p)
     if (threadIdx.x < kRadix) cnt[p][threadIdx.x] = 0;
+  if (B.on)
+    for (int b = (int)threadIdx.x; b < B.nb; b += kBuildThreads) bcnt[b] = 0;
   __syncthreads();
   unsigned int desc = 0, dup = 0;
   unsigned long long mr = 0, mc = 0;  // probe == 2: the range check's maxima (unsigned: a negative id reads as huge)
@@ -156,6 +190,16 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
           atomicAdd(&cnt[p][d], 1u);
         }
       }
+      if (B.on) {  // (packed words only)
+        const unsigned int b = (unsigned int)(((key << L.idx_bits) | (unsigned long long)i) >> B.shift);
+        const unsigned int b0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+        const unsigned long long act = __ballot(ok[u]);
+        if (__ballot(ok[u] && b == b0) == act) {
+          if (lane == 0 && act) atomicAdd(&bcnt[b0], (unsigned int)__popcll(act));
+        } else if (ok[u]) {
+          atomicAdd(&bcnt[b], 1u);
+        }
+      }
     }
   }
   __syncthreads();
@@ -200,6 +244,80 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
       }
     }
   }
+  if (!B.on) return;
+  // bucket histogram -> global (bucket_plan_kernel turns it into offsets and decides the route)
+  // (kBkHistCopies copies of the histogram, one per residue of the workgroup id: 512 workgroups adding to the same
+  // 128 cache lines queued for ~150 us on the lines' atomic units; 16 adds per line and copy do not)
+  {
+    unsigned int *mine = bhist + (size_t)(blockIdx.x % kBkHistCopies) * kBkMaxBuckets;
+    for (int b = (int)threadIdx.x; b < B.nb; b += kBuildThreads) {
+      const unsigned int c = bcnt[b];
+      if (c) atomicAdd(&mine[b], c);
+    }
+  }
+}
+
+// The bucket histogram -> bucket offsets, the scatter cursors and the decision (one workgroup; a kernel of its own
+// because the alternative -- the build kernel's last workgroup -- needs a device-scope release fence in EVERY build
+// workgroup, which on this part writes the workgroup's XCD L2 back: the build kernel went from 46 to 200 us).
+__global__ __launch_bounds__(kBuildThreads) void bucket_plan_kernel(
+    const unsigned int *__restrict__ bhist, unsigned int *__restrict__ boff, unsigned int *__restrict__ cursor,
+    unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo, int probe, BucketPlan B, int64_t n) {
+  if (todo != nullptr && *todo == 0) return;  // (hdr[kHdrFast] stays 0: the passes write the copy + identity)
+  const int lane = (int)(threadIdx.x & 63);
+  constexpr int kPer = kBkMaxBuckets / kBuildThreads > 0 ? kBkMaxBuckets / kBuildThreads : 1;
+  unsigned int c[kPer], sum = 0, mx = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const int b = (int)threadIdx.x * kPer + j;
+    c[j] = 0;
+    if (b < B.nb) {
+      unsigned int part[kBkHistCopies];
+#pragma unroll
+      for (int r = 0; r < kBkHistCopies; ++r) part[r] = bhist[(size_t)r * kBkMaxBuckets + b];
+#pragma unroll
+      for (int r = 0; r < kBkHistCopies; ++r) c[j] += part[r];
+    }
+    sum += c[j];
+    mx = c[j] > mx ? c[j] : mx;
+  }
+  // exclusive scan of `sum` over the 1024 threads + the block maximum
+  unsigned int inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int o = lane_read(inc, lane >= off ? lane - off : lane);
+    if (lane >= off) inc += o;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned int o = lane_xor(mx, off);
+    mx = o > mx ? o : mx;
+  }
+  __shared__ unsigned int s_wsum[kBuildThreads / 64], s_wmax[kBuildThreads / 64];
+  if (lane == 63) s_wsum[threadIdx.x >> 6] = inc;
+  if (lane == 0) s_wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  unsigned int base = 0, gmx = 0;
+  for (int ww = 0; ww < kBuildThreads / 64; ++ww) {
+    if (ww < (int)(threadIdx.x >> 6)) base += s_wsum[ww];
+    gmx = s_wmax[ww] > gmx ? s_wmax[ww] : gmx;
+  }
+  unsigned int run = base + inc - sum;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const int b = (int)threadIdx.x * kPer + j;
+    if (b < B.nb) {
+      boff[b] = run;
+      cursor[b] = run;
+      run += c[j];
+    }
+  }
+  if (threadIdx.x == 0) {
+    boff[B.nb] = (unsigned int)n;
+    bool fast = gmx <= (unsigned int)B.cap;
+    // an input without descents is not sorted at all (the passes' last kernel writes the copy + identity)
+    if (probe && hdr[kHdrDescents] == 0ull) fast = false;
+    hdr[kHdrFast] = fast ? 1ull : 0ull;
+  }
 }
 
 // exclusive scan of one value per thread over a 256-thread block (u64); smem: 4 words
@@ -228,7 +346,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long 
 // the first pass reads it in input order (`gather_src[e]`: the entry at position e of the first pass IS entry e), the
 // last pass stores it next to the decoded ids -- instead of being gathered through the permutation by the last pass
 // (7.5 M random 4-byte reads: +125 us, against +12 bytes per entry and pass of streamed traffic).
-template <bool PACKED, bool LAST, bool VAL = false>
+template <bool PACKED, bool LAST, bool VAL = false, bool BALLOT = false>
 __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
     const unsigned long long *__restrict__ in, const unsigned int *__restrict__ idx_in,
     unsigned long long *__restrict__ out, unsigned int *__restrict__ idx_out, int64_t *__restrict__ row_out,
@@ -241,6 +359,7 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
   constexpr bool kPayload = !PACKED || VAL;  // a 32-bit word travels beside the 64-bit one
   constexpr int kSortItems = kItemsOf<PACKED, VAL>;
   constexpr int kSortTile = kSortThreads * kSortItems;
+  if (hdr[kHdrFast] != 0) return;  // the bucket path has sorted this input
   if constexpr (LAST) {  // the probe's counters travel with the last pass (no separate kernel)
     if (counts_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
       counts_out[0] = (int64_t)hdr[kHdrDescents];
@@ -304,38 +423,38 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
     dig[i] = (unsigned int)(word[i] >> shift) & (kRadix - 1);
   }
   // rank of every entry among the equal digits of its wave, in input order
-#if TSAMD_SORT_ATOMIC_RANK
-  // One returning LDS atomic per entry.  When several lanes of ONE ds_add_rtn hit the same counter the LDS unit
-  // serves them in ascending lane order on gfx950, so the value returned is the stable rank (tests/test_sort_gpu.py
-  // pins the exact stable permutation on inputs made of a few hot keys; -DTSAMD_SORT_ATOMIC_RANK=0 selects the
-  // ballot matching below, which does not depend on that order but issues ~190 instead of ~40 instructions per
-  // entry and pass: 60 vs ~30 us per pass at 7.5 M entries).
+  if constexpr (!BALLOT) {
+    // One returning LDS atomic per entry.  When several lanes of ONE ds_add_rtn hit the same counter the LDS unit
+    // serves them in ascending lane order on gfx950, so the value returned is the stable rank.  That order is not
+    // an ISA guarantee: `sort_selftest_kernel` checks it once per process on the device and the host launches the
+    // BALLOT instantiation (ballot matching: independent of the order, ~190 instead of ~40 instructions per entry
+    // and pass) when the check fails; tests/test_sort_gpu.py forces both and compares the permutations.
 #pragma unroll
-  for (int i = 0; i < kSortItems; ++i) {
-    lrank[i] = 0;
-    if (valid[i]) lrank[i] = atomicAdd(&cnt[w][dig[i]], 1u);
-  }
-#else
-#pragma unroll
-  for (int i = 0; i < kSortItems; ++i) {
-    unsigned long long peers = __ballot(valid[i]);
-#pragma unroll
-    for (int b = 0; b < kRadixBits; ++b) {
-      const bool bit = (dig[i] >> b) & 1u;
-      const unsigned long long m = __ballot(valid[i] && bit);
-      peers &= bit ? m : ~m;
+    for (int i = 0; i < kSortItems; ++i) {
+      lrank[i] = 0;
+      if (valid[i]) lrank[i] = atomicAdd(&cnt[w][dig[i]], 1u);
     }
-    const unsigned int rank = (unsigned int)__popcll(peers & ((1ull << lane) - 1ull));
-    const int leader = valid[i] ? (__ffsll((long long)peers) - 1) : lane;
-    unsigned int pre = 0;
-    if (valid[i] && lane == leader) {
-      pre = cnt[w][dig[i]];
-      cnt[w][dig[i]] = pre + (unsigned int)__popcll(peers);
+  } else {
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+      unsigned long long peers = __ballot(valid[i]);
+#pragma unroll
+      for (int b = 0; b < kRadixBits; ++b) {
+        const bool bit = (dig[i] >> b) & 1u;
+        const unsigned long long m = __ballot(valid[i] && bit);
+        peers &= bit ? m : ~m;
+      }
+      const unsigned int rank = (unsigned int)__popcll(peers & ((1ull << lane) - 1ull));
+      const int leader = valid[i] ? (__ffsll((long long)peers) - 1) : lane;
+      unsigned int pre = 0;
+      if (valid[i] && lane == leader) {
+        pre = cnt[w][dig[i]];
+        cnt[w][dig[i]] = pre + (unsigned int)__popcll(peers);
+      }
+      pre = lane_read(pre, leader);
+      lrank[i] = pre + rank;
     }
-    pre = lane_read(pre, leader);
-    lrank[i] = pre + rank;
   }
-#endif
   __syncthreads();
 
   // thread t owns digit t
@@ -484,6 +603,412 @@ __global__ void sort_identity_kernel(const int64_t *__restrict__ row, const int6
   perm_out[i] = i;
 }
 
+// ---------------------------------------------------------------------------
+// Is the returning LDS atomic a stable rank on this device?  One wave per workgroup, 24 collision patterns (all lanes
+// on one counter ... all lanes on different counters, strided, hashed): the value a lane gets back from ONE
+// ds_add_rtn must be the number of LOWER lanes that hit the same counter.  flag[0] |= 1 when it is not.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sort_selftest_kernel(unsigned int *__restrict__ flag) {
+  __shared__ unsigned int c[64];
+  const int lane = (int)threadIdx.x;
+  unsigned int bad = 0;
+  for (int t = 0; t < 24; ++t) {
+    c[lane] = 0;
+    unsigned int d;
+    if (t == 0) d = 0;
+    else if (t < 8) d = (unsigned int)lane % (unsigned int)(t + 1);            // 2 .. 8 counters, interleaved
+    else if (t < 14) d = (unsigned int)lane >> (t - 8);                         // runs of 1 .. 32 lanes
+    else if (t < 23) d = (((unsigned int)lane + blockIdx.x) * 2654435761u >> (t + 3)) & (t & 1 ? 7u : 63u);  // hashed
+    else d = (unsigned int)lane;
+    d &= 63u;
+    const unsigned int got = atomicAdd(&c[d], 1u);
+    unsigned long long peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const unsigned int want = (unsigned int)__popcll(peers & ((1ull << lane) - 1ull));
+    bad |= got != want;
+    // the packed form of the bucket sort: two 16-bit counters per word, neighbours collide on one address
+    c[lane] = 0;
+    const unsigned int sh = (d & 1u) * 16u;
+    const unsigned int got2 = (atomicAdd(&c[d >> 1], 1u << sh) >> sh) & 0xffffu;
+    bad |= got2 != want;
+  }
+  if (__ballot(bad != 0) != 0ull && lane == 0) atomicOr(flag, 1u);
+}
+
+// ---------------------------------------------------------------------------
+// bucket path, kernel 1 of 2: scatter the words into their buckets.  A tile counts its entries per bucket in LDS
+// (any distinct rank inside the tile will do: the order inside a bucket is irrelevant, see above), reserves a run in
+// every bucket with ONE global atomic per (tile, bucket) -- 64 neighbouring cursors per wave instruction -- and
+// writes the tile bucket by bucket (reordered in LDS first, so that a run is one contiguous store).
+// ---------------------------------------------------------------------------
+constexpr int kBkScatterThreads = 256;
+#ifndef TSAMD_BK_SCATTER_ITEMS
+#define TSAMD_BK_SCATTER_ITEMS 30      // 8-byte entries: 60 KB + 16 KB of counters -> two workgroups per CU
+#endif
+#ifndef TSAMD_BK_SCATTER_ITEMS_VAL
+#define TSAMD_BK_SCATTER_ITEMS_VAL 20  // 12-byte entries
+#endif
+template <bool VAL>
+constexpr int kBkScatterItems = VAL ? TSAMD_BK_SCATTER_ITEMS_VAL : TSAMD_BK_SCATTER_ITEMS;
+
+// (LDS index of bucket b: one pad word per 32 buckets, so that "thread t scans buckets 8t .. 8t + 7" is not a
+// 16-way bank conflict)
+__device__ __forceinline__ unsigned int bk_slot(unsigned int b) { return b + (b >> 5); }
+
+template <bool VAL>
+__global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
+    const unsigned long long *__restrict__ in, const unsigned int *__restrict__ val_in, int64_t n, BucketPlan B,
+    unsigned int *__restrict__ cursor, unsigned long long *__restrict__ out, unsigned int *__restrict__ val_out,
+    const unsigned long long *__restrict__ hdr) {
+  if (hdr[kHdrFast] == 0) return;
+  constexpr int kItems = kBkScatterItems<VAL>;
+  constexpr int kTile = kBkScatterThreads * kItems;
+  constexpr int kPer = kBkMaxBuckets / kBkScatterThreads;
+  constexpr int kSlots = kBkMaxBuckets + kBkMaxBuckets / 32;
+  __shared__ unsigned long long sword[kTile];
+  __shared__ unsigned int sval[VAL ? kTile : 1];
+  __shared__ unsigned int cnt[kSlots];   // entries of the tile per bucket, later: first output slot - first LDS slot
+  __shared__ unsigned int loff[kSlots];  // first LDS slot of the bucket's run
+  __shared__ unsigned int s_wsum[kBkScatterThreads / 64];
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int b = tid; b < kSlots; b += kBkScatterThreads) cnt[b] = 0;
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * kTile;
+  const int count = n - tile0 < kTile ? (int)(n - tile0) : kTile;
+  unsigned long long word[kItems];
+  unsigned int val[VAL ? kItems : 1], rank[kItems];
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int j = i * kBkScatterThreads + tid;
+    word[i] = j < count ? in[tile0 + j] : 0ull;
+    if constexpr (VAL) val[i] = j < count ? val_in[tile0 + j] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int j = i * kBkScatterThreads + tid;
+    rank[i] = 0;
+    if (j < count) rank[i] = atomicAdd(&cnt[bk_slot((unsigned int)(word[i] >> B.shift))], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the counts in bucket order: thread t takes the kPer buckets from t * kPer on
+  unsigned int c[kPer], sum = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const unsigned int b = (unsigned int)(tid * kPer + j);
+    c[j] = (int)b < B.nb ? cnt[bk_slot(b)] : 0u;
+    sum += c[j];
+  }
+  unsigned int inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int o = lane_read(inc, lane >= off ? lane - off : lane);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) s_wsum[w] = inc;
+  __syncthreads();
+  unsigned int run = inc - sum;
+#pragma unroll
+  for (int ww = 0; ww < kBkScatterThreads / 64; ++ww)
+    if (ww < w) run += s_wsum[ww];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const unsigned int b = (unsigned int)(tid * kPer + j);
+    if ((int)b < B.nb) loff[bk_slot(b)] = run;
+    run += c[j];
+  }
+  __syncthreads();
+  // reserve the runs: bucket k * 256 + t (neighbouring cursors per wave instruction); the results are needed last
+  unsigned int gbase[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const unsigned int b = (unsigned int)(k * kBkScatterThreads + tid);
+    const unsigned int cb = (int)b < B.nb ? cnt[bk_slot(b)] : 0u;
+    gbase[k] = cb ? atomicAdd(&cursor[b], cb) : 0u;
+  }
+  // reorder the tile by bucket in LDS
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int j = i * kBkScatterThreads + tid;
+    if (j < count) {
+      const unsigned int pos = loff[bk_slot((unsigned int)(word[i] >> B.shift))] + rank[i];
+      sword[pos] = word[i];
+      if constexpr (VAL) sval[pos] = val[i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const unsigned int b = (unsigned int)(k * kBkScatterThreads + tid);
+    if ((int)b < B.nb) cnt[bk_slot(b)] = gbase[k] - loff[bk_slot(b)];  // (modulo 2^32: E < 2^32)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int j = i * kBkScatterThreads + tid;
+    if (j >= count) break;
+    const unsigned long long wd = sword[j];
+    const unsigned int o = cnt[bk_slot((unsigned int)(wd >> B.shift))] + (unsigned int)j;
+    out[o] = wd;
+    if constexpr (VAL) val_out[o] = sval[j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bucket path, kernel 2 of 2: one workgroup sorts one bucket inside LDS and writes the decoded rows / columns /
+// permutation (and the value that rode along) as one contiguous, coalesced piece of the output.
+//   1. 8-bit LSD passes over the TOP `SB.n_top` digits below the bucket id (16 bits: a bucket of a few thousand
+//      entries falls into ~65 k groups), entries in registers between the passes: wave w owns a contiguous segment of
+//      the bucket and ranks by one returning LDS atomic per entry on a per-wave counter (two 16-bit counters per
+//      word); the BALLOT instantiation ranks by ballot matching (see the pass kernel);
+//   2. FINISH: what is left to order are the entries that agree in all of those bits -- neighbours in LDS now.  Every
+//      entry counts the larger words of its group to its left and the smaller ones to its right (full 64-bit compare:
+//      words are unique) and moves to `j - greater + smaller`.  Typically zero or one neighbour;
+//   3. a group longer than kBkGroupMax (many duplicates of one key, a dense block) makes the workgroup sort the whole
+//      bucket by LSD passes over ALL the bits below the bucket id instead (SB.n passes): fixed cost, any input.
+// ---------------------------------------------------------------------------
+constexpr int kBkGroupMax = 24;
+
+template <int THREADS, int ITEMS, bool VAL, bool BALLOT>
+__global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kernel(
+    const unsigned long long *__restrict__ in, const unsigned int *__restrict__ val_in,
+    const unsigned int *__restrict__ boff, SortBits SB, KeyLayout L, int64_t *__restrict__ row_out,
+    int64_t *__restrict__ col_out, int64_t *__restrict__ perm_out, const unsigned long long *__restrict__ hdr,
+    int64_t *__restrict__ counts_out, int check4, const void *__restrict__ gather_src, void *__restrict__ gather_dst,
+    int gather_bytes) {
+  if (hdr[kHdrFast] == 0) return;
+  if (counts_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // the probe's counters (see the last pass kernel)
+    counts_out[0] = (int64_t)hdr[kHdrDescents];
+    counts_out[1] = (int64_t)hdr[kHdrDups];
+    if (check4) {
+      counts_out[2] = (int64_t)hdr[kHdrMaxRow];
+      counts_out[3] = (int64_t)hdr[kHdrMaxCol];
+    }
+  }
+  constexpr int kW = THREADS / 64, kCap = THREADS * ITEMS;
+  static_assert(THREADS >= 128 && kCap < 65536, "two waves scan the digits; 16-bit counters");
+  __shared__ unsigned long long sword[kCap];
+  __shared__ unsigned int sval[VAL ? kCap : 1];
+  __shared__ unsigned int cnt[kW][kRadix / 2];
+  __shared__ unsigned int dig_off[kRadix];
+  __shared__ unsigned int s_w0, s_over;
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned int start = boff[blockIdx.x];
+  const int n = (int)(boff[blockIdx.x + 1] - start);
+  if (n == 0) return;
+  if (tid == 0) s_over = 0;
+  // wave w owns the entries [w * seg, (w + 1) * seg), seg a multiple of 64: the waves share the bucket evenly
+  const int seg = (((n + kW - 1) / kW) + 63) & ~63;
+  const int items = seg >> 6;  // <= ITEMS because n <= kCap
+  const int wbase = w * seg;
+  unsigned long long word[ITEMS];
+  unsigned int val[VAL ? ITEMS : 1];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    word[i] = 0ull;
+    if constexpr (VAL) val[i] = 0u;
+    const int e = wbase + i * 64 + lane;
+    if (i < items && e < n) {
+      word[i] = in[start + e];
+      if constexpr (VAL) val[i] = val_in[start + e];
+    }
+  }
+  // LSD passes p0 .. p1 - 1 of SB over the entries in registers; leaves the result in sword / sval (LDS)
+  auto lsd_passes = [&](int p0, int p1) {
+    for (int p = p0; p < p1; ++p) {
+      const int shift = SB.shift[p];
+      const unsigned int mask = (1u << SB.width[p]) - 1u;
+      unsigned int lrank[ITEMS];
+      cnt[w][lane] = 0;  // this wave's counters (wave-local: LDS operations of one wave stay in order)
+      cnt[w][lane + 64] = 0;
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        lrank[i] = 0;
+        if (i < items) {
+          const bool valid = wbase + i * 64 + lane < n;
+          const unsigned int d = (unsigned int)(word[i] >> shift) & mask;
+          const unsigned int sh = (d & 1u) * 16u;
+          if constexpr (!BALLOT) {
+            if (valid) lrank[i] = (atomicAdd(&cnt[w][d >> 1], 1u << sh) >> sh) & 0xffffu;
+          } else {
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < kRadixBits; ++b) {
+              const bool bit = (d >> b) & 1u;
+              const unsigned long long m = __ballot(valid && bit);
+              peers &= bit ? m : ~m;
+            }
+            const unsigned int rank = (unsigned int)__popcll(peers & ((1ull << lane) - 1ull));
+            const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+            unsigned int pre = 0;
+            if (valid && lane == leader) pre = (atomicAdd(&cnt[w][d >> 1], (unsigned int)__popcll(peers) << sh) >> sh) & 0xffffu;
+            pre = lane_read(pre, leader);
+            lrank[i] = pre + rank;
+          }
+        }
+      }
+      __syncthreads();
+      // thread t < 128 owns the digits 2t and 2t + 1: exclusive prefix over the waves, then over the digits
+      if (tid < kRadix / 2) {
+        unsigned int run0 = 0, run1 = 0;
+#pragma unroll
+        for (int ww = 0; ww < kW; ++ww) {
+          const unsigned int v = cnt[ww][tid];
+          cnt[ww][tid] = run0 | (run1 << 16);
+          run0 += v & 0xffffu;
+          run1 += v >> 16;
+        }
+        const unsigned int both = run0 + run1;
+        unsigned int inc = both;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned int o = lane_read(inc, lane >= off ? lane - off : lane);
+          if (lane >= off) inc += o;
+        }
+        if (tid == 63) s_w0 = inc;
+        dig_off[2 * tid] = inc - both;
+        dig_off[2 * tid + 1] = inc - both + run0;
+      }
+      __syncthreads();
+      if (tid >= 64 && tid < kRadix / 2) {  // the second wave's digits start behind the first wave's
+        const unsigned int b0 = s_w0;
+        dig_off[2 * tid] += b0;
+        dig_off[2 * tid + 1] += b0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        if (i < items && wbase + i * 64 + lane < n) {
+          const unsigned int d = (unsigned int)(word[i] >> shift) & mask;
+          const unsigned int pos = dig_off[d] + ((cnt[w][d >> 1] >> ((d & 1u) * 16u)) & 0xffffu) + lrank[i];
+          sword[pos] = word[i];
+          if constexpr (VAL) sval[pos] = val[i];
+        }
+      }
+      __syncthreads();
+      if (p + 1 < p1) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+          const int e = wbase + i * 64 + lane;
+          if (i < items && e < n) {
+            word[i] = sword[e];
+            if constexpr (VAL) val[i] = sval[e];
+          }
+        }
+        // (the next pass's scatter into sword comes two barriers later)
+      }
+    }
+  };
+  const int p_top = SB.n - SB.n_top;  // the top digits are the last n_top passes of the list
+  lsd_passes(p_top, SB.n);
+  if (p_top > 0) {
+    // FINISH: groups = runs of entries that agree in every bit from SB.lo up
+    const int lo = SB.lo;
+    unsigned long long fw[ITEMS];
+    unsigned int fv[VAL ? ITEMS : 1];
+    int fpos[ITEMS];
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int j = k * THREADS + tid;
+      fpos[k] = -1;
+      fw[k] = 0ull;
+      if (k * THREADS < n && j < n) {
+        const unsigned long long x = sword[j];
+        const unsigned long long pre = x >> lo;
+        int gt = 0, lt = 0, len = 0;
+        for (int q = j - 1; q >= 0; --q) {
+          const unsigned long long y = sword[q];
+          if ((y >> lo) != pre) break;
+          gt += y > x;
+          if (++len > kBkGroupMax) break;
+        }
+        for (int q = j + 1; q < n; ++q) {
+          const unsigned long long y = sword[q];
+          if ((y >> lo) != pre) break;
+          lt += y < x;
+          if (++len > kBkGroupMax) break;
+        }
+        over |= len > kBkGroupMax;
+        fw[k] = x;
+        if constexpr (VAL) fv[k] = sval[j];
+        fpos[k] = j - gt + lt;
+      }
+    }
+    if (over) s_over = 1;
+    __syncthreads();
+    if (s_over == 0) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        if (fpos[k] >= 0) {
+          sword[fpos[k]] = fw[k];
+          if constexpr (VAL) sval[fpos[k]] = fv[k];
+        }
+      }
+    } else {
+      // a long group: the whole bucket by LSD passes over every bit below the bucket id (stable, any input)
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        const int e = wbase + i * 64 + lane;
+        if (i < items && e < n) {
+          word[i] = sword[e];
+          if constexpr (VAL) val[i] = sval[e];
+        }
+      }
+      __syncthreads();
+      lsd_passes(0, SB.n);
+    }
+    __syncthreads();
+  }
+  // decoded output, coalesced
+  const unsigned long long imask = (1ull << L.idx_bits) - 1ull, cmask = (1ull << L.col_bits) - 1ull;
+  constexpr int kBatch = 4;
+  for (int j0 = tid; j0 < n; j0 += THREADS * kBatch) {
+    unsigned long long key[kBatch], e[kBatch];
+    bool ok[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int j = j0 + k * THREADS;
+      ok[k] = j < n;
+      const unsigned long long wd = sword[ok[k] ? j : 0];
+      key[k] = wd >> L.idx_bits;
+      e[k] = wd & imask;
+    }
+    if constexpr (VAL) {
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k)
+        if (ok[k]) reinterpret_cast<uint32_t *>(gather_dst)[start + j0 + k * THREADS] = sval[j0 + k * THREADS];
+    } else if (gather_dst != nullptr) {
+      if (gather_bytes == 4) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) v[k] = reinterpret_cast<const uint32_t *>(gather_src)[ok[k] ? e[k] : 0];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+          if (ok[k]) reinterpret_cast<uint32_t *>(gather_dst)[start + j0 + k * THREADS] = v[k];
+      } else {
+        uint64_t v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) v[k] = reinterpret_cast<const uint64_t *>(gather_src)[ok[k] ? e[k] : 0];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+          if (ok[k]) reinterpret_cast<uint64_t *>(gather_dst)[start + j0 + k * THREADS] = v[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      if (!ok[k]) continue;
+      const size_t o = (size_t)start + (size_t)(j0 + k * THREADS);
+      if (row_out) row_out[o] = (int64_t)(key[k] >> L.col_bits);
+      if (col_out) col_out[o] = (int64_t)(key[k] & cmask);
+      perm_out[o] = (int64_t)e[k];
+    }
+  }
+}
+
 KeyLayout layout_for(int64_t E, int64_t M, int64_t N) {
   KeyLayout L;
   L.col_bits = bits_for(N > 0 ? N : 1);
@@ -494,10 +1019,73 @@ KeyLayout layout_for(int64_t E, int64_t M, int64_t N) {
   return L;
 }
 
+// bucket-sort launch shapes: (threads, entries per thread); the capacity is their product
+#ifndef TSAMD_BK_SORT_THREADS
+#define TSAMD_BK_SORT_THREADS 512
+#endif
+#ifndef TSAMD_BK_SORT_ITEMS
+#define TSAMD_BK_SORT_ITEMS 16      // 8192 entries: 64 KB of words + counters -> two workgroups per CU
+#endif
+#ifndef TSAMD_BK_SORT_ITEMS_VAL
+#define TSAMD_BK_SORT_ITEMS_VAL 12  // 6144 entries of 12 bytes
+#endif
+#ifndef TSAMD_BK_FILL_PCT
+#define TSAMD_BK_FILL_PCT 70        // planned mean fill of a bucket, per cent of the capacity
+#endif
+
+BucketPlan plan_buckets(int64_t E, int64_t M, int64_t N, const KeyLayout &L, bool val) {
+  BucketPlan B{0, 0, 0, 0, 0};
+  if (!L.packed || E < TSAMD_BK_MIN_ENTRIES) return B;
+  const int total = L.key_bits + L.idx_bits;
+  if (total < 2) return B;
+  B.cap = TSAMD_BK_SORT_THREADS * (val ? TSAMD_BK_SORT_ITEMS_VAL : TSAMD_BK_SORT_ITEMS);
+  // the part of the word space [0, 2^total) that the sizes can populate: words <= maxword
+  const unsigned long long maxkey = (((unsigned long long)(M > 0 ? M - 1 : 0)) << L.col_bits) | (unsigned long long)(N > 0 ? N - 1 : 0);
+  const long double maxword = (long double)((maxkey << L.idx_bits) | (unsigned long long)(E - 1)) + 1.0L;
+  const long double frac = maxword / ((long double)(1ull << (total - 1)) * 2.0L);
+  for (int bits = 1; bits <= kBkMaxBits && bits <= total; ++bits) {
+    const long double populated = frac * (long double)(1 << bits);
+    const long double fill = (long double)E / (populated < 1.0L ? 1.0L : populated);
+    if (fill * 100.0L <= (long double)B.cap * TSAMD_BK_FILL_PCT) {
+      B.on = 1;
+      B.bits = bits;
+      B.nb = 1 << bits;
+      B.shift = total - bits;
+      return B;
+    }
+  }
+  return B;
+}
+
+// LSD passes over the bits [0, hi) of the word: the top kBkTopBits in 8-bit digits (n_top passes, from `lo` up), the
+// bits below in 8-bit digits from 0 (only run when the finish step meets a long group)
+#ifndef TSAMD_BK_TOP_BITS
+#define TSAMD_BK_TOP_BITS 16
+#endif
+SortBits sort_bits_for(int hi) {
+  SortBits sb;
+  sb.n = 0;
+  sb.lo = hi > TSAMD_BK_TOP_BITS ? hi - TSAMD_BK_TOP_BITS : 0;
+  for (int lo = 0; lo < sb.lo; lo += kRadixBits) {
+    sb.shift[sb.n] = (unsigned char)lo;
+    sb.width[sb.n] = (unsigned char)(sb.lo - lo < kRadixBits ? sb.lo - lo : kRadixBits);
+    ++sb.n;
+  }
+  sb.n_top = 0;
+  for (int lo = sb.lo; lo < hi; lo += kRadixBits) {
+    sb.shift[sb.n] = (unsigned char)lo;
+    sb.width[sb.n] = (unsigned char)(hi - lo < kRadixBits ? hi - lo : kRadixBits);
+    ++sb.n;
+    ++sb.n_top;
+  }
+  return sb;
+}
+
 struct SortWs {
   unsigned long long *hdr, *hist, *tile_state, *a, *b;
   unsigned int *ia, *ib;
-  size_t zero_bytes;  // hdr + hist + tile_state are contiguous: one memset
+  unsigned int *bhist, *boff, *cursor;
+  size_t zero_bytes;  // hdr + hist + bhist + tile_state are contiguous: one memset
 };
 
 size_t carve_sort(void *base, int64_t E, SortWs *ws) {
@@ -513,8 +1101,11 @@ size_t carve_sort(void *base, int64_t E, SortWs *ws) {
   SortWs w;
   w.hdr = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * kHdrWords));
   w.hist = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * kMaxPasses * kRadix));
+  w.bhist = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxBuckets * kBkHistCopies));
   w.tile_state = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * ntiles * kRadix));
   w.zero_bytes = off;
+  w.boff = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * (kBkMaxBuckets + 1)));
+  w.cursor = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxBuckets));
   w.a = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * n));
   w.b = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * n));
   w.ia = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * n));
@@ -523,7 +1114,42 @@ size_t carve_sort(void *base, int64_t E, SortWs *ws) {
   return off;
 }
 
+// 0 = returning LDS atomics are a stable rank (checked on the device), 1 = ballot matching; -1 = not decided yet
+std::atomic<int> g_rank_mode{-1};
+std::mutex g_rank_mutex;
+
 }  // namespace
+
+// The ranking the radix kernels use.  The first call runs `sort_selftest_kernel` (one synchronising round trip of
+// a few words; callers that must not synchronise -- stream capture -- call tsamd_sort_selftest() beforehand, the
+// Python package does at import).
+int sort_rank_mode(hipStream_t) {
+  int m = g_rank_mode.load(std::memory_order_acquire);
+  if (m >= 0) return m;
+  std::lock_guard<std::mutex> lock(g_rank_mutex);
+  m = g_rank_mode.load(std::memory_order_acquire);
+  if (m >= 0) return m;
+  unsigned int *flag = nullptr, host = 1;
+  m = 1;  // anything going wrong below leaves the order-independent ranking
+  if (hipMalloc(reinterpret_cast<void **>(&flag), sizeof(unsigned int)) == hipSuccess) {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+      if (hipMemsetAsync(flag, 0, sizeof(unsigned int), st) == hipSuccess) {
+        hipLaunchKernelGGL(sort_selftest_kernel, dim3(512), dim3(64), 0, st, flag);
+        if (hipGetLastError() == hipSuccess &&
+            hipMemcpyAsync(&host, flag, sizeof(unsigned int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipStreamSynchronize(st) == hipSuccess)
+          m = host == 0 ? 0 : 1;
+      }
+      (void)hipStreamDestroy(st);
+    }
+    (void)hipFree(flag);
+  }
+  g_rank_mode.store(m, std::memory_order_release);
+  return m;
+}
+
+void sort_set_rank_mode(int mode) { g_rank_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_release); }
 
 size_t sort_coo_workspace_bytes(int64_t E) { return carve_sort(nullptr, E, nullptr); }
 
@@ -556,17 +1182,45 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
     return TSAMD_OK;
   }
   TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes, stream));
-  // a 4-byte value array rides through the passes of a packed sort (TSAMD_SORT_VALUE_RIDE=0: gathered by the last pass)
-  bool ride = L.packed && gather_dst != nullptr && gather_bytes == 4 && L.passes >= 2;
-  if (ride) {
-    const char *env = getenv("TSAMD_SORT_VALUE_RIDE");
-    if (env != nullptr && env[0] == '0') ride = false;
-  }
+  // a 4-byte value array rides through the passes of a packed sort
+  const bool ride = L.packed && gather_dst != nullptr && gather_bytes == 4 && L.passes >= 2;
   const int64_t ntiles = ceil_div(E, kSortThreads * (L.packed ? (ride ? kItemsOf<true, true> : kItemsOf<true>) : kItemsOf<false>));
+  const BucketPlan B = plan_buckets(E, M, N, L, ride);
+  const bool ballot = sort_rank_mode(stream) == 1;
   {
     const int64_t nb = ceil_div(E, kBuildThreads * 4);
     hipLaunchKernelGGL(sort_build_kernel, dim3((unsigned int)(nb < 512 ? nb : 512)), dim3(kBuildThreads), 0, stream,
-                       row, col, E, L, ws.a, ws.hist, ws.hdr, todo, probe ? (check4 ? 2 : 1) : 0);
+                       row, col, E, L, ws.a, ws.hist, ws.hdr, todo, probe ? (check4 ? 2 : 1) : 0, B, ws.bhist);
+    TSAMD_LAUNCH_CHECK();
+  }
+  if (B.on) {
+    hipLaunchKernelGGL(bucket_plan_kernel, dim3(1), dim3(kBuildThreads), 0, stream, ws.bhist, ws.boff, ws.cursor, ws.hdr,
+                       todo, probe ? 1 : 0, B, E);
+    TSAMD_LAUNCH_CHECK();
+    // bucket path: scatter into ws.b (values into ws.ia), sort every bucket in LDS, write the outputs.  Both kernels
+    // return at once unless the build kernel raised hdr[kHdrFast]; the passes below return at once when it did.
+    const SortBits SB = sort_bits_for(B.shift);
+    const unsigned int *vin = reinterpret_cast<const unsigned int *>(gather_src);
+    if (ride) {
+      hipLaunchKernelGGL((bucket_scatter_kernel<true>), dim3((unsigned int)ceil_div(E, kBkScatterThreads * kBkScatterItems<true>)),
+                         dim3(kBkScatterThreads), 0, stream, ws.a, vin, E, B, ws.cursor, ws.b, ws.ia, ws.hdr);
+    } else {
+      hipLaunchKernelGGL((bucket_scatter_kernel<false>), dim3((unsigned int)ceil_div(E, kBkScatterThreads * kBkScatterItems<false>)),
+                         dim3(kBkScatterThreads), 0, stream, ws.a, vin, E, B, ws.cursor, ws.b, ws.ia, ws.hdr);
+    }
+    TSAMD_LAUNCH_CHECK();
+#define TSAMD_BK_SORT(ITEMS, V, BAL)                                                                                     \
+  hipLaunchKernelGGL((bucket_sort_kernel<TSAMD_BK_SORT_THREADS, ITEMS, V, BAL>), dim3((unsigned int)B.nb),              \
+                     dim3(TSAMD_BK_SORT_THREADS), 0, stream, ws.b, ws.ia, ws.boff, SB, L, row_out, col_out, perm_out,    \
+                     ws.hdr, probe ? counts_out : (int64_t *)nullptr, check4 ? 1 : 0, gather_src, gather_dst, gather_bytes)
+    if (ride) {
+      if (ballot) TSAMD_BK_SORT(TSAMD_BK_SORT_ITEMS_VAL, true, true);
+      else TSAMD_BK_SORT(TSAMD_BK_SORT_ITEMS_VAL, true, false);
+    } else {
+      if (ballot) TSAMD_BK_SORT(TSAMD_BK_SORT_ITEMS, false, true);
+      else TSAMD_BK_SORT(TSAMD_BK_SORT_ITEMS, false, false);
+    }
+#undef TSAMD_BK_SORT
     TSAMD_LAUNCH_CHECK();
   }
   // the passes of a probing sort are decided by the probe's own counter
@@ -579,29 +1233,35 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
     unsigned int *idst = (isrc == ws.ia) ? ws.ib : ws.ia;
     const int shift = pass * kRadixBits + (L.packed ? L.idx_bits : 0);
 #define TSAMD_SORT_PASS(P, LST)                                                                                     \
-  hipLaunchKernelGGL((onesweep_pass_kernel<P, LST>), dim3((unsigned int)ntiles), dim3(kSortThreads), 0, stream, src, \
+  if (ballot) TSAMD_SORT_PASS_(P, LST, true); else TSAMD_SORT_PASS_(P, LST, false)
+#define TSAMD_SORT_PASS_(P, LST, BAL)                                                                                     \
+  hipLaunchKernelGGL((onesweep_pass_kernel<P, LST, false, BAL>), dim3((unsigned int)ntiles), dim3(kSortThreads), 0, stream, src, \
                      isrc, dst, idst, row_out, col_out, perm_out, E, shift, L, ws.hist + pass * kRadix,              \
                      ws.tile_state, ws.hdr, (unsigned int)(pass + 1), pass_todo, row, col,                          \
                      (last && probe) ? counts_out : (int64_t *)nullptr, gather_src, gather_dst, gather_bytes,          \
                      check4 ? 1 : 0)
     if (ride) {
 #define TSAMD_SORT_PASS_VAL(LST)                                                                                      \
-  hipLaunchKernelGGL((onesweep_pass_kernel<true, LST, true>), dim3((unsigned int)ntiles), dim3(kSortThreads), 0,      \
+  if (ballot) TSAMD_SORT_PASS_VAL_(LST, true); else TSAMD_SORT_PASS_VAL_(LST, false)
+#define TSAMD_SORT_PASS_VAL_(LST, BAL)                                                                                      \
+  hipLaunchKernelGGL((onesweep_pass_kernel<true, LST, true, BAL>), dim3((unsigned int)ntiles), dim3(kSortThreads), 0,      \
                      stream, src, isrc, dst, idst, row_out, col_out, perm_out, E, shift, L, ws.hist + pass * kRadix,  \
                      ws.tile_state, ws.hdr, (unsigned int)(pass + 1), pass_todo, row, col,                           \
                      (last && probe) ? counts_out : (int64_t *)nullptr, gather_src, gather_dst, gather_bytes,           \
                      check4 ? 1 : 0)
-      if (last) TSAMD_SORT_PASS_VAL(true);
-      else TSAMD_SORT_PASS_VAL(false);
+      if (last) { TSAMD_SORT_PASS_VAL(true); }
+      else { TSAMD_SORT_PASS_VAL(false); }
 #undef TSAMD_SORT_PASS_VAL
+#undef TSAMD_SORT_PASS_VAL_
     } else if (L.packed) {
-      if (last) TSAMD_SORT_PASS(true, true);
-      else TSAMD_SORT_PASS(true, false);
+      if (last) { TSAMD_SORT_PASS(true, true); }
+      else { TSAMD_SORT_PASS(true, false); }
     } else {
-      if (last) TSAMD_SORT_PASS(false, true);
-      else TSAMD_SORT_PASS(false, false);
+      if (last) { TSAMD_SORT_PASS(false, true); }
+      else { TSAMD_SORT_PASS(false, false); }
     }
 #undef TSAMD_SORT_PASS
+#undef TSAMD_SORT_PASS_
     TSAMD_LAUNCH_CHECK();
     src = dst;
     isrc = idst;

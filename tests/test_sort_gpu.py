@@ -85,6 +85,82 @@ def test_onesweep_sort_full_size_properties(dev, ops, E, m, n):
     assert torch.equal(ops.sort_coo_values(row, col, m, n, 0, None, v8)[4], v8[perm])  # 8-byte values: last-pass gather
 
 
+@pytest.mark.parametrize('E,m,n,kind', [
+    (131072, 9000, 7000, 'uniform'),            # the smallest input on the bucket path (27-bit keys + 17)
+    (400003, 500000, 500000, 'uniform'),        # 38-bit keys, ragged last tile / last bucket
+    (1 << 20, 16, 16, 'uniform'),               # 8-bit keys: the bucket id reaches into the position bits
+    (900000, 3, 5, 'uniform'),                  # 5-bit keys: three populated rows
+    (600000, 1, 1 << 20, 'uniform'),            # no row bits
+    (700001, (1 << 19) + 1, 1000, 'uniform'),   # M just above a power of two: half of the buckets stay empty
+    (500000, 1 << 20, 1 << 20, 'hub'),          # one row holds a third of the entries: a bucket overflows -> one-sweep passes
+    (300000, 1000, 1000, 'onekey'),             # one distinct key among random ones (heavy duplication)
+])
+def test_bucket_path_bit_exact(dev, ops, E, m, n, kind):
+    """Round 6: most-significant-digit scatter + one LDS sort per bucket (and the device-side decision to leave
+    it): exact stable permutation, the riding 4-byte values, the 8-byte gather, the probing variants."""
+    g = torch.Generator().manual_seed(E % 997)
+    row = torch.randint(0, m, (E, ), generator=g)
+    col = torch.randint(0, n, (E, ), generator=g)
+    if kind == 'hub':
+        row[torch.randperm(E, generator=g)[:E // 3]] = 12345
+    elif kind == 'onekey':
+        keep = torch.randperm(E, generator=g)[:2000]
+        r2, c2 = torch.full((E, ), 77), torch.full((E, ), 5)
+        r2[keep], c2[keep] = row[keep], col[keep]
+        row, col = r2, c2
+    q = E // 5
+    row[:q], col[:q] = row[q:2 * q].clone(), col[q:2 * q].clone()  # duplicates: stability is visible in perm
+    er, ec, ep = _check(ops, row, col, m, n, dev)
+    val = torch.rand(E, generator=g)
+    rd, cd, vd = row.to(dev), col.to(dev), val.to(dev)
+    key = row.numpy().astype(np.int64) * n + col.numpy()
+    want_counts = [int((key[1:] < key[:-1]).sum()), int((key[1:] == key[:-1]).sum())]
+    for mode in (0, 1, 3):
+        rs, cs, perm, counts, vs = ops.sort_coo_values(rd, cd, m, n, mode, None, vd)
+        assert np.array_equal(perm.cpu().numpy(), ep), mode
+        assert np.array_equal(rs.cpu().numpy(), er) and np.array_equal(cs.cpu().numpy(), ec)
+        assert np.array_equal(vs.cpu().numpy(), val.numpy()[ep])
+        if mode == 1:
+            assert counts.tolist() == want_counts
+        if mode == 3:
+            assert counts.tolist() == want_counts + [int(row.max()), int(col.max())]
+    v8 = val.double().to(dev)
+    assert np.array_equal(ops.sort_coo_values(rd, cd, m, n, 0, None, v8)[4].cpu().numpy(), val.double().numpy()[ep])
+    # already sorted input through the device-decided variant: copy + identity
+    rs, cs, perm, counts = ops.sort_coo_auto(torch.from_numpy(er).to(dev), torch.from_numpy(ec).to(dev), m, n)
+    assert counts[0].item() == 0 and torch.equal(perm.cpu(), torch.arange(E))
+    assert np.array_equal(rs.cpu().numpy(), er) and np.array_equal(cs.cpu().numpy(), ec)
+
+
+def test_rank_self_test_and_forced_ballot_ranking(dev, ops):
+    """The stable rank of the radix kernels is a returning LDS atomic when the device-side self-test finds the lanes of
+    one instruction served in ascending order, ballot matching otherwise.  Both must give the SAME permutation on
+    inputs made of a few hot keys (many lanes of one instruction on one counter)."""
+    decided = ops.sort_rank_mode(2)  # run the self-test again
+    assert decided in (0, 1)
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    for (E, m, n) in ((300000, 7, 9), (200000, 1 << 20, 1 << 20), (9000, 40, 3), (150000, 1 << 31, 1 << 30)):
+        row = torch.randint(0, m, (E, ), generator=g)
+        col = torch.randint(0, n, (E, ), generator=g)
+        hot = torch.rand(E, generator=g) < 0.6
+        row[hot], col[hot] = row[0], col[0]
+        cases.append((row, col, m, n))
+    try:
+        outs = {}
+        for mode in (0, 1):
+            assert ops.sort_rank_mode(mode) == mode
+            outs[mode] = [ops.sort_coo(r.to(dev), c.to(dev), m, n, True) for (r, c, m, n) in cases]
+        for (r, c, m, n), a, b in zip(cases, outs[0], outs[1]):
+            ep = no.sort_coo(r.numpy(), c.numpy(), m, n)[2]
+            assert np.array_equal(b[2].cpu().numpy(), ep), 'ballot ranking'
+            if decided == 0:
+                assert np.array_equal(a[2].cpu().numpy(), ep), 'atomic ranking'
+    finally:
+        ops.sort_rank_mode(2)
+    assert ops.sort_rank_mode(-1) == decided
+
+
 def test_device_decided_sort_and_probe(dev, ops):
     E, m, n = 300000, 4000, 5000
     g = torch.Generator().manual_seed(2)
