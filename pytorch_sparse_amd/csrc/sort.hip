@@ -103,7 +103,10 @@ int bits_for(int64_t n) {  // bits needed for ids in [0, n)
 // ---------------------------------------------------------------------------
 constexpr int kBkMaxBits = 11;
 constexpr int kBkMaxBuckets = 1 << kBkMaxBits;
-constexpr int kBkHistCopies = 32;
+#ifndef TSAMD_BK_HIST_COPIES
+#define TSAMD_BK_HIST_COPIES 8
+#endif
+constexpr int kBkHistCopies = TSAMD_BK_HIST_COPIES;
 #ifndef TSAMD_BK_MIN_ENTRIES
 #define TSAMD_BK_MIN_ENTRIES (1 << 17)  // below: the one-sweep passes (a handful of tiles; the bucket kernels' fixed costs win nothing)
 #endif
@@ -134,7 +137,9 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
   if (todo != nullptr && *todo == 0) return;
   __shared__ unsigned int cnt[kMaxPasses][kRadix];
   __shared__ unsigned int bcnt[kBkMaxBuckets];
-  for (int p = 0; p < L.passes; ++p)
+  // with a bucket plan the pass digits are only histogrammed if the passes run at all (sort_hist_kernel)
+  const int hist_passes = B.on ? 0 : L.passes;
+  for (int p = 0; p < hist_passes; ++p)
     if (threadIdx.x < kRadix) cnt[p][threadIdx.x] = 0;
   if (B.on)
     for (int b = (int)threadIdx.x; b < B.nb; b += kBuildThreads) bcnt[b] = 0;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
           dup += (r[u] == pr) && (c[u] == pc);
         }
       }
-      for (int p = 0; p < L.passes; ++p) {
+      for (int p = 0; p < hist_passes; ++p) {
         const unsigned int d = (unsigned int)(key >> (p * kRadixBits)) & (kRadix - 1);
         // the high digits of a power-law matrix take a handful of values: one add per wave when all lanes agree
         const unsigned int d0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)d);
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
   __syncthreads();
   // (few, big workgroups: every histogram word is a hot address -- ~12 ns per atomic, serialised; 4096 workgroups
   // spent 50 us queueing on them, 256 spend 3)
-  for (int p = (int)(threadIdx.x >> 8); p < L.passes; p += kBuildThreads / kRadix) {
+  for (int p = (int)(threadIdx.x >> 8); p < hist_passes; p += kBuildThreads / kRadix) {
     const unsigned int c = cnt[p][threadIdx.x & (kRadix - 1)];
     if (c) atomicAdd(&hist[p * kRadix + (threadIdx.x & (kRadix - 1))], (unsigned long long)c);
   }
@@ -254,6 +259,50 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
       const unsigned int c = bcnt[b];
       if (c) atomicAdd(&mine[b], c);
     }
+  }
+}
+
+// Digit histograms of every pass from the built words: the first kernel of the one-sweep chain when the build kernel
+// took the bucket histogram instead (returns at once when the bucket path sorts the input).
+__global__ __launch_bounds__(kBuildThreads) void sort_hist_kernel(
+    const unsigned long long *__restrict__ words, int64_t n, KeyLayout L, unsigned long long *__restrict__ hist,
+    const unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo) {
+  if (hdr[kHdrFast] != 0) return;
+  if (todo != nullptr && *todo == 0) return;
+  __shared__ unsigned int cnt[kMaxPasses][kRadix];
+  for (int p = 0; p < L.passes; ++p)
+    if (threadIdx.x < kRadix) cnt[p][threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = (int)(threadIdx.x & 63);
+  const int kshift = L.packed ? L.idx_bits : 0;
+  constexpr int kB = 4;
+  for (int64_t base = (int64_t)blockIdx.x * (kBuildThreads * kB); base < n; base += (int64_t)gridDim.x * (kBuildThreads * kB)) {
+    unsigned long long key[kB];
+    bool ok[kB];
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const int64_t i = base + u * kBuildThreads + threadIdx.x;
+      ok[u] = i < n;
+      key[u] = ok[u] ? words[i] >> kshift : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      for (int p = 0; p < L.passes; ++p) {
+        const unsigned int d = (unsigned int)(key[u] >> (p * kRadixBits)) & (kRadix - 1);
+        const unsigned int d0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)d);
+        const unsigned long long act = __ballot(ok[u]);
+        if (__ballot(ok[u] && d == d0) == act) {
+          if (lane == 0 && act) atomicAdd(&cnt[p][d0], (unsigned int)__popcll(act));
+        } else if (ok[u]) {
+          atomicAdd(&cnt[p][d], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = (int)(threadIdx.x >> 8); p < L.passes; p += kBuildThreads / kRadix) {
+    const unsigned int c = cnt[p][threadIdx.x & (kRadix - 1)];
+    if (c) atomicAdd(&hist[p * kRadix + (threadIdx.x & (kRadix - 1))], (unsigned long long)c);
   }
 }
 
@@ -656,6 +705,12 @@ constexpr int kBkScatterThreads = 256;
 template <bool VAL>
 constexpr int kBkScatterItems = VAL ? TSAMD_BK_SCATTER_ITEMS_VAL : TSAMD_BK_SCATTER_ITEMS;
 
+// a word and the value riding with it, as they lie in the bucket array of a sort with values: one 12-byte record, so
+// that a tile's run in a bucket is ONE contiguous piece (two arrays: two pieces of 2-3 entries each per run)
+struct __attribute__((packed, aligned(4))) BkRec {
+  unsigned int lo, hi, v;
+};
+
 // (LDS index of bucket b: one pad word per 32 buckets, so that "thread t scans buckets 8t .. 8t + 7" is not a
 // 16-way bank conflict)
 __device__ __forceinline__ unsigned int bk_slot(unsigned int b) { return b + (b >> 5); }
@@ -692,7 +747,11 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
   for (int i = 0; i < kItems; ++i) {
     const int j = i * kBkScatterThreads + tid;
     rank[i] = 0;
+#if defined(TSAMD_EXP_SCATTER_NO_RANK)  // timing experiment
+    if (j < count) rank[i] = cnt[bk_slot((unsigned int)(word[i] >> B.shift))];
+#else
     if (j < count) rank[i] = atomicAdd(&cnt[bk_slot((unsigned int)(word[i] >> B.shift))], 1u);
+#endif
   }
   __syncthreads();
   // exclusive scan of the counts in bucket order: thread t takes the kPer buckets from t * kPer on
@@ -728,7 +787,11 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
   for (int k = 0; k < kPer; ++k) {
     const unsigned int b = (unsigned int)(k * kBkScatterThreads + tid);
     const unsigned int cb = (int)b < B.nb ? cnt[bk_slot(b)] : 0u;
+#if defined(TSAMD_EXP_SCATTER_NO_CURSOR)  // timing experiment (scripts/variants.py): wrong result
+    gbase[k] = cursor[b];
+#else
     gbase[k] = cb ? atomicAdd(&cursor[b], cb) : 0u;
+#endif
   }
   // reorder the tile by bucket in LDS
 #pragma unroll
@@ -752,8 +815,20 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
     if (j >= count) break;
     const unsigned long long wd = sword[j];
     const unsigned int o = cnt[bk_slot((unsigned int)(wd >> B.shift))] + (unsigned int)j;
-    out[o] = wd;
-    if constexpr (VAL) val_out[o] = sval[j];
+#if defined(TSAMD_EXP_SCATTER_LINEAR_STORE)  // timing experiment: the tile goes out as one contiguous piece
+    out[tile0 + j] = wd ^ (unsigned long long)(o & 1u);
+    if constexpr (VAL) val_out[tile0 + j] = sval[j];
+#else
+    if constexpr (VAL) {
+      BkRec rec;
+      rec.lo = (unsigned int)wd;
+      rec.hi = (unsigned int)(wd >> 32);
+      rec.v = sval[j];
+      reinterpret_cast<BkRec *>(out)[o] = rec;
+    } else {
+      out[o] = wd;
+    }
+#endif
   }
 }
 
@@ -764,11 +839,12 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
 //      entries falls into ~65 k groups), entries in registers between the passes: wave w owns a contiguous segment of
 //      the bucket and ranks by one returning LDS atomic per entry on a per-wave counter (two 16-bit counters per
 //      word); the BALLOT instantiation ranks by ballot matching (see the pass kernel);
-//   2. FINISH: what is left to order are the entries that agree in all of those bits -- neighbours in LDS now.  Every
-//      entry counts the larger words of its group to its left and the smaller ones to its right (full 64-bit compare:
-//      words are unique) and moves to `j - greater + smaller`.  Typically zero or one neighbour;
+//   2. FINISH: what is left to order are the entries that agree in all of those bits -- neighbours in LDS now.  While
+//      the output is written every entry counts the larger words of its group to its left and the smaller ones to its
+//      right (full 64-bit compare: words are unique) and goes to place `j - greater + smaller` of the bucket's piece
+//      of the output.  Typically one read per side and no match;
 //   3. a group longer than kBkGroupMax (many duplicates of one key, a dense block) makes the workgroup sort the whole
-//      bucket by LSD passes over ALL the bits below the bucket id instead (SB.n passes): fixed cost, any input.
+//      bucket by LSD passes over ALL the bits below the bucket id first (SB.n passes): fixed cost, any input.
 // ---------------------------------------------------------------------------
 constexpr int kBkGroupMax = 24;
 
@@ -794,12 +870,11 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
   __shared__ unsigned int sval[VAL ? kCap : 1];
   __shared__ unsigned int cnt[kW][kRadix / 2];
   __shared__ unsigned int dig_off[kRadix];
-  __shared__ unsigned int s_w0, s_over;
+  __shared__ unsigned int s_w0;
   const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
   const unsigned int start = boff[blockIdx.x];
   const int n = (int)(boff[blockIdx.x + 1] - start);
   if (n == 0) return;
-  if (tid == 0) s_over = 0;
   // wave w owns the entries [w * seg, (w + 1) * seg), seg a multiple of 64: the waves share the bucket evenly
   const int seg = (((n + kW - 1) / kW) + 63) & ~63;
   const int items = seg >> 6;  // <= ITEMS because n <= kCap
@@ -812,8 +887,13 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
     if constexpr (VAL) val[i] = 0u;
     const int e = wbase + i * 64 + lane;
     if (i < items && e < n) {
-      word[i] = in[start + e];
-      if constexpr (VAL) val[i] = val_in[start + e];
+      if constexpr (VAL) {
+        const BkRec rec = reinterpret_cast<const BkRec *>(in)[start + e];
+        word[i] = ((unsigned long long)rec.hi << 32) | rec.lo;
+        val[i] = rec.v;
+      } else {
+        word[i] = in[start + e];
+      }
     }
   }
   // LSD passes p0 .. p1 - 1 of SB over the entries in registers; leaves the result in sword / sval (LDS)
@@ -903,52 +983,27 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
     }
   };
   const int p_top = SB.n - SB.n_top;  // the top digits are the last n_top passes of the list
+#if defined(TSAMD_EXP_BSORT_ONE_PASS)  // timing experiments: wrong result
+  lsd_passes(SB.n - 1, SB.n);
+#else
   lsd_passes(p_top, SB.n);
-  if (p_top > 0) {
-    // FINISH: groups = runs of entries that agree in every bit from SB.lo up
-    const int lo = SB.lo;
-    unsigned long long fw[ITEMS];
-    unsigned int fv[VAL ? ITEMS : 1];
-    int fpos[ITEMS];
-    bool over = false;
+#endif
+  // FINISH.  Groups = runs of entries that agree in every bit from SB.lo up; an entry's final place is its place in
+  // the run, taken while the output is written (no second trip through LDS).  First: is any group too long for that?
+  // (sorted by prefix: a group longer than G exists exactly when some entry and the entry G places on agree)
+  const int lo = SB.lo;
+  bool exact = p_top == 0;
+#if defined(TSAMD_EXP_BSORT_NO_FINISH)
+  exact = true;
+#endif
+  if (!exact) {
+    int over = 0;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       const int j = k * THREADS + tid;
-      fpos[k] = -1;
-      fw[k] = 0ull;
-      if (k * THREADS < n && j < n) {
-        const unsigned long long x = sword[j];
-        const unsigned long long pre = x >> lo;
-        int gt = 0, lt = 0, len = 0;
-        for (int q = j - 1; q >= 0; --q) {
-          const unsigned long long y = sword[q];
-          if ((y >> lo) != pre) break;
-          gt += y > x;
-          if (++len > kBkGroupMax) break;
-        }
-        for (int q = j + 1; q < n; ++q) {
-          const unsigned long long y = sword[q];
-          if ((y >> lo) != pre) break;
-          lt += y < x;
-          if (++len > kBkGroupMax) break;
-        }
-        over |= len > kBkGroupMax;
-        fw[k] = x;
-        if constexpr (VAL) fv[k] = sval[j];
-        fpos[k] = j - gt + lt;
-      }
+      if (j + kBkGroupMax < n) over |= (sword[j] >> lo) == (sword[j + kBkGroupMax] >> lo);
     }
-    if (over) s_over = 1;
-    __syncthreads();
-    if (s_over == 0) {
-#pragma unroll
-      for (int k = 0; k < ITEMS; ++k) {
-        if (fpos[k] >= 0) {
-          sword[fpos[k]] = fw[k];
-          if constexpr (VAL) sval[fpos[k]] = fv[k];
-        }
-      }
-    } else {
+    if (__syncthreads_or(over)) {
       // a long group: the whole bucket by LSD passes over every bit below the bucket id (stable, any input)
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i) {
@@ -958,29 +1013,46 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
           if constexpr (VAL) val[i] = sval[e];
         }
       }
-      __syncthreads();
       lsd_passes(0, SB.n);
+      exact = true;
     }
-    __syncthreads();
   }
   // decoded output, coalesced
   const unsigned long long imask = (1ull << L.idx_bits) - 1ull, cmask = (1ull << L.col_bits) - 1ull;
   constexpr int kBatch = 4;
   for (int j0 = tid; j0 < n; j0 += THREADS * kBatch) {
     unsigned long long key[kBatch], e[kBatch];
+    size_t o[kBatch];
     bool ok[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int j = j0 + k * THREADS;
       ok[k] = j < n;
       const unsigned long long wd = sword[ok[k] ? j : 0];
+      int pos = j;
+      if (!exact && ok[k]) {
+        const unsigned long long pre = wd >> lo;
+        int gt = 0, lt = 0;
+        for (int q = j - 1; q >= 0; --q) {  // (typically: one read, no match)
+          const unsigned long long y = sword[q];
+          if ((y >> lo) != pre) break;
+          gt += y > wd;
+        }
+        for (int q = j + 1; q < n; ++q) {
+          const unsigned long long y = sword[q];
+          if ((y >> lo) != pre) break;
+          lt += y < wd;
+        }
+        pos = j - gt + lt;
+      }
+      o[k] = (size_t)start + (size_t)pos;
       key[k] = wd >> L.idx_bits;
       e[k] = wd & imask;
     }
     if constexpr (VAL) {
 #pragma unroll
       for (int k = 0; k < kBatch; ++k)
-        if (ok[k]) reinterpret_cast<uint32_t *>(gather_dst)[start + j0 + k * THREADS] = sval[j0 + k * THREADS];
+        if (ok[k]) reinterpret_cast<uint32_t *>(gather_dst)[o[k]] = sval[j0 + k * THREADS];
     } else if (gather_dst != nullptr) {
       if (gather_bytes == 4) {
         uint32_t v[kBatch];
@@ -988,23 +1060,26 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
         for (int k = 0; k < kBatch; ++k) v[k] = reinterpret_cast<const uint32_t *>(gather_src)[ok[k] ? e[k] : 0];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k)
-          if (ok[k]) reinterpret_cast<uint32_t *>(gather_dst)[start + j0 + k * THREADS] = v[k];
+          if (ok[k]) reinterpret_cast<uint32_t *>(gather_dst)[o[k]] = v[k];
       } else {
         uint64_t v[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) v[k] = reinterpret_cast<const uint64_t *>(gather_src)[ok[k] ? e[k] : 0];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k)
-          if (ok[k]) reinterpret_cast<uint64_t *>(gather_dst)[start + j0 + k * THREADS] = v[k];
+          if (ok[k]) reinterpret_cast<uint64_t *>(gather_dst)[o[k]] = v[k];
       }
     }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       if (!ok[k]) continue;
-      const size_t o = (size_t)start + (size_t)(j0 + k * THREADS);
-      if (row_out) row_out[o] = (int64_t)(key[k] >> L.col_bits);
-      if (col_out) col_out[o] = (int64_t)(key[k] & cmask);
-      perm_out[o] = (int64_t)e[k];
+#if defined(TSAMD_EXP_BSORT_NO_STORE)
+      if (key[k] == 0x123456789ull) perm_out[o[k]] = (int64_t)e[k];
+#else
+      if (row_out) row_out[o[k]] = (int64_t)(key[k] >> L.col_bits);
+      if (col_out) col_out[o[k]] = (int64_t)(key[k] & cmask);
+      perm_out[o[k]] = (int64_t)e[k];
+#endif
     }
   }
 }
@@ -1107,7 +1182,7 @@ size_t carve_sort(void *base, int64_t E, SortWs *ws) {
   w.boff = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * (kBkMaxBuckets + 1)));
   w.cursor = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxBuckets));
   w.a = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * n));
-  w.b = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * n));
+  w.b = reinterpret_cast<unsigned long long *>(take(12 * n));  // words, or the 12-byte records of the bucket path
   w.ia = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * n));
   w.ib = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * n));
   if (ws) *ws = w;
@@ -1198,7 +1273,9 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
                        todo, probe ? 1 : 0, B, E);
     TSAMD_LAUNCH_CHECK();
     // bucket path: scatter into ws.b (values into ws.ia), sort every bucket in LDS, write the outputs.  Both kernels
-    // return at once unless the build kernel raised hdr[kHdrFast]; the passes below return at once when it did.
+    // return at once unless the plan kernel raised hdr[kHdrFast]; the passes below return at once when it did (~5 us
+    // per kernel that returns at once; running that chain on a forked side stream was measured SLOWER, 0.205 vs
+    // 0.193 ms at 7.5 M entries: the idle kernels queue behind the busy ones and the join waits for them).
     const SortBits SB = sort_bits_for(B.shift);
     const unsigned int *vin = reinterpret_cast<const unsigned int *>(gather_src);
     if (ride) {
@@ -1225,6 +1302,12 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
   }
   // the passes of a probing sort are decided by the probe's own counter
   const int64_t *pass_todo = probe ? reinterpret_cast<const int64_t *>(ws.hdr + kHdrDescents) : todo;
+  if (B.on) {  // (the build kernel took the bucket histogram instead of the pass digits)
+    const int64_t nb = ceil_div(E, kBuildThreads * 4);
+    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned int)(nb < 512 ? nb : 512)), dim3(kBuildThreads), 0, stream, ws.a, E,
+                       L, ws.hist, ws.hdr, pass_todo);
+    TSAMD_LAUNCH_CHECK();
+  }
   const unsigned long long *src = ws.a;
   const unsigned int *isrc = nullptr;  // first pass: payload = position
   for (int pass = 0; pass < L.passes; ++pass) {
