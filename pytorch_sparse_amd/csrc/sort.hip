@@ -101,8 +101,10 @@ int bits_for(int64_t n) {  // bits needed for ids in [0, n)
 //   run while the one-sweep passes return at once; otherwise (power-law rows, heavy duplication over few keys, ...)
 //   the two bucket kernels return at once and the one-sweep passes sort as before.  No host sync either way.
 // ---------------------------------------------------------------------------
-constexpr int kBkMaxBits = 11;
+constexpr int kBkMaxBits = 11;                   // buckets one scatter level separates (LDS counters of a tile)
 constexpr int kBkMaxBuckets = 1 << kBkMaxBits;
+constexpr int kBkMaxTotalBits = 14;              // buckets of a sort (two levels): bins of the build kernel's LDS histogram
+constexpr int kBkMaxHist = 1 << kBkMaxTotalBits;
 #ifndef TSAMD_BK_HIST_COPIES
 #define TSAMD_BK_HIST_COPIES 8
 #endif
@@ -110,12 +112,25 @@ constexpr int kBkHistCopies = TSAMD_BK_HIST_COPIES;
 #ifndef TSAMD_BK_MIN_ENTRIES
 #define TSAMD_BK_MIN_ENTRIES (1 << 17)  // below: the one-sweep passes (a handful of tiles; the bucket kernels' fixed costs win nothing)
 #endif
+// Two word formats in the bucket array:
+//   full  (strip = 0): the packed word (key << idx_bits | position) as built; bucket = word >> shift -- the top bits of
+//                      the word space the sizes can populate, which for tiny key spaces reaches into the position bits;
+//                      one level only;
+//   strip (strip = 1): the bucket id is the top `bits` bits of the KEY; scatter level 1 drops its `bits1` bits from the
+//                      word and puts the position in ((key & low) << idx_bits | position): fits 64 bits where the full
+//                      word does not (75 M entries of a 4 M x 4 M matrix: 44 + 27 bits), and lets a second scatter
+//                      level split every level-1 bucket by the next `bits - bits1` bits (more buckets than a tile has
+//                      LDS counters, still >= 64-byte runs per tile and bucket).
 struct BucketPlan {
-  int on;     // 0: the build kernel takes no bucket histogram and never raises kHdrFast
-  int bits;   // log2(#buckets)
-  int shift;  // bucket = word >> shift; the bucket sort orders the `shift` bits below
-  int nb;     // 1 << bits
-  int cap;    // largest bucket the bucket-sort kernel of this launch holds in LDS
+  int on;      // 0: the build kernel takes no bucket histogram and the plan kernel never raises kHdrFast
+  int levels;  // scatter levels: 1 or 2
+  int strip;
+  int bits;    // log2(#buckets) = bits1 + bits2
+  int bits1;
+  int kshift;  // strip: bucket = key >> kshift
+  int shift;   // bits of the word below the bucket id (what the bucket sort orders); full: bucket = word >> shift
+  int nb;      // 1 << bits
+  int cap;     // largest bucket the bucket-sort kernel of this launch holds in LDS
 };
 // the bits the bucket sort runs its 8-bit LSD passes over: up to two ranges of the word
 struct SortBits {
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
     unsigned int *__restrict__ bhist) {
   if (todo != nullptr && *todo == 0) return;
   __shared__ unsigned int cnt[kMaxPasses][kRadix];
-  __shared__ unsigned int bcnt[kBkMaxBuckets];
+  __shared__ unsigned int bcnt[kBkMaxHist];
   // with a bucket plan the pass digits are only histogrammed if the passes run at all (sort_hist_kernel)
   const int hist_passes = B.on ? 0 : L.passes;
   for (int p = 0; p < hist_passes; ++p)
@@ -195,8 +210,9 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
           atomicAdd(&cnt[p][d], 1u);
         }
       }
-      if (B.on) {  // (packed words only)
-        const unsigned int b = (unsigned int)(((key << L.idx_bits) | (unsigned long long)i) >> B.shift);
+      if (B.on) {
+        const unsigned int b = B.strip ? (unsigned int)(key >> B.kshift)
+                                       : (unsigned int)(((key << L.idx_bits) | (unsigned long long)i) >> B.shift);
         const unsigned int b0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
         const unsigned long long act = __ballot(ok[u]);
         if (__ballot(ok[u] && b == b0) == act) {
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
   // (kBkHistCopies copies of the histogram, one per residue of the workgroup id: 512 workgroups adding to the same
   // 128 cache lines queued for ~150 us on the lines' atomic units; 16 adds per line and copy do not)
   {
-    unsigned int *mine = bhist + (size_t)(blockIdx.x % kBkHistCopies) * kBkMaxBuckets;
+    unsigned int *mine = bhist + (size_t)(blockIdx.x % kBkHistCopies) * B.nb;
     for (int b = (int)threadIdx.x; b < B.nb; b += kBuildThreads) {
       const unsigned int c = bcnt[b];
       if (c) atomicAdd(&mine[b], c);
@@ -311,24 +327,27 @@ __global__ __launch_bounds__(kBuildThreads) void sort_hist_kernel(
 // workgroup, which on this part writes the workgroup's XCD L2 back: the build kernel went from 46 to 200 us).
 __global__ __launch_bounds__(kBuildThreads) void bucket_plan_kernel(
     const unsigned int *__restrict__ bhist, unsigned int *__restrict__ boff, unsigned int *__restrict__ cursor,
-    unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo, int probe, BucketPlan B, int64_t n) {
+    unsigned int *__restrict__ cursor1, unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo,
+    int probe, BucketPlan B, int64_t n) {
   if (todo != nullptr && *todo == 0) return;  // (hdr[kHdrFast] stays 0: the passes write the copy + identity)
   const int lane = (int)(threadIdx.x & 63);
-  constexpr int kPer = kBkMaxBuckets / kBuildThreads > 0 ? kBkMaxBuckets / kBuildThreads : 1;
-  unsigned int c[kPer], sum = 0, mx = 0;
+  __shared__ unsigned int sc[kBkMaxHist];
+  for (int b = (int)threadIdx.x; b < B.nb; b += kBuildThreads) {  // (coalesced; the copies' loads in flight together)
+    unsigned int part[kBkHistCopies], t = 0;
 #pragma unroll
-  for (int j = 0; j < kPer; ++j) {
-    const int b = (int)threadIdx.x * kPer + j;
-    c[j] = 0;
-    if (b < B.nb) {
-      unsigned int part[kBkHistCopies];
+    for (int r = 0; r < kBkHistCopies; ++r) part[r] = bhist[(size_t)r * B.nb + b];
 #pragma unroll
-      for (int r = 0; r < kBkHistCopies; ++r) part[r] = bhist[(size_t)r * kBkMaxBuckets + b];
-#pragma unroll
-      for (int r = 0; r < kBkHistCopies; ++r) c[j] += part[r];
-    }
-    sum += c[j];
-    mx = c[j] > mx ? c[j] : mx;
+    for (int r = 0; r < kBkHistCopies; ++r) t += part[r];
+    sc[b] = t;
+  }
+  __syncthreads();
+  const int per = (B.nb + kBuildThreads - 1) / kBuildThreads;  // thread t owns the buckets [t * per, (t + 1) * per)
+  unsigned int sum = 0, mx = 0;
+  for (int j = 0; j < per; ++j) {
+    const int b = (int)threadIdx.x * per + j;
+    const unsigned int c = b < B.nb ? sc[b] : 0u;
+    sum += c;
+    mx = c > mx ? c : mx;
   }
   // exclusive scan of `sum` over the 1024 threads + the block maximum
   unsigned int inc = sum;
@@ -351,13 +370,14 @@ __global__ __launch_bounds__(kBuildThreads) void bucket_plan_kernel(
     gmx = s_wmax[ww] > gmx ? s_wmax[ww] : gmx;
   }
   unsigned int run = base + inc - sum;
-#pragma unroll
-  for (int j = 0; j < kPer; ++j) {
-    const int b = (int)threadIdx.x * kPer + j;
+  const int bits2 = B.bits - B.bits1;
+  for (int j = 0; j < per; ++j) {
+    const int b = (int)threadIdx.x * per + j;
     if (b < B.nb) {
       boff[b] = run;
-      cursor[b] = run;
-      run += c[j];
+      cursor[b] = run;  // the last scatter level reserves its runs here
+      if (B.levels == 2 && (b & ((1 << bits2) - 1)) == 0) cursor1[b >> bits2] = run;  // level 1: one cursor per group of 2^bits2
+      run += sc[b];
     }
   }
   if (threadIdx.x == 0) {
@@ -715,14 +735,25 @@ struct __attribute__((packed, aligned(4))) BkRec {
 // 16-way bank conflict)
 __device__ __forceinline__ unsigned int bk_slot(unsigned int b) { return b + (b >> 5); }
 
-template <bool VAL>
+// LEVEL 1 reads the built words / keys in input order (entry e IS position e; a riding value comes from `val_in[e]`)
+// and separates them by the top bits1 bits of the bucket id; LEVEL 2 (plans with two levels) reads level 1's output
+// and separates every level-1 bucket by the remaining bits: the tile's entries lie in a few neighbouring level-1
+// buckets (found from the tile's position), its LDS counters cover the final buckets of the first kBkWin of them, and
+// an entry beyond that window (a tile over many tiny level-1 buckets) reserves its slot by itself.
+// In LDS a strip-mode LEVEL 1 tile holds (key << kBkTileBits | place in the tile): bucket id and final word both follow
+// from it (the final word no longer has the bucket's bits, and key + full position may not fit 64 bits).
+constexpr int kBkTileBits = 13;
+constexpr int kBkWinMax = 32;
+
+template <bool VAL, int LEVEL, bool STRIP>
 __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
     const unsigned long long *__restrict__ in, const unsigned int *__restrict__ val_in, int64_t n, BucketPlan B,
-    unsigned int *__restrict__ cursor, unsigned long long *__restrict__ out, unsigned int *__restrict__ val_out,
-    const unsigned long long *__restrict__ hdr) {
+    KeyLayout L, const unsigned int *__restrict__ boff, unsigned int *__restrict__ cursor,
+    unsigned long long *__restrict__ out, const unsigned long long *__restrict__ hdr) {
   if (hdr[kHdrFast] == 0) return;
   constexpr int kItems = kBkScatterItems<VAL>;
   constexpr int kTile = kBkScatterThreads * kItems;
+  static_assert(kTile <= (1 << kBkTileBits), "place in the tile: kBkTileBits bits");
   constexpr int kPer = kBkMaxBuckets / kBkScatterThreads;
   constexpr int kSlots = kBkMaxBuckets + kBkMaxBuckets / 32;
   __shared__ unsigned long long sword[kTile];
@@ -730,28 +761,89 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
   __shared__ unsigned int cnt[kSlots];   // entries of the tile per bucket, later: first output slot - first LDS slot
   __shared__ unsigned int loff[kSlots];  // first LDS slot of the bucket's run
   __shared__ unsigned int s_wsum[kBkScatterThreads / 64];
+  __shared__ unsigned int sbnd[kBkWinMax];  // LEVEL 2: first position of the level-1 buckets behind the tile's first
+  __shared__ unsigned int s_direct;         // LEVEL 2: entries outside the counter window
   const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int b = tid; b < kSlots; b += kBkScatterThreads) cnt[b] = 0;
-  __syncthreads();
+  if (tid == 0) s_direct = 0;
   const int64_t tile0 = (int64_t)blockIdx.x * kTile;
   const int count = n - tile0 < kTile ? (int)(n - tile0) : kTile;
+  const int bits2 = B.bits - B.bits1;
+  const unsigned int nb1 = 1u << B.bits1;
+  // the buckets this tile counts in LDS: [gid0, gid0 + nloc)
+  unsigned int gid0 = 0, b1_first = 0;
+  int nloc = 1 << B.bits1, nwin = 1;
+  if constexpr (LEVEL == 2) {
+    // level-1 bucket of the tile's first entry: the last b with boff[b << bits2] <= tile0
+    unsigned int lo = 0, hi = nb1 - 1u;
+    while (lo < hi) {
+      const unsigned int mid = (lo + hi + 1) >> 1;
+      if ((int64_t)boff[mid << bits2] <= tile0) lo = mid; else hi = mid - 1;
+    }
+    b1_first = lo;
+    gid0 = lo << bits2;
+    nwin = kBkMaxBuckets >> bits2;
+    nwin = nwin > kBkWinMax ? kBkWinMax : nwin;
+    nwin = (int)(nb1 - lo) < nwin ? (int)(nb1 - lo) : nwin;
+    nloc = nwin << bits2;
+    if (tid < kBkWinMax) sbnd[tid] = b1_first + 1u + (unsigned int)tid < nb1 ? boff[(b1_first + 1u + (unsigned int)tid) << bits2] : 0xffffffffu;
+  }
+  __syncthreads();
   unsigned long long word[kItems];
-  unsigned int val[VAL ? kItems : 1], rank[kItems];
+  unsigned int val[VAL ? kItems : 1], rank[kItems], bid2[LEVEL == 2 ? kItems : 1];
+  // the bucket (relative to gid0) of a staged word; LEVEL 2 keeps it in bid2 (it depends on where the entry came from)
+  const int kb1 = L.key_bits - B.bits1;
+  auto bucket_of = [&](unsigned long long wd) -> unsigned int {
+    if constexpr (STRIP) return (unsigned int)((wd >> kBkTileBits) >> kb1);
+    else return (unsigned int)(wd >> B.shift);
+  };
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int j = i * kBkScatterThreads + tid;
-    word[i] = j < count ? in[tile0 + j] : 0ull;
-    if constexpr (VAL) val[i] = j < count ? val_in[tile0 + j] : 0u;
+    word[i] = 0ull;
+    if constexpr (VAL) val[i] = 0u;
+    if (j < count) {
+      if constexpr (LEVEL == 1) {
+        word[i] = in[tile0 + j];
+        if constexpr (VAL) val[i] = val_in[tile0 + j];
+      } else if constexpr (VAL) {
+        const BkRec rec = reinterpret_cast<const BkRec *>(in)[tile0 + j];
+        word[i] = ((unsigned long long)rec.hi << 32) | rec.lo;
+        val[i] = rec.v;
+      } else {
+        word[i] = in[tile0 + j];
+      }
+    }
   }
+  int dl = 0;  // LEVEL 2: this thread's entries come in rising positions, their level-1 bucket only moves forward
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int j = i * kBkScatterThreads + tid;
     rank[i] = 0;
+    if constexpr (LEVEL == 2) bid2[i] = 0;
+    if (j < count) {
+      unsigned int bid;
+      if constexpr (LEVEL == 1) {
+        if constexpr (STRIP) {
+          const unsigned long long key = L.packed ? word[i] >> L.idx_bits : word[i];
+          word[i] = (key << kBkTileBits) | (unsigned long long)j;
+        }
+        bid = bucket_of(word[i]);
+      } else {
+        const unsigned int p = (unsigned int)(tile0 + j);
+        while (dl < kBkWinMax && sbnd[dl] <= p) ++dl;
+        // (dl >= nwin: outside the window -- the true level-1 bucket is looked up when the entry is stored)
+        bid = dl < nwin ? ((unsigned int)dl << bits2) + (unsigned int)(word[i] >> B.shift) : 0xffffffffu;
+        bid2[i] = bid;
+      }
+      if (LEVEL == 1 || bid != 0xffffffffu) {
 #if defined(TSAMD_EXP_SCATTER_NO_RANK)  // timing experiment
-    if (j < count) rank[i] = cnt[bk_slot((unsigned int)(word[i] >> B.shift))];
+        rank[i] = cnt[bk_slot(bid)];
 #else
-    if (j < count) rank[i] = atomicAdd(&cnt[bk_slot((unsigned int)(word[i] >> B.shift))], 1u);
+        rank[i] = atomicAdd(&cnt[bk_slot(bid)], 1u);
 #endif
+      }
+    }
   }
   __syncthreads();
   // exclusive scan of the counts in bucket order: thread t takes the kPer buckets from t * kPer on
@@ -759,7 +851,7 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
 #pragma unroll
   for (int j = 0; j < kPer; ++j) {
     const unsigned int b = (unsigned int)(tid * kPer + j);
-    c[j] = (int)b < B.nb ? cnt[bk_slot(b)] : 0u;
+    c[j] = (int)b < nloc ? cnt[bk_slot(b)] : 0u;
     sum += c[j];
   }
   unsigned int inc = sum;
@@ -777,7 +869,7 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
 #pragma unroll
   for (int j = 0; j < kPer; ++j) {
     const unsigned int b = (unsigned int)(tid * kPer + j);
-    if ((int)b < B.nb) loff[bk_slot(b)] = run;
+    if ((int)b < nloc) loff[bk_slot(b)] = run;
     run += c[j];
   }
   __syncthreads();
@@ -786,48 +878,78 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     const unsigned int b = (unsigned int)(k * kBkScatterThreads + tid);
-    const unsigned int cb = (int)b < B.nb ? cnt[bk_slot(b)] : 0u;
+    const unsigned int cb = (int)b < nloc ? cnt[bk_slot(b)] : 0u;
 #if defined(TSAMD_EXP_SCATTER_NO_CURSOR)  // timing experiment (scripts/variants.py): wrong result
-    gbase[k] = cursor[b];
+    gbase[k] = cursor[gid0 + b];
 #else
-    gbase[k] = cb ? atomicAdd(&cursor[b], cb) : 0u;
+    gbase[k] = cb ? atomicAdd(&cursor[gid0 + b], cb) : 0u;
 #endif
   }
+  auto store_rec = [&](unsigned int o, unsigned long long wd, unsigned int v) {
+    if constexpr (VAL) {
+      BkRec rec;
+      rec.lo = (unsigned int)wd;
+      rec.hi = (unsigned int)(wd >> 32);
+      rec.v = v;
+      reinterpret_cast<BkRec *>(out)[o] = rec;
+    } else {
+      out[o] = wd;
+    }
+  };
   // reorder the tile by bucket in LDS
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int j = i * kBkScatterThreads + tid;
     if (j < count) {
-      const unsigned int pos = loff[bk_slot((unsigned int)(word[i] >> B.shift))] + rank[i];
-      sword[pos] = word[i];
-      if constexpr (VAL) sval[pos] = val[i];
+      unsigned int bid;
+      if constexpr (LEVEL == 1) bid = bucket_of(word[i]);
+      else bid = bid2[i];
+      if (LEVEL == 1 || bid != 0xffffffffu) {
+        const unsigned int pos = loff[bk_slot(bid)] + rank[i];
+        sword[pos] = word[i];
+        if constexpr (VAL) sval[pos] = val[i];
+      } else {  // outside the counter window: a slot of its own, stored at once
+        const unsigned int p = (unsigned int)(tile0 + j);
+        unsigned int lo = b1_first, hi = nb1 - 1u;
+        while (lo < hi) {
+          const unsigned int mid = (lo + hi + 1) >> 1;
+          if (boff[mid << bits2] <= p) lo = mid; else hi = mid - 1;
+        }
+        store_rec(atomicAdd(&cursor[(lo << bits2) + (unsigned int)(word[i] >> B.shift)], 1u), word[i], VAL ? val[i] : 0u);
+        atomicAdd(&s_direct, 1u);
+      }
     }
   }
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     const unsigned int b = (unsigned int)(k * kBkScatterThreads + tid);
-    if ((int)b < B.nb) cnt[bk_slot(b)] = gbase[k] - loff[bk_slot(b)];  // (modulo 2^32: E < 2^32)
+    if ((int)b < nloc) cnt[bk_slot(b)] = gbase[k] - loff[bk_slot(b)];  // (modulo 2^32: E < 2^32)
   }
   __syncthreads();
+  const int staged = LEVEL == 1 ? count : count - (int)s_direct;
+  int dlo = 0;  // LEVEL 2: level-1 bucket (relative to the tile's first) of LDS slot j; rises with j
 #pragma unroll
   for (int i = 0; i < kItems; ++i) {
     const int j = i * kBkScatterThreads + tid;
-    if (j >= count) break;
-    const unsigned long long wd = sword[j];
-    const unsigned int o = cnt[bk_slot((unsigned int)(wd >> B.shift))] + (unsigned int)j;
-#if defined(TSAMD_EXP_SCATTER_LINEAR_STORE)  // timing experiment: the tile goes out as one contiguous piece
-    out[tile0 + j] = wd ^ (unsigned long long)(o & 1u);
-    if constexpr (VAL) val_out[tile0 + j] = sval[j];
-#else
-    if constexpr (VAL) {
-      BkRec rec;
-      rec.lo = (unsigned int)wd;
-      rec.hi = (unsigned int)(wd >> 32);
-      rec.v = sval[j];
-      reinterpret_cast<BkRec *>(out)[o] = rec;
+    if (j >= staged) break;
+    unsigned long long wd = sword[j];
+    unsigned int b;
+    if constexpr (LEVEL == 1) {
+      b = bucket_of(wd);
+      if constexpr (STRIP) {  // the word of the bucket array: the key without its bits1 top bits, then the position
+        const unsigned long long key = wd >> kBkTileBits;
+        wd = ((key & ((1ull << kb1) - 1ull)) << L.idx_bits) |
+             (unsigned long long)(tile0 + (int64_t)(wd & ((1u << kBkTileBits) - 1u)));
+      }
     } else {
-      out[o] = wd;
+      while (dlo + 1 < nwin && loff[bk_slot((unsigned int)(dlo + 1) << bits2)] <= (unsigned int)j) ++dlo;
+      b = ((unsigned int)dlo << bits2) + (unsigned int)(wd >> B.shift);
     }
+    const unsigned int o = cnt[bk_slot(b)] + (unsigned int)j;
+#if defined(TSAMD_EXP_SCATTER_LINEAR_STORE)  // timing experiment: the tile goes out as one contiguous piece
+    store_rec((unsigned int)(tile0 + j), wd ^ (unsigned long long)(o & 1u), VAL ? sval[j] : 0u);
+#else
+    store_rec(o, wd, VAL ? sval[j] : 0u);
 #endif
   }
 }
@@ -851,7 +973,7 @@ constexpr int kBkGroupMax = 24;
 template <int THREADS, int ITEMS, bool VAL, bool BALLOT>
 __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kernel(
     const unsigned long long *__restrict__ in, const unsigned int *__restrict__ val_in,
-    const unsigned int *__restrict__ boff, SortBits SB, KeyLayout L, int64_t *__restrict__ row_out,
+    const unsigned int *__restrict__ boff, SortBits SB, KeyLayout L, BucketPlan B, int64_t *__restrict__ row_out,
     int64_t *__restrict__ col_out, int64_t *__restrict__ perm_out, const unsigned long long *__restrict__ hdr,
     int64_t *__restrict__ counts_out, int check4, const void *__restrict__ gather_src, void *__restrict__ gather_dst,
     int gather_bytes) {
@@ -1019,6 +1141,9 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
   }
   // decoded output, coalesced
   const unsigned long long imask = (1ull << L.idx_bits) - 1ull, cmask = (1ull << L.col_bits) - 1ull;
+  // strip mode: the words lost the level-1 bits of the key in the scatter; the bucket id has them
+  const unsigned long long keybase =
+      B.strip ? (unsigned long long)(blockIdx.x >> (B.bits - B.bits1)) << (L.key_bits - B.bits1) : 0ull;
   constexpr int kBatch = 4;
   for (int j0 = tid; j0 < n; j0 += THREADS * kBatch) {
     unsigned long long key[kBatch], e[kBatch];
@@ -1046,7 +1171,7 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
         pos = j - gt + lt;
       }
       o[k] = (size_t)start + (size_t)pos;
-      key[k] = wd >> L.idx_bits;
+      key[k] = keybase | (wd >> L.idx_bits);
       e[k] = wd & imask;
     }
     if constexpr (VAL) {
@@ -1105,29 +1230,53 @@ KeyLayout layout_for(int64_t E, int64_t M, int64_t N) {
 #define TSAMD_BK_SORT_ITEMS_VAL 12  // 6144 entries of 12 bytes
 #endif
 #ifndef TSAMD_BK_FILL_PCT
-#define TSAMD_BK_FILL_PCT 70        // planned mean fill of a bucket, per cent of the capacity
+#define TSAMD_BK_FILL_PCT 80        // planned mean fill of a bucket, per cent of the capacity
 #endif
 
 BucketPlan plan_buckets(int64_t E, int64_t M, int64_t N, const KeyLayout &L, bool val) {
-  BucketPlan B{0, 0, 0, 0, 0};
-  if (!L.packed || E < TSAMD_BK_MIN_ENTRIES) return B;
-  const int total = L.key_bits + L.idx_bits;
-  if (total < 2) return B;
+  BucketPlan B{0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (E < TSAMD_BK_MIN_ENTRIES) return B;
   B.cap = TSAMD_BK_SORT_THREADS * (val ? TSAMD_BK_SORT_ITEMS_VAL : TSAMD_BK_SORT_ITEMS);
-  // the part of the word space [0, 2^total) that the sizes can populate: words <= maxword
   const unsigned long long maxkey = (((unsigned long long)(M > 0 ? M - 1 : 0)) << L.col_bits) | (unsigned long long)(N > 0 ? N - 1 : 0);
-  const long double maxword = (long double)((maxkey << L.idx_bits) | (unsigned long long)(E - 1)) + 1.0L;
-  const long double frac = maxword / ((long double)(1ull << (total - 1)) * 2.0L);
-  for (int bits = 1; bits <= kBkMaxBits && bits <= total; ++bits) {
+  auto fill_ok = [&](long double frac, int bits) {
     const long double populated = frac * (long double)(1 << bits);
     const long double fill = (long double)E / (populated < 1.0L ? 1.0L : populated);
-    if (fill * 100.0L <= (long double)B.cap * TSAMD_BK_FILL_PCT) {
-      B.on = 1;
-      B.bits = bits;
-      B.nb = 1 << bits;
-      B.shift = total - bits;
-      return B;
+    return fill * 100.0L <= (long double)B.cap * TSAMD_BK_FILL_PCT;
+  };
+  // full words, one level: the bucket id is the top of the word space [0, 2^total) that the sizes can populate
+  const int total = L.key_bits + L.idx_bits;
+  if (L.packed && total >= 2) {
+    const long double maxword = (long double)((maxkey << L.idx_bits) | (unsigned long long)(E - 1)) + 1.0L;
+    const long double frac = maxword / ((long double)(1ull << (total - 1)) * 2.0L);
+    for (int bits = 1; bits <= kBkMaxBits && bits <= total; ++bits) {
+      if (fill_ok(frac, bits)) {
+        B.on = 1;
+        B.levels = 1;
+        B.strip = 0;
+        B.bits = B.bits1 = bits;
+        B.nb = 1 << bits;
+        B.shift = total - bits;
+        return B;
+      }
     }
+  }
+  // strip mode: the bucket id is the top of the KEY space; one or two levels
+  if (L.key_bits < 1 || L.key_bits + kBkTileBits > 64) return B;
+  const long double kfrac = ((long double)maxkey + 1.0L) / ((long double)(1ull << (L.key_bits - 1)) * 2.0L);
+  for (int bits = 1; bits <= kBkMaxTotalBits && bits <= L.key_bits; ++bits) {
+    if (!fill_ok(kfrac, bits)) continue;
+    const int levels = bits <= kBkMaxBits ? 1 : 2;
+    const int bits1 = levels == 1 ? bits : (bits + 1) / 2;
+    if (L.key_bits - bits1 + L.idx_bits > 64) return B;  // (more bits would only help with a third level)
+    B.on = 1;
+    B.levels = levels;
+    B.strip = 1;
+    B.bits = bits;
+    B.bits1 = bits1;
+    B.nb = 1 << bits;
+    B.kshift = L.key_bits - bits;
+    B.shift = L.key_bits - bits + L.idx_bits;
+    return B;
   }
   return B;
 }
@@ -1159,8 +1308,8 @@ SortBits sort_bits_for(int hi) {
 struct SortWs {
   unsigned long long *hdr, *hist, *tile_state, *a, *b;
   unsigned int *ia, *ib;
-  unsigned int *bhist, *boff, *cursor;
-  size_t zero_bytes;  // hdr + hist + bhist + tile_state are contiguous: one memset
+  unsigned int *bhist, *boff, *cursor, *cursor1;
+  size_t zero_bytes;  // hdr + hist + tile_state (+ the used part of bhist) are contiguous: one memset
 };
 
 size_t carve_sort(void *base, int64_t E, SortWs *ws) {
@@ -1176,12 +1325,13 @@ size_t carve_sort(void *base, int64_t E, SortWs *ws) {
   SortWs w;
   w.hdr = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * kHdrWords));
   w.hist = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * kMaxPasses * kRadix));
-  w.bhist = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxBuckets * kBkHistCopies));
   w.tile_state = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * ntiles * kRadix));
-  w.zero_bytes = off;
-  w.boff = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * (kBkMaxBuckets + 1)));
-  w.cursor = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxBuckets));
-  w.a = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * n));
+  w.zero_bytes = off;  // (+ the part of bhist a plan uses: sort_coo_onesweep)
+  w.bhist = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxHist * kBkHistCopies));
+  w.boff = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * (kBkMaxHist + 1)));
+  w.cursor = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxHist));
+  w.cursor1 = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxBuckets));
+  w.a = reinterpret_cast<unsigned long long *>(take(12 * n));  // built words / keys; level 2's output (12-byte records with values)
   w.b = reinterpret_cast<unsigned long long *>(take(12 * n));  // words, or the 12-byte records of the bucket path
   w.ia = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * n));
   w.ib = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * n));
@@ -1256,12 +1406,13 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
       TSAMD_HIP_TRY(hipMemcpyAsync(gather_dst, gather_src, (size_t)E * gather_bytes, hipMemcpyDeviceToDevice, stream));
     return TSAMD_OK;
   }
-  TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes, stream));
-  // a 4-byte value array rides through the passes of a packed sort
-  const bool ride = L.packed && gather_dst != nullptr && gather_bytes == 4 && L.passes >= 2;
+  // a 4-byte value array rides through the passes of a packed sort / through the bucket kernels
+  const bool want4 = gather_dst != nullptr && gather_bytes == 4;
+  const bool ride = L.packed && want4 && L.passes >= 2;
   const int64_t ntiles = ceil_div(E, kSortThreads * (L.packed ? (ride ? kItemsOf<true, true> : kItemsOf<true>) : kItemsOf<false>));
-  const BucketPlan B = plan_buckets(E, M, N, L, ride);
+  const BucketPlan B = plan_buckets(E, M, N, L, want4);
   const bool ballot = sort_rank_mode(stream) == 1;
+  TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes + (B.on ? sizeof(unsigned int) * (size_t)B.nb * kBkHistCopies : 0), stream));
   {
     const int64_t nb = ceil_div(E, kBuildThreads * 4);
     hipLaunchKernelGGL(sort_build_kernel, dim3((unsigned int)(nb < 512 ? nb : 512)), dim3(kBuildThreads), 0, stream,
@@ -1269,28 +1420,41 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
     TSAMD_LAUNCH_CHECK();
   }
   if (B.on) {
-    hipLaunchKernelGGL(bucket_plan_kernel, dim3(1), dim3(kBuildThreads), 0, stream, ws.bhist, ws.boff, ws.cursor, ws.hdr,
-                       todo, probe ? 1 : 0, B, E);
+    hipLaunchKernelGGL(bucket_plan_kernel, dim3(1), dim3(kBuildThreads), 0, stream, ws.bhist, ws.boff, ws.cursor,
+                       ws.cursor1, ws.hdr, todo, probe ? 1 : 0, B, E);
     TSAMD_LAUNCH_CHECK();
-    // bucket path: scatter into ws.b (values into ws.ia), sort every bucket in LDS, write the outputs.  Both kernels
-    // return at once unless the plan kernel raised hdr[kHdrFast]; the passes below return at once when it did (~5 us
+    // bucket path: scatter into ws.b (two levels: on into ws.a), sort every bucket in LDS, write the outputs.  These
+    // kernels return at once unless the plan kernel raised hdr[kHdrFast]; the passes below return at once when it did (~5 us
     // per kernel that returns at once; running that chain on a forked side stream was measured SLOWER, 0.205 vs
     // 0.193 ms at 7.5 M entries: the idle kernels queue behind the busy ones and the join waits for them).
     const SortBits SB = sort_bits_for(B.shift);
     const unsigned int *vin = reinterpret_cast<const unsigned int *>(gather_src);
-    if (ride) {
-      hipLaunchKernelGGL((bucket_scatter_kernel<true>), dim3((unsigned int)ceil_div(E, kBkScatterThreads * kBkScatterItems<true>)),
-                         dim3(kBkScatterThreads), 0, stream, ws.a, vin, E, B, ws.cursor, ws.b, ws.ia, ws.hdr);
+    unsigned int *cur1 = B.levels == 2 ? ws.cursor1 : ws.cursor;
+#define TSAMD_BK_SCATTER(V, LV, ST, SRC, DST, CUR)                                                                            \
+  hipLaunchKernelGGL((bucket_scatter_kernel<V, LV, ST>), dim3((unsigned int)ceil_div(E, kBkScatterThreads * kBkScatterItems<V>)), \
+                     dim3(kBkScatterThreads), 0, stream, SRC, vin, E, B, L, ws.boff, CUR, DST, ws.hdr)
+    if (B.strip) {
+      if (want4) TSAMD_BK_SCATTER(true, 1, true, ws.a, ws.b, cur1);
+      else TSAMD_BK_SCATTER(false, 1, true, ws.a, ws.b, cur1);
     } else {
-      hipLaunchKernelGGL((bucket_scatter_kernel<false>), dim3((unsigned int)ceil_div(E, kBkScatterThreads * kBkScatterItems<false>)),
-                         dim3(kBkScatterThreads), 0, stream, ws.a, vin, E, B, ws.cursor, ws.b, ws.ia, ws.hdr);
+      if (want4) TSAMD_BK_SCATTER(true, 1, false, ws.a, ws.b, cur1);
+      else TSAMD_BK_SCATTER(false, 1, false, ws.a, ws.b, cur1);
     }
     TSAMD_LAUNCH_CHECK();
+    const unsigned long long *sorted_in = ws.b;
+    if (B.levels == 2) {
+      if (want4) TSAMD_BK_SCATTER(true, 2, true, ws.b, ws.a, ws.cursor);
+      else TSAMD_BK_SCATTER(false, 2, true, ws.b, ws.a, ws.cursor);
+      TSAMD_LAUNCH_CHECK();
+      sorted_in = ws.a;
+    }
+#undef TSAMD_BK_SCATTER
 #define TSAMD_BK_SORT(ITEMS, V, BAL)                                                                                     \
   hipLaunchKernelGGL((bucket_sort_kernel<TSAMD_BK_SORT_THREADS, ITEMS, V, BAL>), dim3((unsigned int)B.nb),              \
-                     dim3(TSAMD_BK_SORT_THREADS), 0, stream, ws.b, ws.ia, ws.boff, SB, L, row_out, col_out, perm_out,    \
-                     ws.hdr, probe ? counts_out : (int64_t *)nullptr, check4 ? 1 : 0, gather_src, gather_dst, gather_bytes)
-    if (ride) {
+                     dim3(TSAMD_BK_SORT_THREADS), 0, stream, sorted_in, (const unsigned int *)nullptr, ws.boff, SB, L, B,  \
+                     row_out, col_out, perm_out, ws.hdr, probe ? counts_out : (int64_t *)nullptr, check4 ? 1 : 0,        \
+                     gather_src, gather_dst, gather_bytes)
+    if (want4) {
       if (ballot) TSAMD_BK_SORT(TSAMD_BK_SORT_ITEMS_VAL, true, true);
       else TSAMD_BK_SORT(TSAMD_BK_SORT_ITEMS_VAL, true, false);
     } else {

@@ -132,6 +132,31 @@ def test_bucket_path_bit_exact(dev, ops, E, m, n, kind):
     assert np.array_equal(rs.cpu().numpy(), er) and np.array_equal(cs.cpu().numpy(), ec)
 
 
+@pytest.mark.parametrize('E,m,n,kind', [
+    (3000000, (1 << 21) + 5, (1 << 21) - 3, 'uniform'),   # 65 bits: keys stripped of the bucket bits, one scatter level
+    (12500000, 1 << 21, 1 << 21, 'uniform'),              # 4096 buckets: two scatter levels (6 + 6 bits)
+    (24000000, 1 << 22, 1 << 22, 'tiny_l1'),              # 8192 buckets (7 + 6); 40 nearly empty level-1 buckets in front:
+])                                                        # the first tile's entries fall outside its counter window
+def test_bucket_path_two_levels_bit_exact(dev, ops, E, m, n, kind):
+    g = torch.Generator().manual_seed(E % 991)
+    if kind == 'tiny_l1':
+        few = 6000
+        cut = (m * 40) // 128
+        row = torch.cat([torch.randint(0, cut, (few, ), generator=g), torch.randint(cut, m, (E - few, ), generator=g)])
+        row = row[torch.randperm(E, generator=g)]
+    else:
+        row = torch.randint(0, m, (E, ), generator=g)
+    col = torch.randint(0, n, (E, ), generator=g)
+    q = E // 7
+    row[:q], col[:q] = row[q:2 * q].clone(), col[q:2 * q].clone()  # duplicates: stability is visible in perm
+    er, ec, ep = _check(ops, row, col, m, n, dev)
+    val = torch.rand(E, generator=g)
+    rs, cs, perm, counts, vs = ops.sort_coo_values(row.to(dev), col.to(dev), m, n, 3, None, val.to(dev))
+    assert np.array_equal(perm.cpu().numpy(), ep) and np.array_equal(rs.cpu().numpy(), er) and np.array_equal(cs.cpu().numpy(), ec)
+    assert np.array_equal(vs.cpu().numpy(), val.numpy()[ep])
+    assert counts.tolist()[2:] == [int(row.max()), int(col.max())]
+
+
 def test_rank_self_test_and_forced_ballot_ranking(dev, ops):
     """The stable rank of the radix kernels is a returning LDS atomic when the device-side self-test finds the lanes of
     one instruction served in ascending order, ballot matching otherwise.  Both must give the SAME permutation on
