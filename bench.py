@@ -200,7 +200,8 @@ def compact_row(r):
 HEAD_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
              'vs_baseline', 'dtype', 'data')
 ROOF_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'balg_over_peak',
-             'algorithmic_bytes_per_launch', 'b_min', 'kernel_ms', 'pre_ms', 'fixup_ms')
+             'algorithmic_bytes_per_launch', 'b_min', 'kernel_ms', 'pre_ms', 'fixup_ms', 'whole_op_balg_over_peak',
+             'whole_op_frac')
 MAX_LINE_BYTES = 6000
 
 
@@ -764,6 +765,13 @@ def _main():
                     roofline=roofline)
         if exchange_info is not None:
             exchange_info['exposed_ms'] = round(max(0.0, ms_per_step - exchange_info['spmm_only_ms']), 3)
+            # what the mandated design can reach at best with PERFECT overlap: the step cannot be shorter than the longer
+            # of the local product and the modelled exchange (print the expectation beside the measurement)
+            mod = exchange_info.get('modelled_exchange_ms')
+            if mod:
+                exchange_info['modelled_efficiency'] = round(
+                    exchange_info['spmm_only_ms'] / max(exchange_info['spmm_only_ms'], mod), 4)
+                exchange_info['measured_efficiency'] = round(exchange_info['spmm_only_ms'] / ms_per_step, 4)
             line['exchange'] = exchange_info
             # the N = 1 default of this script is ANOTHER workload (ns); the single-GPU rate of THIS workload -- the
             # reference point of a weak-scaling efficiency -- is the local SpMM without the exchange:

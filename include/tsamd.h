@@ -59,6 +59,11 @@ typedef enum { TSAMD_SUM = 0, TSAMD_MEAN = 1, TSAMD_MIN = 2, TSAMD_MAX = 3 } tsa
 /* Library / runtime identification.  Replaces torch_sparse::cuda_version
  * (csrc/version.cpp:26-41): returns HIP_VERSION the library was built with. */
 int64_t tsamd_hip_version(void);
+/* Bit 0: the library was built with -DTSAMD_EXPERIMENTS=1 (scripts/variants.py): alternative / rejected kernel
+ * variants are compiled in and TSAMD_* environment switches select them.  The shipped build returns 0: it reads no
+ * environment variable on any call path and contains none of those variants.  (No reference counterpart:
+ * csrc/version.cpp:26-41 only reports the toolkit version.) */
+int tsamd_build_flags(void);
 /* Last hipError_t observed by this library on the calling thread. */
 int tsamd_last_hip_error(void);
 /* Human-readable string for a tsamd_status. */

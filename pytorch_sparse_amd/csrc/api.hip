@@ -9,6 +9,14 @@ thread_local int g_last_hip_error = 0;
 
 extern "C" int64_t tsamd_hip_version(void) { return (int64_t)HIP_VERSION; }
 
+extern "C" int tsamd_build_flags(void) {
+#if defined(TSAMD_EXPERIMENTS)
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" int tsamd_last_hip_error(void) { return tsamd::g_last_hip_error; }
 
 extern "C" const char *tsamd_status_string(int status) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <limits>
 #include <type_traits>
 
@@ -26,6 +27,15 @@ extern thread_local int g_last_hip_error;
   } while (0)
 
 #define TSAMD_LAUNCH_CHECK() TSAMD_HIP_TRY(hipGetLastError())
+
+// Experiment switches (A/B runs of rejected or alternative variants: scripts/variants.py builds with
+// -DTSAMD_EXPERIMENTS=1) read the environment; the shipped library has none of them: exp_env() is a constant there
+// and the branches behind it fold away.
+#if defined(TSAMD_EXPERIMENTS)
+static inline const char *exp_env(const char *name) { return getenv(name); }
+#else
+static inline const char *exp_env(const char *) { return nullptr; }
+#endif
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

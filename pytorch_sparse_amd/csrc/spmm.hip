@@ -1244,7 +1244,7 @@ void plan_partition(int64_t M, int64_t E, int64_t row_bytes, int64_t *P, int64_t
   const int64_t total = M + E > 0 ? M + E : 1;
   int64_t cap = row_bytes <= 512 ? 256 : (row_bytes < 1024 ? 512 : 1024);
   if (row_bytes <= 128) cap = kShortRowItems;  // side-by-side short rows: long partitions amortise the batches
-  if (const char *env = getenv("TSAMD_SPMM_ITEMS")) {  // experiments
+  if (const char *env = exp_env("TSAMD_SPMM_ITEMS")) {  // experiments
     const long v = atol(env);
     if (v >= 64 && v <= 4096) cap = v;
   }
@@ -1268,7 +1268,7 @@ void plan_partition(int64_t M, int64_t E, int64_t row_bytes, int64_t *P, int64_t
 // F = 24 / 40 / 48 / 80 / 96 / 112 / 160 / 192 LOSE 13-25 % (they spread by themselves and only pay
 // for the copy and the hashing), 64-byte rows lose 2-10 %.  TSAMD_SPMM_RELABEL=1 still forces it.
 bool relabel_forced() {
-  const char *env = getenv("TSAMD_SPMM_RELABEL");
+  const char *env = exp_env("TSAMD_SPMM_RELABEL");
   return env != nullptr && env[0] == '1';
 }
 
@@ -1311,7 +1311,7 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.tail_arg = reinterpret_cast<uint32_t *>(minmax ? take(sizeof(uint32_t) * plane) : nullptr);
   w.relabel_mode = 0;
   w.relabel_flag = reinterpret_cast<int *>(take(256));
-  if (const char *env = getenv("TSAMD_SPMM_XPERM_PAD")) {  // experiments: shift the copy of X
+  if (const char *env = exp_env("TSAMD_SPMM_XPERM_PAD")) {  // experiments: shift the copy of X
     const long v = atol(env);
     if (v > 0 && v <= (64l << 20)) (void)take((size_t)v);
   }
@@ -1365,7 +1365,7 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   {
     int mode = 0;
     if (ws.xperm != nullptr && VEC > 1 && !ws.out_relabel) {
-      const char *env = getenv("TSAMD_SPMM_RELABEL");
+      const char *env = exp_env("TSAMD_SPMM_RELABEL");
       mode = env ? (env[0] == '1' ? 1 : (env[0] == '0' ? 0 : 2)) : 2;
     }
     // masked sums (the pull of the min / max backward): `col` points at winner records, not at column ids, so there

@@ -747,7 +747,7 @@ int launch_value_bw_masked(const int64_t *row, const int64_t *rowptr, const int6
   const uint32_t lpr = slots >= 64 ? 64u : (1u << ilog2_ceil(slots));
   const int lgG = 6 - ilog2_ceil(lpr);
   const unsigned int blocks = (unsigned int)ceil_div(ceil_div(E, kWave), kWavesPerBlock);
-  const char *env_pipe = getenv("TSAMD_MASKED_SDDMM_PIPE");  // experiments: 0 = the round-4 kernel
+  const char *env_pipe = exp_env("TSAMD_MASKED_SDDMM_PIPE");  // experiments: 0 = the round-4 kernel
   const bool pipelined = !(env_pipe != nullptr && env_pipe[0] == '0');
   if (pipelined && slots <= 64u && K % VEC == 0 && (uint64_t)kWave * rec_stride < (1ull << 32)) {
     hipLaunchKernelGGL((spmm_value_bw_masked_kernel<T>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, stream, row,
@@ -843,7 +843,7 @@ extern "C" int tsamd_spmm_value_bw(int dtype, int reduce, const int64_t *row,
 // narrowing pass over [B,N,K]).
 static bool minmax_bw_shadow(int dtype) {
   if (dtype != TSAMD_F16 && dtype != TSAMD_BF16) return false;
-  const char *env = getenv("TSAMD_MINMAX_BW_SHADOW");
+  const char *env = exp_env("TSAMD_MINMAX_BW_SHADOW");
   return env != nullptr && env[0] == '1';
 }
 
@@ -935,9 +935,14 @@ static size_t winrec_bytes(int64_t B, int64_t K, int64_t E) {
 // only for bf16 F = 64 (1.58 vs 1.75) and fp32 F = 256 (4.30 vs 4.43).  Kept as an option, bit-identical results
 // for value-less narrow types, tests/test_spmm_gpu.py runs both.
 static bool use_lists(int dtype, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E) {
-  const char *env = getenv("TSAMD_MINMAX_BW_LISTS");
+#if defined(TSAMD_EXPERIMENTS)
+  const char *env = exp_env("TSAMD_MINMAX_BW_LISTS");
   if (env == nullptr || env[0] != '1') return false;
   return minmax_bw_lists_supported(dtype, B, M, N, K, E);
+#else
+  (void)dtype; (void)B; (void)M; (void)N; (void)K; (void)E;
+  return false;  // (csrc/spmm_bw_list.hip is only compiled into experiment builds)
+#endif
 }
 
 extern "C" size_t tsamd_spmm_minmax_bw_csc_workspace_bytes(int dtype, int64_t B, int64_t M, int64_t N,
@@ -945,7 +950,11 @@ extern "C" size_t tsamd_spmm_minmax_bw_csc_workspace_bytes(int dtype, int64_t B,
   if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
   // the masked sum runs on the transposed matrix: N rows, M columns
   const size_t masked = winrec_bytes(B, K, E) + spmm_masked_sum_workspace_bytes(dtype, B, N, M, K, E);
+#if defined(TSAMD_EXPERIMENTS)
   const size_t lists = minmax_bw_lists_supported(dtype, B, M, N, K, E) ? minmax_bw_lists_workspace_bytes(dtype, B, M, N, K, E) : 0;
+#else
+  const size_t lists = 0;
+#endif
   return masked > lists ? masked : lists;
 }
 
@@ -968,6 +977,7 @@ static int minmax_bw_csc_impl(int dtype, const int64_t *rowptr, const int64_t *c
   if (total > 0 && (!rowptr || !col || !mat || !grad_out || !arg_out)) return TSAMD_ERR_INVALID;
   if (grad_mat && E > 0 && (!colptr || !csr2csc || !row)) return TSAMD_ERR_INVALID;
   const size_t es = dtype_size(dtype);
+#if defined(TSAMD_EXPERIMENTS)
   if (grad_mat && total > 0 && E > 0 && B * N * K > 0 && use_lists(dtype, B, M, N, K, E)) {
     if (arg32) return TSAMD_ERR_UNSUPPORTED;  // the (opt-in) list route reads int64 ids: the caller widens them
     if (!workspace || workspace_bytes < minmax_bw_lists_workspace_bytes(dtype, B, M, N, K, E) ||
@@ -981,6 +991,7 @@ static int minmax_bw_csc_impl(int dtype, const int64_t *rowptr, const int64_t *c
     return minmax_bw_lists(dtype, row, col, value, grad_out, arg_out, colptr, csr2csc, grad_mat, B, M, N, K, E,
                            workspace, stream);
   }
+#endif
   // grad_value as a masked SDDMM over the records needs 16-byte packets; else the row-parallel LDS kernel
   const bool sddmm_ok = grad_value && row && (K * (int64_t)es) % 16 == 0 && ((uintptr_t)mat % 16) == 0 &&
                         ((uintptr_t)grad_out % 16) == 0;

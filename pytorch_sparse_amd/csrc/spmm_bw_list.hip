@@ -22,6 +22,7 @@
 //   3. listfix_kernel folds in position order.
 // Deterministic (fixed partition, fixed order of the LDS adds), no global atomics, grad_mat needs no memset
 // beyond the one for columns without entries.
+#if defined(TSAMD_EXPERIMENTS)  // measured slower than the mask route (profiles/r04_minmax_bw_routes.md): experiment builds only
 #include "common.h"
 #include "spmm_internal.h"
 
@@ -541,3 +542,4 @@ int minmax_bw_lists(int dtype, const int64_t *row, const int64_t *col, const voi
 }
 
 }  // namespace tsamd
+#endif  // TSAMD_EXPERIMENTS

@@ -1989,7 +1989,7 @@ size_t carve_large(void *base, int64_t n_large, int64_t P_large, int64_t N, size
   if (l.nr < 1) l.nr = 1;
   l.ntask = n_large * (int64_t)l.nr;
   static const bool subbins = [] {  // TSAMD_SPSPMM_SUBBINS=0 in the environment: the round-4 shared cursors (A/B runs)
-    const char *e = getenv("TSAMD_SPSPMM_SUBBINS");
+    const char *e = exp_env("TSAMD_SPSPMM_SUBBINS");
     return e ? e[0] != '0' : (TSAMD_SPSPMM_SUBBINS != 0);
   }();
   l.sub = (subbins && l.nr <= kMaxRanges / (kLargeThreads / 64)) ? kLargeThreads / 64 : 1;
@@ -2058,7 +2058,7 @@ unsigned int persistent_blocks() {
 // for the round-4 footprint of kMaxRanges counters: same-box A/B runs of the occupancy effect)
 static size_t large_counter_bytes(int nr, int sub) {
   static const bool fat = [] {
-    const char *e = getenv("TSAMD_SPSPMM_STATIC_COUNTERS");
+    const char *e = exp_env("TSAMD_SPSPMM_STATIC_COUNTERS");
     return e != nullptr && e[0] == '1';
   }();
   const size_t n = fat ? (size_t)kMaxRanges : (size_t)nr * (size_t)sub;

@@ -4,8 +4,9 @@ Covers construction, format views (coo/csr/csc), caches, dtype/device plumbing, 
 torch.sparse conversions, and -- attached by the sibling modules, as the reference does --
 ``matmul/spmm/spspmm/@``, ``t()``, ``coalesce()``, reductions, element-wise ``mul/add``, diagonal
 edits, ``narrow/select/index_select/masked_select/permute/[]``, ``sample/sample_adj``,
-``random_walk``, ``saint_subgraph`` and ``reverse_cuthill_mckee``.  Not provided: the heterogeneous /
-temporal samplers and the METIS partitioner.
+``random_walk``, ``saint_subgraph`` and ``reverse_cuthill_mckee``.  Not provided: ``hgt_sample``,
+``ego_k_hop_sample_adj`` and the METIS partitioner; the heterogeneous / temporal neighbour
+samplers are operators (``torch.ops.torch_sparse.hetero_neighbor_sample`` / ``hetero_temporal_neighbor_sample``).
 
 Like the reference's (tensor.py:12) the class is a TorchScript class: ``torch.jit.script`` functions and
 modules can take, build and return it (``matmul(adj, x, reduce)`` inside a scripted ``nn.Module``,

@@ -11,7 +11,8 @@ def build(name, defs, sources=None):
     os.makedirs(OUT, exist_ok=True)
     so = os.path.join(OUT, name + '.so')
     cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
-    cmd += ['-D' + d for d in defs] + [os.path.join(CSRC, s) for s in sources] + ['-o', so]
+    # (variants are experiment builds: the TSAMD_* environment switches and the rejected kernel variants are compiled in)
+    cmd += ['-DTSAMD_EXPERIMENTS=1'] + ['-D' + d for d in defs] + [os.path.join(CSRC, s) for s in sources] + ['-o', so]
     subprocess.check_call(cmd)
     return so
 if __name__ == '__main__':

@@ -714,6 +714,25 @@ def run_c1(dev, cpu=True, iters=50):
                                    sample='full workload; the ATen call sequence of torch_sparse/spmm.py:25-31 '
                                           '(index_select, mul, scatter_add_), one thread, best of %d' % runs)
         res['cpu_baseline']['port_matches_fixture'] = bool(torch.allclose(ro, torch.from_numpy(z['out']), rtol=1e-5, atol=1e-6))
+        # BASELINE.json words configs[0] "via csrc/cpu reference": the same product through the COMPILED reference
+        # kernels that travel to the GPU box (oracle/_ref: ind2ptr_cpu + spmm_cpu of csrc/cpu/convert_cpu.cpp:7-35,
+        # spmm_cpu.cpp:8-101) behind a host sort by (row, col) -- the route SparseTensor.matmul takes in the reference.
+        # When it is available THIS is the row's cpu_baseline (kind "reference"); the ATen port's time stays beside it.
+        r = _ref_ops()
+        if r is not None:
+            def ref_route():
+                perm = torch.argsort(ic[0] * n + ic[1], stable=True)
+                rs, cs, vs = ic[0][perm], ic[1][perm], vc[perm]
+                return r.spmm_sum(None, r.ind2ptr(rs, m), cs, vs, None, None, xc)
+            t2, ro2, runs2 = cpu_time(ref_route, budget_s=2.0, max_reps=200)
+            port = res['cpu_baseline']
+            res['cpu_baseline'] = dict(
+                value=round(E / t2 / 1e9, 5), unit='GEdges/s', cores=1, kind='reference', ms=round(t2 * 1e3, 4),
+                sample='full workload; host argsort by (row, col) + the compiled reference ind2ptr_cpu + spmm_cpu '
+                       '(oracle/_ref), one thread, best of %d' % runs2,
+                reference_matches_fixture=bool(torch.allclose(ro2, torch.from_numpy(z['out']), rtol=1e-5, atol=1e-5)),
+                port_ms=port['ms'], port_matches_fixture=port['port_matches_fixture'],
+                port_note='the ATen call chain of torch_sparse/spmm.py:25-31 (index_select, mul, scatter_add_), same thread count')
     return res
 
 

@@ -87,3 +87,84 @@ def test_overlapped_training_step_two_ranks_one_gpu(dev):
     for rank, res in results.items():
         for reduce, oks in res.items():
             assert all(oks), (rank, reduce, oks)
+
+
+def _nccl_world1_worker(port, q):
+    """RCCL with ONE rank on the real device: library load, communicator creation on a HIP stream, the async work
+    handles of all_gather_into_tensor / reduce_scatter_tensor / all_to_all_single and every exchange of parallel.py
+    (forward + backward), all through backend 'nccl' -- what N > 1 runs, minus the second device."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    res = {}
+    try:
+        import pytorch_sparse_amd as ts
+        from pytorch_sparse_amd import synth
+        from pytorch_sparse_amd.parallel import shard_matrix
+        # the raw collectives with async_op=True, on a side stream like the overlapped plan uses them
+        a = torch.arange(1 << 16, device=dev, dtype=torch.float32)
+        out = torch.empty_like(a)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            w1 = dist.all_gather_into_tensor(out, a, async_op=True)
+        w1.wait()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        res['all_gather'] = bool(torch.equal(out, a))
+        rs = torch.empty_like(a)
+        w2 = dist.reduce_scatter_tensor(rs, a.clone(), async_op=True)
+        w2.wait()
+        res['reduce_scatter'] = bool(torch.equal(rs, a))
+        a2a = torch.empty_like(a)
+        dist.all_to_all_single(a2a, a)
+        res['all_to_all'] = bool(torch.equal(a2a, a))
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)
+        res['all_reduce'] = bool(t.sum().item() == 4.0)
+        # every exchange of parallel.py at world 1 against the plain product, forward and both gradients
+        rp, c = synth.rmat_csr(11, 12, seed=4, device=dev)
+        n, K = rp.numel() - 1, 32
+        v = synth.values(c.numel(), device=dev)
+        x = synth.features(n, K, device=dev)
+        g = synth.features(n, K, seed=5, device=dev)
+        for exchange in ('allgather', 'allgather_serial', 'halo', 'pipelined'):
+            kw = dict(chunks=3) if exchange in ('allgather', 'pipelined') else {}
+            for reduce in ('sum', 'max'):
+                if reduce == 'max' and exchange != 'allgather':
+                    continue
+                xl = x.clone().requires_grad_()
+                vl = v.clone().requires_grad_()
+                op, (s, e) = shard_matrix(rp, c, vl, n, balance='nnz', exchange=exchange, **kw)
+                out = op(xl, reduce)
+                out.backward(g)
+                vg, xg = v.clone().requires_grad_(), x.clone().requires_grad_()
+                A = ts.SparseTensor(rowptr=rp, col=c, value=vg, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
+                ref = A.matmul(xg, reduce)
+                ref.backward(g)
+                res['%s_%s' % (exchange, reduce)] = bool(
+                    torch.allclose(out.detach(), ref.detach(), rtol=1e-5, atol=1e-5) and
+                    torch.allclose(xl.grad, xg.grad, rtol=1e-4, atol=1e-4) and
+                    torch.allclose(vl.grad, vg.grad, rtol=1e-4, atol=1e-5))
+        torch.cuda.synchronize()
+        q.put(res)
+    except Exception as exc:  # noqa: BLE001 -- reported to the parent
+        q.put({'error': repr(exc)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_collectives_and_exchanges(dev):
+    """nothing in parallel.py had met RCCL.  One rank, backend 'nccl' (= RCCL), real device."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        res = q.get(timeout=240)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert 'error' not in res, res
+    assert res and all(res.values()), res

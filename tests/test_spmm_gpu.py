@@ -10,7 +10,7 @@ import torch
 from oracle import c_oracle as oc
 from pytorch_sparse_amd import _native as nat
 from pytorch_sparse_amd import synth
-from tests.util import (ALL_DTYPES, CODE, FLOAT_DTYPES, SUM_ATOL, SUM_TOL, bits_equal, check_spmm, fromnp,
+from tests.util import (ALL_DTYPES, CODE, FLOAT_DTYPES, SUM_ATOL, SUM_TOL, bits_equal, check_spmm, experiments_build, fromnp,
                         oracle_spmm, tonp)
 
 pytestmark = pytest.mark.gpu
@@ -227,6 +227,12 @@ def _csc_arrays(rp, c, n_cols):
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float64])
 def test_minmax_bw_winner_lists_hub_columns(dev, dtype):
+    if not experiments_build():
+        pytest.skip('the winner-list route is only compiled into experiment builds (scripts/variants.py)')
+    _minmax_bw_winner_lists_hub_columns(dev, dtype)
+
+
+def _minmax_bw_winner_lists_hub_columns(dev, dtype):
     """The winner-list route of tsamd_spmm_minmax_bw_csc (csrc/spmm_bw_list.hip, TSAMD_MINMAX_BW_LISTS=1, K <= 1024) on a
     power-law graph whose hub columns span many 256-position waves of the pull kernel (head / tail carries + fix-up)
     and whose long rows span many 64-entry chunks of the list kernel (offsets of cut rows): against the default route
@@ -284,6 +290,8 @@ def pull_route(request):
     winner lists (TSAMD_MINMAX_BW_LISTS=1)."""
     import os
     if request.param == 'lists':
+        if not experiments_build():
+            pytest.skip('the winner-list route is only compiled into experiment builds (scripts/variants.py)')
         os.environ['TSAMD_MINMAX_BW_LISTS'] = '1'
     yield request.param
     os.environ.pop('TSAMD_MINMAX_BW_LISTS', None)
@@ -391,6 +399,12 @@ def test_minmax_arg32_forward_and_pull(dev, dtype):
 
 @pytest.mark.parametrize('dtype', FLOAT_DTYPES)
 def test_masked_sddmm_pipelined_against_round4_kernel(dev, dtype):
+    if not experiments_build():
+        pytest.skip('TSAMD_MASKED_SDDMM_PIPE is only read by experiment builds (scripts/variants.py)')
+    _masked_sddmm_pipelined_against_round4_kernel(dev, dtype)
+
+
+def _masked_sddmm_pipelined_against_round4_kernel(dev, dtype):
     """grad_value of the pull backward: the pipelined masked SDDMM (record words of 8 steps in one round trip, the
     gathers of two steps in flight, v_dot2c for 2-byte types) against the round-4 kernel (TSAMD_MASKED_SDDMM_PIPE=0)
     for every lane-group width (1 ... 64 packets per row, also counts that are not powers of two), batches, a chunk
@@ -598,6 +612,8 @@ def test_relabel_path_is_bit_identical(dev, dtype, monkeypatch):
     rp, c = synth.to_csr(row, col, m, n)
     v, x = make_inputs(rp, c, n, K, dtype, True, batch=(2, ))
     res = {}
+    if not experiments_build():
+        pytest.skip('TSAMD_SPMM_RELABEL is only read by experiment builds; tests/test_relabelled_gpu.py covers the copy')
     for mode in ('0', '1', 'auto'):
         monkeypatch.setenv('TSAMD_SPMM_RELABEL', mode)
         for reduce in ('sum', 'max'):

@@ -16,6 +16,13 @@ SUM_TOL = {torch.float32: 1e-5, torch.float64: 1e-13, torch.float16: 2e-3, torch
 SUM_ATOL = {torch.float32: 1e-37, torch.float64: 1e-300, torch.float16: 6e-8, torch.bfloat16: 1e-37}
 
 
+def experiments_build():
+    """True when the loaded libtsamd.so was built with -DTSAMD_EXPERIMENTS=1 (scripts/variants.py): only then do the
+    TSAMD_* environment switches select the alternative kernel variants (include/tsamd.h: tsamd_build_flags)."""
+    from pytorch_sparse_amd import _native as nat
+    return bool(nat.lib().tsamd_build_flags() & 1)
+
+
 def tonp(t):
     if t is None:
         return None
