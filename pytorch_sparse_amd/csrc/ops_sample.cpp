@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <map>
+#include <unordered_map>
 
 namespace tsamd_ops {
 namespace {
@@ -356,6 +357,45 @@ struct HeteroSetup {
   Tensor any;                           // some device tensor (options / device of the outputs)
 };
 
+// largest id of an index array, remembered per (data pointer, length, version counter): see hetero_setup
+struct MaxKey {
+  const void *data;
+  int64_t numel;
+  uint64_t version;
+  bool operator==(const MaxKey &o) const { return data == o.data && numel == o.numel && version == o.version; }
+};
+struct MaxKeyHash {
+  size_t operator()(const MaxKey &k) const {
+    return std::hash<const void *>()(k.data) ^ (std::hash<int64_t>()(k.numel) * 1000003u) ^ (std::hash<uint64_t>()(k.version) * 7919u);
+  }
+};
+// (an entry also holds the tensor's storage WEAKLY: while that storage is alive its address cannot be handed to another
+// tensor, so pointer + length + version identify the contents; once it has expired the entry is dead)
+struct MaxEntry {
+  int64_t value;
+  c10::weak_intrusive_ptr<c10::StorageImpl> storage;
+};
+std::mutex g_max_cache_mutex;
+std::unordered_map<MaxKey, MaxEntry, MaxKeyHash> g_max_cache;
+
+bool max_cache_lookup(const MaxKey &k, int64_t *out) {
+  std::lock_guard<std::mutex> lock(g_max_cache_mutex);
+  auto it = g_max_cache.find(k);
+  if (it == g_max_cache.end()) return false;
+  if (it->second.storage.expired()) {
+    g_max_cache.erase(it);
+    return false;
+  }
+  *out = it->second.value;
+  return true;
+}
+void max_cache_store(const MaxKey &k, int64_t v, const Tensor &t) {
+  std::lock_guard<std::mutex> lock(g_max_cache_mutex);
+  if (g_max_cache.size() > 1024) g_max_cache.clear();
+  g_max_cache.erase(k);
+  g_max_cache.emplace(k, MaxEntry{v, c10::weak_intrusive_ptr<c10::StorageImpl>(t.storage().getWeakStorageImpl())});
+}
+
 HeteroSetup hetero_setup(const std::vector<node_t> &node_types, const std::vector<edge_t> &edge_types,
                          const TensorDict &colptr_dict, const TensorDict &row_dict, const TensorDict &input_node_dict,
                          const c10::Dict<rel_t, std::vector<int64_t>> &num_neighbors_dict) {
@@ -376,19 +416,47 @@ HeteroSetup hetero_setup(const std::vector<node_t> &node_types, const std::vecto
     n = std::max<int64_t>(n, cp.numel() - 1);
   }
   TORCH_CHECK(have, "hetero_neighbor_sample: no relations");
-  // source types: the largest id any relation or input refers to (one read-back per tensor, setup only)
+  // source types: the largest id any relation or input refers to.  The relations' row arrays are the graph -- the same
+  // tensors call after call: their maxima are remembered per (data pointer, length, version counter); what is left
+  // (first call: every array; later: the input nodes of the mini-batch) is reduced on the device and read back in ONE
+  // transfer (round 5 paid one reduction over the relation's whole edge list + one host sync per dict entry, per call).
+  std::vector<Tensor> pending;              // 0-dim device maxima still to be read
+  std::vector<int64_t *> pending_dst;       // where each goes (num_nodes entry), as max(n, value + 1)
+  std::vector<MaxKey> pending_key;          // cache slot to fill (data == nullptr: not cached)
+  std::vector<Tensor> pending_src;
   for (const auto &kv : row_dict) {
     const Tensor &r = kv.value();
     check_index(r, "row");
     auto &n = hs.num_nodes[std::get<0>(hs.to_edge_type.at(kv.key()))];
-    if (r.numel() > 0) n = std::max<int64_t>(n, r.max().item<int64_t>() + 1);
+    if (r.numel() == 0) continue;
+    const MaxKey key{r.data_ptr(), r.numel(), (uint64_t)r._version()};
+    int64_t cached = 0;
+    if (max_cache_lookup(key, &cached)) {
+      n = std::max<int64_t>(n, cached + 1);
+    } else {
+      pending.push_back(r.max());
+      pending_dst.push_back(&n);
+      pending_key.push_back(key);
+      pending_src.push_back(r);
+    }
   }
   for (const auto &kv : input_node_dict) {
     const Tensor &x = kv.value();
     check_index(x, "input_node");
     TORCH_CHECK(hs.num_nodes.count(kv.key()), "unknown node type ", kv.key());
-    auto &n = hs.num_nodes[kv.key()];
-    if (x.numel() > 0) n = std::max<int64_t>(n, x.max().item<int64_t>() + 1);
+    if (x.numel() == 0) continue;
+    pending.push_back(x.max());
+    pending_dst.push_back(&hs.num_nodes[kv.key()]);
+    pending_key.push_back(MaxKey{nullptr, 0, 0});
+    pending_src.push_back(x);
+  }
+  if (!pending.empty()) {
+    const Tensor host = torch::stack(pending).cpu();  // the one read-back of the set-up
+    const int64_t *h = host.data_ptr<int64_t>();
+    for (size_t i = 0; i < pending.size(); ++i) {
+      *pending_dst[i] = std::max<int64_t>(*pending_dst[i], h[i] + 1);
+      if (pending_key[i].data != nullptr) max_cache_store(pending_key[i], h[i], pending_src[i]);
+    }
   }
   for (const auto &kv : num_neighbors_dict) hs.rels_sorted.push_back(kv.key());
   std::sort(hs.rels_sorted.begin(), hs.rels_sorted.end());

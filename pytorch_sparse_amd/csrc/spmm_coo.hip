@@ -33,7 +33,7 @@ __device__ __forceinline__ void lds_add<int64_t>(int64_t *p, int64_t v) {
 template <typename T>
 __global__ __launch_bounds__(kCooThreads) void spmm_coo_small_kernel(
     const int64_t *__restrict__ row, const int64_t *__restrict__ col, const T *__restrict__ value,
-    const T *__restrict__ mat, T *__restrict__ out, int64_t E, int64_t M, int K, int rows_per_wg) {
+    const T *__restrict__ mat, T *__restrict__ out, int64_t E, int64_t M, int64_t N, int K, int rows_per_wg) {
   using A = typename Traits<T>::acc_t;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kCooAccBytes];
   A *acc = reinterpret_cast<A *>(s_raw);
@@ -56,6 +56,10 @@ __global__ __launch_bounds__(kCooThreads) void spmm_coo_small_kernel(
       const int64_t e = base + u * kCooThreads + threadIdx.x;
       mine[u] = r[u] >= r0 && r[u] < r1;
       c[u] = mine[u] ? col[e] : 0;
+      // an entry whose column id lies outside [0, N) is skipped, like one whose row id lies outside [0, M): the
+      // reference's index_select / scatter_add raise a device assert for both (torch_sparse/spmm.py:25-31); nothing
+      // here reads or writes out of bounds
+      mine[u] = mine[u] && (uint64_t)c[u] < (uint64_t)N;
       w[u] = mine[u] ? Traits<T>::to_acc(value[e]) : (A)0;
     }
 #pragma unroll
@@ -119,7 +123,7 @@ extern "C" int tsamd_spmm_coo_small(int dtype, const int64_t *row, const int64_t
   return TSAMD_DISPATCH_DTYPE_ALL(dtype, [&]() -> int {
     hipLaunchKernelGGL((spmm_coo_small_kernel<scalar_t>), dim3((unsigned int)G), dim3(kCooThreads), 0, stream, row, col,
                        reinterpret_cast<const scalar_t *>(value), reinterpret_cast<const scalar_t *>(mat),
-                       reinterpret_cast<scalar_t *>(out), E, M, (int)K, (int)R);
+                       reinterpret_cast<scalar_t *>(out), E, M, N, (int)K, (int)R);
     TSAMD_LAUNCH_CHECK();
     return TSAMD_OK;
   });

@@ -21,7 +21,10 @@ def spmm(index: Tensor, value: Tensor, m: int, n: int, matrix: Tensor) -> Tensor
     # ranges of `out` in LDS and scan the entries) -- what the reference's three ATen calls do, without the [nnz, F]
     # temporary; the sorted route below costs 8+ launches whatever the size
     wants_grad = torch.is_grad_enabled() and (value.requires_grad or matrix.requires_grad)
-    if matrix.is_cuda and not wants_grad and m * matrix.size(-1) > 0:
+    # (its floating-point sums are accumulated through LDS atomics in arrival order: not taken when deterministic
+    # algorithms are asked for -- the sorted route below adds a row's entries in a fixed order)
+    if (matrix.is_cuda and not wants_grad and m * matrix.size(-1) > 0 and
+            not (matrix.is_floating_point() and torch.ops.tsamd.deterministic())):
         out = torch.ops.tsamd.spmm_coo_small(index, value, m, n, matrix)  # (an empty tensor: not taken)
         if out.dim() == 2:
             return out

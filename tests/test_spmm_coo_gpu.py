@@ -96,3 +96,34 @@ def test_small_coo_route_is_one_launch_and_skipped_under_autograd(dev):
     assert v2.grad is not None and x2.grad is not None
     # too big for the direct route: falls through to the sorted one
     assert not torch.ops.tsamd.spmm_coo_small_supported(value, 1 << 20, 300, 16)
+
+
+def test_small_coo_skips_ids_out_of_range_and_honours_deterministic_mode(dev):
+    """a column id outside [0, N) must not read past `mat` (the entry is skipped, like a row id outside
+    [0, M)); under torch.use_deterministic_algorithms(True) the call takes the sorted route, whose sums are reproducible
+    (the one-launch route adds through LDS atomics in arrival order)."""
+    import pytorch_sparse_amd as ts
+    E, m, n, K = 3000, 200, 150, 16
+    index, value, x = _inputs(E, m, n, K, torch.float32, seed=9)
+    bad = index.clone()
+    bad[1, 7] = n            # one past the last column
+    bad[1, 1234] = -3        # negative
+    bad[1, 2999] = 1 << 40   # far out
+    keep = torch.ones(E, dtype=torch.bool)
+    keep[[7, 1234, 2999]] = False
+    out = ts.spmm(bad.to(dev), value.to(dev), m, n, x.to(dev))
+    want, l1 = _expected(index[:, keep], value[keep], x, m)
+    err = (out.cpu().double() - want).abs()
+    assert bool((err <= 1e-5 * l1 + 1e-30).all())
+    # deterministic algorithms: bit-identical run to run, and equal to the sorted route
+    index_d, value_d, x_d = index.to(dev), value.to(dev), x.to(dev)
+    was = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True)
+    try:
+        a = ts.spmm(index_d, value_d, m, n, x_d)
+        b = ts.spmm(index_d, value_d, m, n, x_d)
+    finally:
+        torch.use_deterministic_algorithms(was)
+    assert torch.equal(a, b)
+    v2 = value_d.clone().requires_grad_()  # (autograd: the sorted route as well)
+    assert torch.equal(a, ts.spmm(index_d, v2, m, n, x_d).detach())
