@@ -247,6 +247,7 @@ class _OverlappedProduct(torch.autograd.Function):
         ctx.plan, ctx.reduce, ctx.has_value = plan, reduce, value is not None
         ctx.n_local = x_local.size(0)
         ctx.mats = [x_pad] + list(bufs)
+        ctx.mat_versions = [m._version for m in ctx.mats]  # (plain attributes, not save_for_backward: checked by hand)
         ctx.vals = vals
         ctx.arg = arg
         return out
@@ -256,6 +257,14 @@ class _OverlappedProduct(torch.autograd.Function):
         plan, reduce = ctx.plan, ctx.reduce
         g = g.contiguous()
         mats, vals, arg = ctx.mats, ctx.vals, ctx.arg
+        if mats is None:
+            # the landed buffers (up to the whole of X) are freed by the first backward: keeping them for
+            # retain_graph=True would hold N x F elements per step
+            raise RuntimeError('_OverlappedProduct: backward called a second time; the gathered operand of the forward was '
+                               'released by the first one (retain_graph=True is not supported by the overlapped all-gather; '
+                               'use RowShardedSpMM for that)')
+        if any(m._version != ver for m, ver in zip(mats, ctx.mat_versions)):
+            raise RuntimeError('_OverlappedProduct: a buffer saved for the backward was modified in place after the forward')
         need_v = ctx.has_value and ctx.needs_input_grad[1]
         minmax = reduce in ('min', 'max')
         if reduce == 'mean':
@@ -333,7 +342,16 @@ class OverlappedAllGatherSpMM(object):
     def __init__(self, rowptr: Tensor, col: Tensor, value: Optional[Tensor], x_sizes: Sequence[int],
                  group=None, spmm_fn: Optional[Callable] = None, chunks: int = 4,
                  partial_fn: Optional[Callable] = None, positions_fn: Optional[Callable] = None,
-                 value_bw_fn: Optional[Callable] = None, minmax_bw_fn: Optional[Callable] = None):
+                 value_bw_fn: Optional[Callable] = None, minmax_bw_fn: Optional[Callable] = None,
+                 agree: str = 'never'):
+        assert agree in ('never', 'always', 'once')
+        # how the ranks settle the autograd path of a call whose `differentiable` is left to be decided (the backward
+        # issues world-wide reduce-scatters: ranks that disagree deadlock).  'never' (default): every rank decides from
+        # its own grad mode / requires_grad -- right when all ranks run the same training loop; 'always' / 'once': one
+        # all_reduce per call / per local state first, as PipelinedHaloSpMM does
+        self.agree = agree
+        self.agreements = 0
+        self._agreed = {}
         self.group = group
         self.spmm_fn = spmm_fn or _default_spmm
         self.partial_fn = partial_fn or _native_partial
@@ -439,6 +457,17 @@ class OverlappedAllGatherSpMM(object):
         if differentiable is None:
             differentiable = torch.is_grad_enabled() and (
                 x_local.requires_grad or (self.value is not None and self.value.requires_grad))
+            if self.agree != 'never':
+                key = (torch.is_grad_enabled(), differentiable)
+                verdict = self._agreed.get(key) if self.agree == 'once' else None
+                if verdict is None:
+                    flag = torch.tensor([1 if differentiable else 0], dtype=torch.int32, device=x_local.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                    self.agreements += 1
+                    verdict = bool(int(flag))
+                    if self.agree == 'once':
+                        self._agreed[key] = verdict
+                differentiable = verdict
         if differentiable:
             return self._differentiable(x_local, reduce)
         x_pad = self.wire_order(x_local.detach())

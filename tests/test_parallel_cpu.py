@@ -79,7 +79,14 @@ def _worker(rank, world, port, balance, q, exchange='allgather'):
                 continue
             out_local = op(x_local, reduce)
             res[reduce] = bool(np.array_equal(out_local.numpy(), full[s:e]))
-        if hasattr(op, '_agreed'):  # pipelined halo: by default every call settles its autograd path with one collective;
+        if exchange == 'allgather':  # overlapped all-gather: the agreement is opt-in
+            assert op.agree == 'never' and op.agreements == 0
+            op.agree = 'always'
+            assert np.allclose(op(x_local, 'sum').numpy(), oc.spmm(oc.F32, 'sum', rp.numpy(), c.numpy(), v.numpy(),
+                                                                    x.numpy())[0][s:e], rtol=1e-5, atol=1e-5)
+            assert op.agreements == 1
+            op.agree = 'never'
+        elif hasattr(op, '_agreed'):  # pipelined halo: by default every call settles its autograd path with one collective;
             assert op.agree == 'always' and op.agreements == 4 and not op._agreed  # agree='once' remembers it per state
             op.agree = 'once'
             for _ in range(3):
