@@ -400,6 +400,20 @@ size_t tsamd_sort_coo_workspace_bytes(int64_t E);
 int tsamd_sort_coo(const int64_t *row, const int64_t *col, int64_t E, int64_t M,
                    int64_t N, int64_t *row_out, int64_t *col_out, int64_t *perm_out,
                    void *workspace, size_t workspace_bytes, void *stream);
+/* tsamd_sort_coo_auto + tsamd_coalesce_index in one call -- the functional coalesce / transpose of
+ * torch_sparse/coalesce.py:5-25, transpose.py:39-62 (storage.py:149-162 + 431-447 behind them): the distinct
+ * (row, col) pairs in row-major order to row_u / col_u (capacity E), the start of every run of equal pairs in the
+ * SORTED order to seg_ptr (capacity E + 1, seg_ptr[nnz] = E), counts[0..2] (DEVICE) = (#descents of the input,
+ * #adjacent duplicates of the input, #distinct pairs); value_out (nullable, with value: E elements of value_bytes = 4
+ * or 8) = the values in sorted order, ready for tsamd_segment_reduce(..., perm = NULL, seg_ptr, ...).  When the bucket
+ * path sorts the input the compaction happens while the last kernel writes its output (the sorted ids are never
+ * written); otherwise row_tmp / col_tmp (capacity E each) receive the sorted ids and a compaction kernel follows.
+ * No host sync; reading counts is the caller's one. */
+size_t tsamd_sort_coalesce_workspace_bytes(int64_t E);
+int tsamd_sort_coalesce(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_tmp,
+                        int64_t *col_tmp, int64_t *row_u, int64_t *col_u, int64_t *seg_ptr, int64_t *counts,
+                        const void *value, void *value_out, int64_t value_bytes, void *workspace,
+                        size_t workspace_bytes, void *stream);
 size_t tsamd_coalesce_workspace_bytes(int64_t E);
 int tsamd_coalesce_index(const int64_t *row, const int64_t *col, int64_t E,
                          int64_t *row_out, int64_t *col_out, int64_t *seg_ptr,

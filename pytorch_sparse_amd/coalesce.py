@@ -56,22 +56,42 @@ def sorted_unique(row: Tensor, col: Tensor, m: int, n: int, value: Optional[Tens
     return row_u[:n_u], col_u[:n_u], perm_opt, seg_ptr, n_u
 
 
+def coalesce_rows_cols(row: Tensor, col: Tensor, value: Optional[Tensor], m: int, n: int,
+                       op: str = 'add') -> Tuple[Tensor, Optional[Tensor]]:
+    """`coalesce` on the two index rows given separately (the functional transpose hands them over swapped, without
+    stacking them first)."""
+    if op not in _OPS:
+        raise ValueError(op)
+    nnz = col.numel()
+    if nnz > 1 and col.is_cuda and (value is None or _rides(value, nnz)):
+        # sort + duplicate compaction in one op (tsamd_sort_coalesce): when the bucket sort takes the input the distinct
+        # pairs are written straight from its last kernel; ONE transfer brings back (#descents, #duplicates, #distinct)
+        index_u, seg_ptr, counts, value_s = torch.ops.tsamd.sort_coalesce(row, col, m, n, value)
+        descents, _, n_u = counts.tolist()  # the one host sync
+        if n_u == nnz:
+            if descents == 0:  # in order, no duplicates: the caller's own data (as the reference hands it back)
+                return torch.stack([row, col], dim=0), value
+            return index_u, (value_s if value is not None else None)
+        if value is not None:  # the values came out of the sort in order: a streamed reduction, no gather
+            value = segment_reduce(value_s, None, seg_ptr, n_u, op, balanced=nnz > 8 * max(n_u, 1))
+        return index_u[:, :n_u].contiguous(), value
+    row, col, perm, seg_ptr, n_u, value_s = sorted_unique(row, col, m, n, value) if value is not None else (
+        sorted_unique(row, col, m, n) + (None, ))
+    if value_s is not None:  # the values came out of the sort in order: a streamed reduction, no gather
+        value = value_s
+        if seg_ptr is not None:
+            value = segment_reduce(value_s, None, seg_ptr, n_u, op, balanced=nnz > 8 * max(n_u, 1))
+    elif value is not None:
+        if seg_ptr is not None:
+            # differentiable, like segment_csr; long runs of duplicates go the entry-balanced way
+            value = segment_reduce(value, perm, seg_ptr, n_u, op, balanced=nnz > 8 * max(n_u, 1))
+        elif perm is not None:
+            value = value.index_select(0, perm)
+    return torch.stack([row, col], dim=0), value
+
+
 def coalesce(index: Tensor, value: Optional[Tensor], m: int, n: int,
              op: str = 'add') -> Tuple[Tensor, Optional[Tensor]]:
     """Sort `index` ([2, nnz]) row-major and merge duplicate entries, reducing their values
     ([nnz, *], any supported dtype) with `op` in add | sum | mean | min | max."""
-    if op not in _OPS:
-        raise ValueError(op)
-    row, col, perm, seg_ptr, n_u, value_s = sorted_unique(index[0], index[1], m, n, value) if value is not None else (
-        sorted_unique(index[0], index[1], m, n) + (None, ))
-    if value_s is not None:  # the values came out of the sort in order: a streamed reduction, no gather
-        value = value_s
-        if seg_ptr is not None:
-            value = segment_reduce(value_s, None, seg_ptr, n_u, op, balanced=index.size(1) > 8 * max(n_u, 1))
-    elif value is not None:
-        if seg_ptr is not None:
-            # differentiable, like segment_csr; long runs of duplicates go the entry-balanced way
-            value = segment_reduce(value, perm, seg_ptr, n_u, op, balanced=index.size(1) > 8 * max(n_u, 1))
-        elif perm is not None:
-            value = value.index_select(0, perm)
-    return torch.stack([row, col], dim=0), value
+    return coalesce_rows_cols(index[0], index[1], value, m, n, op)

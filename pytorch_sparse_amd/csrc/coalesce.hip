@@ -135,7 +135,9 @@ constexpr int kCompactTile = 256 * kCompactItems;
 __global__ __launch_bounds__(256) void coalesce_compact_kernel(
     const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t n, int64_t *__restrict__ row_out,
     int64_t *__restrict__ col_out, int64_t *__restrict__ seg_ptr, int64_t *__restrict__ nnz_out,
-    unsigned long long *__restrict__ state /* [1] error, [8 + tile] status */) {
+    unsigned long long *__restrict__ state /* [1] error, [8 + tile] status */,
+    const unsigned long long *__restrict__ skip /* nullable: non-zero = the outputs are there already (compacting sort) */) {
+  if (skip != nullptr && *skip != 0) return;
   __shared__ unsigned long long s_base;
   __shared__ unsigned int s_cnt[kCompactItems][4];
   const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -598,7 +600,58 @@ extern "C" int tsamd_coalesce_index(const int64_t *row, const int64_t *col, int6
   TSAMD_HIP_TRY(hipMemsetAsync(workspace, 0, need, stream));
   hipLaunchKernelGGL(coalesce_compact_kernel, dim3((unsigned int)ceil_div(E, kCompactTile)), dim3(256), 0, stream,
                      row, col, E, row_out, col_out, seg_ptr, nnz_out,
-                     reinterpret_cast<unsigned long long *>(workspace));
+                     reinterpret_cast<unsigned long long *>(workspace), (const unsigned long long *)nullptr);
+  TSAMD_LAUNCH_CHECK();
+  return TSAMD_OK;
+}
+
+// Sort + duplicate compaction in one go (include/tsamd.h): the functional coalesce / transpose.
+extern "C" size_t tsamd_sort_coalesce_workspace_bytes(int64_t E) {
+  return align_up(sort_coo_workspace_bytes(E), 256) + align_up(sizeof(unsigned long long) * kSortCoalesceStatusWords, 256) +
+         tsamd_coalesce_workspace_bytes(E);
+}
+
+extern "C" int tsamd_sort_coalesce(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                                   int64_t *row_tmp, int64_t *col_tmp, int64_t *row_u, int64_t *col_u, int64_t *seg_ptr,
+                                   int64_t *counts, const void *value, void *value_out, int64_t value_bytes,
+                                   void *workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (E < 0 || M < 0 || N < 0 || !counts || !seg_ptr) return TSAMD_ERR_INVALID;
+  if ((value == nullptr) != (value_out == nullptr)) return TSAMD_ERR_INVALID;
+  if (value != nullptr && value_bytes != 4 && value_bytes != 8) return TSAMD_ERR_UNSUPPORTED;
+  if (E == 0) {
+    TSAMD_HIP_TRY(hipMemsetAsync(counts, 0, 3 * sizeof(int64_t), stream));
+    TSAMD_HIP_TRY(hipMemsetAsync(seg_ptr, 0, sizeof(int64_t), stream));
+    return TSAMD_OK;
+  }
+  if (!row || !col || !row_tmp || !col_tmp || !row_u || !col_u) return TSAMD_ERR_INVALID;
+  if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < tsamd_sort_coalesce_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
+  char *wsp = reinterpret_cast<char *>(workspace);
+  void *sort_ws = wsp;
+  unsigned long long *status = reinterpret_cast<unsigned long long *>(wsp + align_up(sort_coo_workspace_bytes(E), 256));
+  void *co_ws = reinterpret_cast<char *>(status) + align_up(sizeof(unsigned long long) * kSortCoalesceStatusWords, 256);
+  const size_t co_bytes = tsamd_coalesce_workspace_bytes(E);
+  const unsigned long long *skip = nullptr;
+  if (E <= kSmallSortMax && small_sort_coo(row, col, E, M, N, row_tmp, col_tmp, seg_ptr /* perm: scratch, rewritten below */,
+                                           counts, true, stream)) {
+    TSAMD_LAUNCH_CHECK();
+    if (value != nullptr) {
+      int st = tsamd_gather_rows(value, seg_ptr, value_out, E, E, value_bytes, stream_);
+      if (st != TSAMD_OK) return st;
+    }
+  } else {
+    SortCoalesce co{row_u, col_u, seg_ptr, counts + 2, status};
+    int st = sort_coo_onesweep(row, col, E, M, N, row_tmp, col_tmp, nullptr, nullptr, true, counts, sort_ws, stream, value,
+                               value_out, (int)value_bytes, false, &co);
+    if (st != TSAMD_OK) return st;
+    skip = sort_fast_flag(sort_ws, E);
+  }
+  // the one-sweep passes (or the one-launch sort) left sorted pairs in row_tmp / col_tmp: compact them -- returns at
+  // once when the bucket path wrote the compacted outputs itself
+  TSAMD_HIP_TRY(hipMemsetAsync(co_ws, 0, co_bytes, stream));
+  hipLaunchKernelGGL(coalesce_compact_kernel, dim3((unsigned int)ceil_div(E, kCompactTile)), dim3(256), 0, stream, row_tmp,
+                     col_tmp, E, row_u, col_u, seg_ptr, counts + 2, reinterpret_cast<unsigned long long *>(co_ws), skip);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
 }

@@ -77,7 +77,8 @@ extern "C" int tsamd_ind2ptr(const int64_t *ind, int64_t M, int64_t E, int64_t *
     return TSAMD_OK;
   }
   const int64_t n = E + 1;
-  TSAMD_HIP_TRY(hipMemsetAsync(out, 0xff, sizeof(int64_t) * (size_t)(M + 1), stream));  // -1 = unset
+  // -1 = unset.  (As 32-bit words: a byte fill of a length that is not a multiple of 16 is TWO fill kernels.)
+  TSAMD_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out), -1, 2 * (size_t)(M + 1), stream));
   hipLaunchKernelGGL(ind2ptr_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
                      ind, out, M, E);
   TSAMD_LAUNCH_CHECK();

@@ -189,6 +189,45 @@ std::tuple<Tensor, Tensor, Tensor> sort_coo(Tensor row, Tensor col, int64_t M, i
   return std::make_tuple(row_s, col_s, perm);
 }
 
+// tsamd_sort_coalesce: unsorted (row, col) [+ a 1-D value of 4- / 8-byte elements without a gradient] ->
+// (index_u[2, E], seg_ptr[E+1], counts[3] = (#descents, #adjacent duplicates, #distinct pairs) on the device,
+//  value in sorted order or an empty tensor); only the first counts[2] (+1) columns of index_u / entries of seg_ptr count.
+std::tuple<Tensor, Tensor, Tensor, Tensor> sort_coalesce(Tensor row, Tensor col, int64_t M, int64_t N,
+                                                       OptTensor opt_value) {
+  check_index(row, "row");
+  check_index(col, "col");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  // (the two rows of ONE [2, E] tensor: without duplicates it IS the result, nothing is stacked afterwards)
+  Tensor index_u = torch::empty({2, E}, row.options());
+  Tensor row_u = index_u.select(0, 0), col_u = index_u.select(0, 1);
+  Tensor row_t = torch::empty({E}, row.options()), col_t = torch::empty({E}, row.options());
+  Tensor seg = torch::empty({E + 1}, row.options()), counts = torch::empty({3}, row.options());
+  Tensor value, value_s = torch::empty({0}, row.options());
+  if (opt_value.has_value()) {
+    value = opt_value.value();
+    check_gpu(value, "value");
+    TORCH_CHECK(value.dim() == 1 && value.size(0) == E && (value.element_size() == 4 || value.element_size() == 8) &&
+                    !needs_grad(value),
+                "sort_coalesce: the value must be 1-D, of 4- / 8-byte elements and need no gradient");
+    value = value.contiguous();
+    value_s = torch::empty_like(value);
+  }
+  const bool with_value = opt_value.has_value() && E > 0;
+  Tensor ws = workspace(tsamd_sort_coalesce_workspace_bytes(E), row);
+  check_status(tsamd_sort_coalesce(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N, row_t.data_ptr<int64_t>(),
+                                   col_t.data_ptr<int64_t>(), row_u.data_ptr<int64_t>(), col_u.data_ptr<int64_t>(),
+                                   seg.data_ptr<int64_t>(), counts.data_ptr<int64_t>(),
+                                   with_value ? value.data_ptr() : nullptr, with_value ? value_s.data_ptr() : nullptr,
+                                   with_value ? (int64_t)value.element_size() : 0, ws.data_ptr(), (size_t)ws.numel(),
+                                   current_stream(row)),
+               "tsamd_sort_coalesce");
+  return std::make_tuple(index_u, seg, counts, value_s);
+}
+
 // sorted (row, col) -> (row_u[E], col_u[E], seg_ptr[E+1], nnz[1]); only the first nnz (+1)
 // entries are meaningful, nnz lives on the device.
 std::tuple<Tensor, Tensor, Tensor, Tensor> coalesce_index(Tensor row, Tensor col) {
@@ -540,6 +579,7 @@ static auto registry_storage = torch::RegisterOperators()
                            .op("tsamd::sort_coo_probed", &sort_coo_probed)
                            .op("tsamd::sort_rank_mode", &sort_rank_mode)
                            .op("tsamd::coalesce_index", &coalesce_index)
+                           .op("tsamd::sort_coalesce", &sort_coalesce)
                            .op("tsamd::segment_reduce", &segment_reduce)
                            .op("tsamd::spspmm", &spspmm)
                            .op("tsamd::select_segments", &select_segments)

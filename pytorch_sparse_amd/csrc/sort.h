@@ -19,8 +19,20 @@ int sort_rank_mode(hipStream_t stream);
 void sort_set_rank_mode(int mode);
 size_t sort_coo_workspace_bytes(int64_t E);
 bool sort_coo_supported(int64_t E, int64_t M, int64_t N);
+// co (nullable): a COMPACTING sort.  When the bucket path sorts the input, its last kernel writes the distinct pairs
+//   to co->row_u / col_u, the start of every run of equal pairs in the sorted order to co->seg_ptr (seg_ptr[nnz] = E)
+//   and their number to co->nnz_out, and row_out / col_out / perm_out stay untouched; otherwise the one-sweep passes
+//   write row_out / col_out (/ perm_out, nullable) as usual and the CALLER compacts them (it can tell on the device:
+//   *sort_fast_flag(workspace, E) != 0 means the compacted outputs are already there).  co->status: nb words of scratch.
+struct SortCoalesce {
+  int64_t *row_u, *col_u, *seg_ptr, *nnz_out;
+  unsigned long long *status;  // [kSortCoalesceStatusWords]
+};
+constexpr int kSortCoalesceStatusWords = 1 << 14;
+const unsigned long long *sort_fast_flag(void *workspace, int64_t E);
 int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_out,
                       int64_t *col_out, int64_t *perm_out, const int64_t *todo, bool probe, int64_t *counts_out,
                       void *workspace, hipStream_t stream, const void *gather_src = nullptr,
-                      void *gather_dst = nullptr, int gather_bytes = 0, bool check4 = false);
+                      void *gather_dst = nullptr, int gather_bytes = 0, bool check4 = false,
+                      const SortCoalesce *co = nullptr);
 }  // namespace tsamd

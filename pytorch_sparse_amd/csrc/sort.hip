@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
         if (e >= n) break;
         if (row_out) row_out[e] = row[e];
         if (col_out) col_out[e] = col[e];
-        perm_out[e] = e;
+        if (perm_out) perm_out[e] = e;
         if (gather_dst != nullptr) {
           if (gather_bytes == 4) reinterpret_cast<uint32_t *>(gather_dst)[e] = reinterpret_cast<const uint32_t *>(gather_src)[e];
           else reinterpret_cast<uint64_t *>(gather_dst)[e] = reinterpret_cast<const uint64_t *>(gather_src)[e];
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kSortThreads) void onesweep_pass_kernel(
         if (!ok[k]) continue;
         if (row_out) row_out[o[k]] = (int64_t)(key[k] >> L.col_bits);
         if (col_out) col_out[o[k]] = (int64_t)(key[k] & ((1ull << L.col_bits) - 1ull));
-        perm_out[o[k]] = (int64_t)e[k];
+        if (perm_out) perm_out[o[k]] = (int64_t)e[k];
       }
     }
   } else {
@@ -627,7 +627,7 @@ __global__ void sort_identity_kernel(const int64_t *__restrict__ row, const int6
   if (i >= n) return;
   if (row_out) row_out[i] = row[i];
   if (col_out) col_out[i] = col[i];
-  perm_out[i] = i;
+  if (perm_out) perm_out[i] = i;
 }
 
 // ---------------------------------------------------------------------------
@@ -928,13 +928,26 @@ __global__ __launch_bounds__(kBkScatterThreads) void bucket_scatter_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kBkGroupMax = 24;
 
-template <int THREADS, int ITEMS, bool VAL, bool BALLOT>
+// COAL (functional coalesce / transpose): the bucket's piece of the output is COMPACTED as it is written -- the
+// first entry of every run of equal keys goes to row_out / col_out (here: the distinct pairs), its position in the
+// sorted order to Co.seg_ptr, the sorted values (all of them) to gather_dst; the number of distinct pairs in the
+// buckets before this one comes from a decoupled look-back over one status word per bucket (as in
+// coalesce_compact_kernel; buckets = workgroups in dispatch order).  Saves writing the sorted ids and the permutation
+// (24 bytes per entry) and reading them back in a compaction kernel.
+struct CoalesceOut {
+  int64_t *seg_ptr;            // [E + 1]
+  int64_t *nnz_out;            // [1]
+  unsigned long long *status;  // [#buckets], zeroed: [63:62] 1 = own count, 2 = inclusive prefix
+  int64_t n_total;
+};
+
+template <int THREADS, int ITEMS, bool VAL, bool BALLOT, bool COAL = false>
 __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kernel(
     const unsigned long long *__restrict__ in, const unsigned int *__restrict__ val_in,
     const unsigned int *__restrict__ boff, SortBits SB, KeyLayout L, BucketPlan B, int64_t *__restrict__ row_out,
     int64_t *__restrict__ col_out, int64_t *__restrict__ perm_out, const unsigned long long *__restrict__ hdr,
     int64_t *__restrict__ counts_out, int check4, const void *__restrict__ gather_src, void *__restrict__ gather_dst,
-    int gather_bytes) {
+    int gather_bytes, CoalesceOut Co) {
   if (hdr[kHdrFast] == 0) return;
   if (counts_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // the probe's counters (see the last pass kernel)
     counts_out[0] = (int64_t)hdr[kHdrDescents];
@@ -954,7 +967,7 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
   const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
   const unsigned int start = boff[blockIdx.x];
   const int n = (int)(boff[blockIdx.x + 1] - start);
-  if (n == 0) return;
+  if (n == 0 && !COAL) return;  // (a compacting launch: an empty bucket still passes the count of its predecessors on)
   // wave w owns the entries [w * seg, (w + 1) * seg), seg a multiple of 64: the waves share the bucket evenly
   const int seg = (((n + kW - 1) / kW) + 63) & ~63;
   const int items = seg >> 6;  // <= ITEMS because n <= kCap
@@ -1097,11 +1110,143 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
       exact = true;
     }
   }
-  // decoded output, coalesced
   const unsigned long long imask = (1ull << L.idx_bits) - 1ull, cmask = (1ull << L.col_bits) - 1ull;
   // strip mode: the words lost the level-1 bits of the key in the scatter; the bucket id has them
   const unsigned long long keybase =
       B.strip ? (unsigned long long)(blockIdx.x >> (B.bits - B.bits1)) << (L.key_bits - B.bits1) : 0ull;
+  if constexpr (COAL) {
+    __shared__ unsigned int s_heads[ITEMS][kW];
+    __shared__ unsigned long long s_base;
+    // 1. the exact order in LDS (the finish step moves what it otherwise only re-addresses)
+    if (!exact) {
+      unsigned long long fw[ITEMS];
+      unsigned int fv[VAL ? ITEMS : 1];
+      int fpos[ITEMS];
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        const int j = k * THREADS + tid;
+        fpos[k] = -1;
+        fw[k] = 0ull;
+        if (k * THREADS < n && j < n) {
+          const unsigned long long x = sword[j];
+          const unsigned long long pre = x >> lo;
+          int gt = 0, lt = 0;
+          for (int q = j - 1; q >= 0; --q) {
+            const unsigned long long y = sword[q];
+            if ((y >> lo) != pre) break;
+            gt += y > x;
+          }
+          for (int q = j + 1; q < n; ++q) {
+            const unsigned long long y = sword[q];
+            if ((y >> lo) != pre) break;
+            lt += y < x;
+          }
+          fw[k] = x;
+          if constexpr (VAL) fv[k] = sval[j];
+          fpos[k] = j - gt + lt;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        if (fpos[k] >= 0) {
+          sword[fpos[k]] = fw[k];
+          if constexpr (VAL) sval[fpos[k]] = fv[k];
+        }
+      }
+      __syncthreads();
+    }
+    // 2. head flags (an entry whose key differs from its predecessor's; the bucket's first entry always: other
+    //    buckets hold other keys) and their count per (step, wave)
+    unsigned long long hmask[ITEMS];
+    unsigned int heads = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int j = k * THREADS + tid;
+      bool h = false;
+      if (k * THREADS < n && j < n) h = j == 0 || (sword[j] >> L.idx_bits) != (sword[j - 1] >> L.idx_bits);
+      hmask[k] = __ballot(h);
+      heads |= (h ? 1u : 0u) << k;
+      if (lane == 0) s_heads[k][w] = (unsigned int)__popcll(hmask[k]);
+    }
+    __syncthreads();
+    unsigned int before_step[ITEMS], total = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+#pragma unroll
+      for (int ww = 0; ww < kW; ++ww) {
+        if (ww == w) before_step[k] = total;
+        total += s_heads[k][ww];
+      }
+    }
+    // 3. distinct pairs in the buckets before this one: publish, look back (wave 0, 64 buckets per step)
+    constexpr unsigned long long kLocal = 1ull << 62, kPrefix = 2ull << 62, kMask = (1ull << 62) - 1ull;
+    const int64_t bucket = (int64_t)blockIdx.x;
+    if (w == 0) {
+      unsigned long long *mine = Co.status + bucket;
+      if (lane == 0)
+        __hip_atomic_store(mine, (bucket == 0 ? kPrefix : kLocal) | (unsigned long long)total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long before = 0;
+      int64_t t = bucket - 1;
+      unsigned int spins = 0;
+      while (t >= 0) {
+        const int64_t mt = t - lane;
+        unsigned long long sv = kPrefix;  // lanes past bucket 0 read as "prefix 0"
+        if (mt >= 0) sv = __hip_atomic_load(Co.status + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ready = __ballot((sv >> 62) != 0);
+        const unsigned long long pref = __ballot((sv >> 62) == 2);
+        const int first_gap = ~ready ? __builtin_ctzll(~ready) : 64;
+        const int first_pref = pref ? __builtin_ctzll(pref) : 64;
+        const int take = first_pref < first_gap ? first_pref + 1 : first_gap;
+        unsigned long long v = lane < take ? (sv & kMask) : 0ull;
+        for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)lane_xor((int64_t)v, off);
+        before += v;
+        if (first_pref < first_gap) break;  // reached an inclusive prefix
+        t -= take;
+        if (take == 0) {
+          if (++spins > kSpinLimit) {  // (see the pass kernel: the dispatch-order assumption does not hold here)
+            __builtin_trap();
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (lane == 0) {
+        if (bucket > 0)
+          __hip_atomic_store(mine, kPrefix | (before + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base = before;
+        if (bucket == (int64_t)gridDim.x - 1) {
+          Co.nnz_out[0] = (int64_t)(before + total);
+          Co.seg_ptr[before + total] = Co.n_total;
+        }
+      }
+    }
+    __syncthreads();
+    // 4. the distinct pairs, where their runs start in the sorted order, and the sorted values
+    const int64_t base = (int64_t)s_base;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int j = k * THREADS + tid;
+      if (k * THREADS >= n || j >= n) continue;
+      const unsigned long long wd = sword[j];
+      if constexpr (VAL) reinterpret_cast<uint32_t *>(gather_dst)[(size_t)start + j] = sval[j];
+      else if (gather_dst != nullptr) {
+        const unsigned long long e = wd & imask;
+        if (gather_bytes == 4) reinterpret_cast<uint32_t *>(gather_dst)[(size_t)start + j] = reinterpret_cast<const uint32_t *>(gather_src)[e];
+        else reinterpret_cast<uint64_t *>(gather_dst)[(size_t)start + j] = reinterpret_cast<const uint64_t *>(gather_src)[e];
+      }
+      if ((heads >> k) & 1u) {
+        const int64_t p = base + before_step[k] + (unsigned int)__popcll(hmask[k] & lt_mask);
+        const unsigned long long key = keybase | (wd >> L.idx_bits);
+        row_out[p] = (int64_t)(key >> L.col_bits);
+        col_out[p] = (int64_t)(key & cmask);
+        Co.seg_ptr[p] = (int64_t)start + j;
+      }
+    }
+    return;
+  }
+  // decoded output, coalesced
   constexpr int kBatch = 4;
   for (int j0 = tid; j0 < n; j0 += THREADS * kBatch) {
     unsigned long long key[kBatch], e[kBatch];
@@ -1161,7 +1306,7 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
 #else
       if (row_out) row_out[o[k]] = (int64_t)(key[k] >> L.col_bits);
       if (col_out) col_out[o[k]] = (int64_t)(key[k] & cmask);
-      perm_out[o[k]] = (int64_t)e[k];
+      if (perm_out) perm_out[o[k]] = (int64_t)e[k];
 #endif
     }
   }
@@ -1336,6 +1481,12 @@ void sort_set_rank_mode(int mode) { g_rank_mode.store(mode < 0 ? -1 : (mode ? 1 
 
 size_t sort_coo_workspace_bytes(int64_t E) { return carve_sort(nullptr, E, nullptr); }
 
+const unsigned long long *sort_fast_flag(void *workspace, int64_t E) {
+  SortWs ws;
+  carve_sort(workspace, E, &ws);
+  return ws.hdr + kHdrFast;
+}
+
 bool sort_coo_supported(int64_t E, int64_t M, int64_t N) {
   return E < ((int64_t)1 << 32) && bits_for(M > 0 ? M : 1) + bits_for(N > 0 ? N : 1) <= 64 &&
          (bits_for(M > 0 ? M : 1) + bits_for(N > 0 ? N : 1) + kRadixBits - 1) / kRadixBits <= kMaxPasses;
@@ -1344,7 +1495,7 @@ bool sort_coo_supported(int64_t E, int64_t M, int64_t N) {
 int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N, int64_t *row_out,
                       int64_t *col_out, int64_t *perm_out, const int64_t *todo, bool probe, int64_t *counts_out,
                       void *workspace, hipStream_t stream, const void *gather_src, void *gather_dst,
-                      int gather_bytes, bool check4) {
+                      int gather_bytes, bool check4, const SortCoalesce *co) {
   if (E <= 0) return TSAMD_OK;
   if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
   const KeyLayout L = layout_for(E, M, N);
@@ -1353,6 +1504,7 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
   SortWs ws;
   carve_sort(workspace, E, &ws);
   if (L.passes == 0 || E == 1) {  // nothing to order (a 1 x 1 matrix: every key is equal)
+    TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, sizeof(unsigned long long) * kHdrWords, stream));  // (kHdrFast = 0 for a caller that asks)
     if (probe && counts_out != nullptr) {
       const int64_t c[2] = {0, E - 1};  // no descent, every adjacent pair a duplicate
       TSAMD_HIP_TRY(hipMemcpyAsync(counts_out, c, sizeof(c), hipMemcpyHostToDevice, stream));
@@ -1368,7 +1520,9 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
   const bool want4 = gather_dst != nullptr && gather_bytes == 4;
   const bool ride = L.packed && want4 && L.passes >= 2;
   const int64_t ntiles = ceil_div(E, kSortThreads * (L.packed ? (ride ? kItemsOf<true, true> : kItemsOf<true>) : kItemsOf<false>));
-  const BucketPlan B = plan_buckets(E, M, N, L, want4);
+  BucketPlan B = plan_buckets(E, M, N, L, want4);
+  // a compacting sort needs buckets that end where keys end (the bucket id inside the key bits)
+  if (co != nullptr && B.on && !B.strip && B.shift < L.idx_bits) B.on = 0;
   const bool ballot = sort_rank_mode(stream) == 1;
   TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes + (B.on ? sizeof(unsigned int) * (size_t)B.nb * kBkHistCopies : 0), stream));
   {
@@ -1409,11 +1563,26 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
       sorted_in = ws.a;
     }
 #undef TSAMD_BK_SCATTER
+    CoalesceOut Co{nullptr, nullptr, nullptr, E};
+    if (co != nullptr) {
+      TSAMD_HIP_TRY(hipMemsetAsync(co->status, 0, sizeof(unsigned long long) * (size_t)B.nb, stream));
+      Co.seg_ptr = co->seg_ptr;
+      Co.nnz_out = co->nnz_out;
+      Co.status = co->status;
+    }
 #define TSAMD_BK_SORT(ITEMS, V, BAL)                                                                                     \
-  hipLaunchKernelGGL((bucket_sort_kernel<TSAMD_BK_SORT_THREADS, ITEMS, V, BAL>), dim3((unsigned int)B.nb),              \
-                     dim3(TSAMD_BK_SORT_THREADS), 0, stream, sorted_in, (const unsigned int *)nullptr, ws.boff, SB, L, B,  \
-                     row_out, col_out, perm_out, ws.hdr, probe ? counts_out : (int64_t *)nullptr, check4 ? 1 : 0,        \
-                     gather_src, gather_dst, gather_bytes)
+  do {                                                                                                                   \
+    if (co != nullptr)                                                                                                   \
+      hipLaunchKernelGGL((bucket_sort_kernel<TSAMD_BK_SORT_THREADS, ITEMS, V, BAL, true>), dim3((unsigned int)B.nb),     \
+                         dim3(TSAMD_BK_SORT_THREADS), 0, stream, sorted_in, (const unsigned int *)nullptr, ws.boff, SB, L, \
+                         B, co->row_u, co->col_u, (int64_t *)nullptr, ws.hdr, probe ? counts_out : (int64_t *)nullptr,   \
+                         check4 ? 1 : 0, gather_src, gather_dst, gather_bytes, Co);                                      \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((bucket_sort_kernel<TSAMD_BK_SORT_THREADS, ITEMS, V, BAL>), dim3((unsigned int)B.nb),           \
+                         dim3(TSAMD_BK_SORT_THREADS), 0, stream, sorted_in, (const unsigned int *)nullptr, ws.boff, SB, L, \
+                         B, row_out, col_out, perm_out, ws.hdr, probe ? counts_out : (int64_t *)nullptr, check4 ? 1 : 0, \
+                         gather_src, gather_dst, gather_bytes, Co);                                                      \
+  } while (0)
     if (want4) {
       if (ballot) TSAMD_BK_SORT(TSAMD_BK_SORT_ITEMS_VAL, true, true);
       else TSAMD_BK_SORT(TSAMD_BK_SORT_ITEMS_VAL, true, false);

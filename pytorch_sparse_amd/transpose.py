@@ -1,7 +1,7 @@
 """t() on SparseTensor and the functional transpose (API of torch_sparse/transpose.py)."""
 import torch
 
-from .coalesce import coalesce
+from .coalesce import coalesce_rows_cols
 from .storage import SparseStorage
 from .tensor import SparseTensor
 
@@ -28,7 +28,6 @@ def transpose(index, value, m, n, coalesced=True):
     """(index, value) of the n x m transpose.  With ``coalesced=True`` (default) the result is
     sorted row-major with duplicates summed -- i.e. a coalesce of the swapped index
     (reference transpose.py:39-62); otherwise only the two index rows are swapped."""
-    swapped = torch.stack([index[1], index[0]], dim=0)
     if not coalesced:
-        return swapped, value
-    return coalesce(swapped, value, n, m, op='add')
+        return torch.stack([index[1], index[0]], dim=0), value
+    return coalesce_rows_cols(index[1], index[0], value, n, m, op='add')  # (the swapped rows, never stacked)

@@ -157,6 +157,49 @@ def test_bucket_path_two_levels_bit_exact(dev, ops, E, m, n, kind):
     assert counts.tolist()[2:] == [int(row.max()), int(col.max())]
 
 
+@pytest.mark.parametrize('E,m,n,kind', [
+    (5000, 300, 200, 'uniform'),                 # the one-launch sort + the compaction kernel
+    (400003, 500000, 500000, 'uniform'),         # bucket path: compaction in the bucket sort's output
+    (400003, 700, 900, 'uniform'),               # ... with many duplicates per key (runs across the finish step's groups)
+    (1 << 20, 16, 16, 'uniform'),                # the bucket id would reach into the position bits: one-sweep + compaction kernel
+    (500000, 1 << 20, 1 << 20, 'hub'),           # a bucket overflows: one-sweep + compaction kernel
+    (3000000, (1 << 21) + 5, (1 << 21) - 3, 'uniform'),   # stripped keys
+    (12500000, 1 << 21, 1 << 21, 'uniform'),     # two scatter levels, 4096 buckets in the look-back
+    (300000, 1000, 1000, 'sorted'),              # already in order (with duplicates): copy + compaction
+])
+@pytest.mark.parametrize('with_value', [False, True])
+def test_sort_coalesce_bit_exact(dev, ops, E, m, n, kind, with_value):
+    """tsamd::sort_coalesce (sort + duplicate compaction in one op): distinct pairs, run starts, counts and the sorted
+    values against the numpy restatement of torch_sparse/storage.py:149-162, 431-447."""
+    g = torch.Generator().manual_seed(E % 983 + 1)
+    row = torch.randint(0, m, (E, ), generator=g)
+    col = torch.randint(0, n, (E, ), generator=g)
+    if kind == 'hub':
+        row[torch.randperm(E, generator=g)[:E // 3]] = 12345
+    q = E // 5
+    row[:q], col[:q] = row[q:2 * q].clone(), col[q:2 * q].clone()
+    if kind == 'sorted':
+        r_, c_, _ = no.sort_coo(row.numpy(), col.numpy(), m, n)
+        row, col = torch.from_numpy(r_.copy()), torch.from_numpy(c_.copy())
+    er, ec, ep = no.sort_coo(row.numpy(), col.numpy(), m, n)
+    key = er.astype(np.int64) * n + ec
+    head = np.ones(E, dtype=bool)
+    head[1:] = key[1:] != key[:-1]
+    pos = np.nonzero(head)[0]
+    ikey = row.numpy().astype(np.int64) * n + col.numpy()
+    val = torch.rand(E, generator=g)
+    index_u, seg, counts, vs = ops.sort_coalesce(row.to(dev), col.to(dev), m, n, val.to(dev) if with_value else None)
+    k = pos.size
+    assert counts.tolist() == [int((ikey[1:] < ikey[:-1]).sum()), int((ikey[1:] == ikey[:-1]).sum()), k]
+    assert np.array_equal(index_u[0, :k].cpu().numpy(), er[pos]) and np.array_equal(index_u[1, :k].cpu().numpy(), ec[pos])
+    assert np.array_equal(seg[:k + 1].cpu().numpy(), np.append(pos, E))
+    if with_value:
+        assert np.array_equal(vs.cpu().numpy(), val.numpy()[ep])
+        v8 = val.double()
+        vs8 = ops.sort_coalesce(row.to(dev), col.to(dev), m, n, v8.to(dev))[3]
+        assert np.array_equal(vs8.cpu().numpy(), v8.numpy()[ep])
+
+
 def test_rank_self_test_and_forced_ballot_ranking(dev, ops):
     """The stable rank of the radix kernels is a returning LDS atomic when the device-side self-test finds the lanes of
     one instruction served in ascending order, ballot matching otherwise.  Both must give the SAME permutation on
