@@ -127,6 +127,24 @@ def cpu_baseline(rowptr, col, value, x, reduce, out):
                              sample='first 1/32 of the rows (%d edges)' % e1)
     if reduce == 'sum':
         res['parity'] = bc.sum_parity(out, rp, c, v, xx, ref_out)
+        # the same product once more in the reference's ORDER OF OPERATIONS (tsamd_spmm_reference_order, a verification
+        # mode of the library: csrc/spmm_ref_order.hip): every bit of the whole output against the compiled reference's
+        if kind == 'reference':
+            import pytorch_sparse_amd  # noqa: F401
+            from pytorch_sparse_amd import _native as nat
+            try:
+                torch.ops.tsamd.reference_order(1)
+                o2, _ = nat.spmm(rowptr, col, value, x, reduce)
+                torch.cuda.synchronize()
+            finally:
+                torch.ops.tsamd.reference_order(0)
+            ref_dev = ref_out.to(o2.device)
+            res['parity']['reference_order_mode'] = dict(
+                elements=int(o2.numel()),
+                n_bits_differ=int((o2.view(torch.int32) != ref_dev.view(torch.int32)).sum()),
+                note='tsamd_spmm_reference_order(1): one thread per output element, entries in CSR order, separately '
+                     'rounded multiply and add -- bit-identical to csrc/cpu/spmm_cpu.cpp:61-87 by construction')
+            del o2, ref_dev
     return res
 
 
@@ -225,6 +243,8 @@ def compact_line(full):
         if par:
             p = _pick(par, ('ok', 'elements', 'max_err_over_l1', 'tol_over_l1', 'ours_vs_fp64_over_l1', 'ref_vs_fp64_over_l1',
                             'n_rel_gt_1e_5_where_ref_ge_1e_1_l1'))
+            if 'reference_order_mode' in par:
+                p['reference_order_n_bits_differ'] = par['reference_order_mode'].get('n_bits_differ')
             p.update(_pick(par.get('survey_8d_literal_bound', {}), ('n_viol_ours_vs_ref', 'n_viol_ours_vs_fp64',
                                                                     'n_viol_ref_vs_fp64')))
             line['parity'] = p

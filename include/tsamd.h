@@ -94,6 +94,13 @@ int tsamd_spmm(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
                const void *value, const void *mat, void *out, int64_t *arg_out,
                int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
                void *workspace, size_t workspace_bytes, void *stream);
+/* Verification mode: set = 1 makes tsamd_spmm / tsamd_spmm_cached / tsamd_spmm_minmax_arg32 (and every torch op on
+ * top of them) compute in the ORDER OF OPERATIONS of the reference CPU kernel (csrc/cpu/spmm_cpu.cpp:61-87,
+ * csrc/cpu/reducer.h:43-84: a row's entries one after the other, product and sum rounded separately in the element
+ * type, mean = sum / (scalar_t)count), one thread per output element: results BIT-IDENTICAL to the reference for every
+ * dtype and reduction, at a fraction of the speed.  set = 0 back to the product kernels, anything else: query.
+ * Returns the mode in force.  Process-wide; the backward kernels are not affected. */
+int tsamd_spmm_reference_order(int set);
 
 /* The same product with the entries of the CSR taken through a permutation: entry e is
  * (col[perm[e]], value[perm[e]]), perm [E] int64.  With (rowptr, col, perm) = (colptr, row, csr2csc)

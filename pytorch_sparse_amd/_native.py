@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('TSAMD_LIB') or os.path.join(_HERE, 'lib', 'libtsamd.s
 # Every symbol include/tsamd.h declares (tests check that all of them resolve).
 SYMBOLS = [
     'tsamd_hip_version', 'tsamd_build_flags', 'tsamd_last_hip_error', 'tsamd_status_string',
-    'tsamd_spmm_workspace_bytes', 'tsamd_spmm', 'tsamd_spmm_permuted', 'tsamd_spmm_profiled',
+    'tsamd_spmm_workspace_bytes', 'tsamd_spmm', 'tsamd_spmm_reference_order', 'tsamd_spmm_permuted', 'tsamd_spmm_profiled',
     'tsamd_spmm_partial_workspace_bytes', 'tsamd_spmm_partial',
     'tsamd_spmm_operand_cache_bytes', 'tsamd_spmm_cached_workspace_bytes', 'tsamd_spmm_cached',
     'tsamd_spmm_minmax_arg32', 'tsamd_spmm_minmax_bw_csc_arg32',

@@ -23,7 +23,7 @@ LIBDIR = os.path.join(PKG, 'lib')
 OBJDIR = os.path.join(ROOT, 'build', 'obj')
 ARCH = 'gfx950'
 
-HIP_SOURCES = ['api.hip', 'spmm.hip', 'spmm_min.hip', 'spmm_max.hip', 'spmm_partial.hip', 'spmm_bw.hip', 'spmm_bw_list.hip', 'spmm_coo.hip', 'convert.hip', 'scan.hip', 'sort.hip',
+HIP_SOURCES = ['api.hip', 'spmm.hip', 'spmm_min.hip', 'spmm_max.hip', 'spmm_partial.hip', 'spmm_bw.hip', 'spmm_bw_list.hip', 'spmm_ref_order.hip', 'spmm_coo.hip', 'convert.hip', 'scan.hip', 'sort.hip',
                'coalesce.hip', 'spspmm.hip', 'select.hip', 'sample.hip', 'segreduce.hip']
 OPS_SOURCES = ['ops_spmm.cpp', 'ops_storage.cpp', 'ops_sample.cpp']
 # translation units that #include another .hip file (rebuilt when that one changes)

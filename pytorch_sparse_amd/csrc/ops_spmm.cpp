@@ -835,6 +835,10 @@ Tensor spmm_coo_small(Tensor index, Tensor value, int64_t M, int64_t N, Tensor m
 
 int64_t cuda_version() { return tsamd_hip_version(); }
 
+// tsamd_spmm_reference_order (include/tsamd.h): 1 = every SpMM forward in the reference CPU kernel's order of
+// operations (bit-identical results, slow), 0 = the product kernels, anything else = query; returns the mode in force
+int64_t reference_order(int64_t set) { return (int64_t)tsamd_spmm_reference_order((int)set); }
+
 // torch.are_deterministic_algorithms_enabled() for TorchScript callers (storage_spmm)
 bool deterministic_mode() { return at::globalContext().deterministicAlgorithms(); }
 
@@ -856,6 +860,7 @@ static auto registry_spmm = torch::RegisterOperators()
                            .op("tsamd::spmm_coo_small_supported", &spmm_coo_small_supported)
                            .op("tsamd::spmm_minmax", &spmm_minmax)
                            .op("tsamd::deterministic", &deterministic_mode)
+                           .op("tsamd::reference_order", &reference_order)
                            .op("tsamd::spmm_sum_owned", &spmm_sum_owned)
                            .op("tsamd::spmm_mean_owned", &spmm_mean_owned)
                            .op("tsamd::operand_cache", &operand_cache_ctl)

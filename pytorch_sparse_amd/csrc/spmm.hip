@@ -1574,6 +1574,9 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   if (B * M * K == 0) return TSAMD_OK;  // nothing to write
   if (!rowptr || !out || (E > 0 && (!col || !mat)) || (minmax && !arg_out))
     return TSAMD_ERR_INVALID;
+  // verification mode (tsamd_spmm_reference_order): the plain product in the reference's order of operations
+  if (spmm_reference_order_on() && !relabelled && perm == nullptr && wmask == nullptr && partial == nullptr)
+    return spmm_reference_order_run(dtype, reduce, rowptr, col, value, mat, out, arg_out, arg32, B, M, N, K, E, stream);
   // operand cache: the relabelled copy and the probe verdict live in the caller's buffer, not in the workspace
   const size_t cache_need = operand_cache_bytes(dtype, reduce, B, N, K, E);
   const bool use_cache = cache != nullptr && !relabelled && cache_need > 0 && cache_bytes >= cache_need &&

@@ -30,6 +30,12 @@ int spmm_masked_sum(int dtype, const int64_t *rowptr, bool has_value, const int6
                     const uint32_t *records, const void *mat, void *out, int64_t B, int64_t M, int64_t N,
                     int64_t K, int64_t E, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
+// Verification mode (csrc/spmm_ref_order.hip): the reference CPU kernel's order of operations, bit-identical results.
+bool spmm_reference_order_on();
+int spmm_reference_order_run(int dtype, int reduce, const int64_t *rowptr, const int64_t *col, const void *value,
+                             const void *mat, void *out, void *arg_out, bool arg32, int64_t B, int64_t M, int64_t N,
+                             int64_t K, int64_t E, hipStream_t stream);
+
 // grad_mat of the min / max backward by winner lists (csrc/spmm_bw_list.hip): compacted (feature, product) pairs per
 // entry instead of one grad_out row per entry.  K <= 1024, ids < 2^32.
 bool minmax_bw_lists_supported(int dtype, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E);

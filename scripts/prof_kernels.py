@@ -143,6 +143,14 @@ def _ctor():
 _index4 = torch.stack([r4, c4])
 run('coalesce_7m5', lambda: ts.coalesce(_index4, v4, m, m), entries=7500000, algorithmic_bytes=7500000 * 20 * 2)
 run('construct_7m5', _ctor, entries=7500000, algorithmic_bytes=7500000 * 20 * 2 + (m + 1) * 8)
+run('transpose_7m5', lambda: ts.transpose(_index4, v4, m, m), entries=7500000, algorithmic_bytes=7500000 * 20 * 2)
+if not which or 'sort_coo_75m' in which:
+    _m75 = 1 << 22
+    _r75, _c75 = synth.uniform_edges(_m75, _m75, 75000000, seed=0, device=dev)
+    run('sort_coo_75m', lambda: torch.ops.tsamd.sort_coo(_r75, _c75, _m75, _m75, True), entries=75000000,
+        algorithmic_bytes=75000000 * 16 * 2 + 75000000 * 8)
+    del _r75, _c75
+    torch.cuda.empty_cache()
 A = ts.SparseTensor(row=r4, col=c4, value=v4, sparse_sizes=(m, m)).coalesce()
 At = A.t()
 rpB = At.storage.rowptr()

@@ -782,3 +782,42 @@ def test_minmax_all_init_value_reports_no_winner(dev):
     lo = torch.tensor([[-big, float('nan')], [-big, float('nan')]])
     out, arg = nat.spmm(rp.to(dev), c.to(dev), None, lo.to(dev), 'max')
     assert arg.cpu().tolist() == [[4, 4], [4, 4]] and out.cpu()[:, 0].tolist() == [-big, -big]
+
+
+@pytest.mark.parametrize('dtype', ALL_DTYPES)
+@pytest.mark.parametrize('reduce', ['sum', 'mean', 'min', 'max'])
+def test_reference_order_mode_is_bit_identical_to_the_reference(dev, dtype, reduce):
+    """tsamd_spmm_reference_order(1): the forward in the reference CPU kernel's order of operations (csrc/cpu/spmm_cpu.cpp:
+    61-87: entries of a row one after the other, product and sum rounded separately in the element type) -- EVERY bit of
+    the output equals the compiled reference's (oracle/_ref), fp sums included; hub rows (thousands of terms), empty rows,
+    batches, value-less matrices, through the C-ABI and through the drop-in torch op."""
+    from tests.baseline_configs import ref_spmm_cpu
+    rp, c = synth.rmat_csr(11, 24, seed=2)  # max degree in the thousands
+    n = 1 << 11
+    try:
+        assert torch.ops.tsamd.reference_order(1) == 1
+        for K, has_value, batch in ((32, True, ()), (5, False, ()), (16, True, (2, ))):
+            v, x = make_inputs(rp, c, n, K, dtype, has_value, batch, seed=3)
+            want, warg, kind = ref_spmm_cpu(rp, c, v, x, reduce)
+            out, arg = run_gpu(dev, rp, c, v, x, reduce)
+            if kind == 'reference':  # (without oracle/_ref the C restatement accumulates 2-byte types in fp32)
+                assert bits_equal(out.cpu(), want), (K, has_value, batch)
+            else:
+                check_spmm(out, arg, rp, c, v, x, reduce)
+            if reduce in ('min', 'max'):
+                live = (rp[1:] > rp[:-1]).view(-1, 1).expand(n, K)  # rows with entries (the reference leaves E elsewhere too)
+                assert torch.equal(arg.cpu()[..., live], warg[..., live])
+        if dtype == torch.float32:  # the drop-in op takes the same switch
+            import pytorch_sparse_amd as ts
+            v, x = make_inputs(rp, c, n, 32, dtype, True, (), seed=4)
+            A = ts.SparseTensor(rowptr=rp.to(dev), col=c.to(dev), value=v.to(dev), sparse_sizes=(n, n), is_sorted=True,
+                                trust_data=True)
+            want = ref_spmm_cpu(rp, c, v, x, reduce)[0]
+            got = A.matmul(x.to(dev), reduce=reduce)
+            assert bits_equal(got.cpu(), want)
+    finally:
+        assert torch.ops.tsamd.reference_order(0) == 0
+    # back on the product kernels: same values within the documented bound
+    v, x = make_inputs(rp, c, n, 32, dtype, True, (), seed=3)
+    out, arg = run_gpu(dev, rp, c, v, x, reduce)
+    check_spmm(out, arg, rp, c, v, x, reduce)
