@@ -103,7 +103,10 @@ int bits_for(int64_t n) {  // bits needed for ids in [0, n)
 // ---------------------------------------------------------------------------
 constexpr int kBkMaxBits = 11;                   // buckets one scatter level separates (LDS counters of a tile)
 constexpr int kBkMaxBuckets = 1 << kBkMaxBits;
-constexpr int kBkMaxTotalBits = 14;              // buckets of a sort (two levels): bins of the build kernel's LDS histogram
+#ifndef TSAMD_BK_MAX_TOTAL_BITS
+#define TSAMD_BK_MAX_TOTAL_BITS 14
+#endif
+constexpr int kBkMaxTotalBits = TSAMD_BK_MAX_TOTAL_BITS;  // buckets of a sort (two levels): bins of the build kernel's LDS histogram
 constexpr int kBkMaxHist = 1 << kBkMaxTotalBits;
 #ifndef TSAMD_BK_HIST_COPIES
 #define TSAMD_BK_HIST_COPIES 8
@@ -155,7 +158,11 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
   // (the pass digits are histogrammed whether or not the passes will run: this kernel is bound by its 24 bytes per
   // entry, the counters cost nothing measurable, and a separate histogram kernel in front of the passes costs the
   // one-sweep chain 5 us when it does not run and a read of the words when it does)
+#if defined(TSAMD_EXP_BUILD_NO_PASS_HIST)  // timing experiment (scripts/variants.py): the one-sweep passes would be wrong
+  const int hist_passes = B.on ? 0 : L.passes;
+#else
   const int hist_passes = L.passes;
+#endif
   for (int p = 0; p < hist_passes; ++p)
     if (threadIdx.x < kRadix) cnt[p][threadIdx.x] = 0;
   if (B.on)
