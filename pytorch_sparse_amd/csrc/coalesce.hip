@@ -59,12 +59,18 @@ __global__ __launch_bounds__(kCheckThreads) void order_check_kernel(const int64_
   const int lane = (int)(threadIdx.x & 63);
   constexpr int kB = 4;  // entries per thread and step, all loads of a step in flight together
   for (int64_t base = (int64_t)blockIdx.x * (kCheckThreads * kB); base < n; base += (int64_t)gridDim.x * (kCheckThreads * kB)) {
-    int64_t r[kB], c[kB];
+    int64_t r[kB], c[kB], pr0[kB], pc0[kB];  // (lane 0's predecessor: requested with the step's other loads)
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
       const int64_t i = base + u * kCheckThreads + threadIdx.x;
       r[u] = i < n ? row[i] : 0;
       c[u] = i < n ? col[i] : 0;
+      pr0[u] = 0;
+      pc0[u] = 0;
+      if (lane == 0 && i < n && i > 0) {
+        pr0[u] = row[i - 1];
+        pc0[u] = col[i - 1];
+      }
     }
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
@@ -73,8 +79,8 @@ __global__ __launch_bounds__(kCheckThreads) void order_check_kernel(const int64_
       int64_t pr = lane_below(r[u]), pc = lane_below(c[u]);  // (DPP: as ds_bpermute these were four LDS-pipe round trips per entry)
       if (i < n) {
         if (lane == 0 && i > 0) {
-          pr = row[i - 1];
-          pc = col[i - 1];
+          pr = pr0[u];
+          pc = pc0[u];
         }
         mr = (uint64_t)r[u] > (uint64_t)mr ? r[u] : mr;  // unsigned: a negative id reads as a huge one and fails the range check
         mc = (uint64_t)c[u] > (uint64_t)mc ? c[u] : mc;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void coalesce_compact_kernel(
   const int64_t ntiles = (n + kCompactTile - 1) / kCompactTile;
   const int64_t tile0 = tile * kCompactTile;
   // entry e = tile0 + i * 256 + tid: every load instruction of a wave covers 512 contiguous bytes
-  int64_t r[kCompactItems], c[kCompactItems];
+  int64_t r[kCompactItems], c[kCompactItems], pr0[kCompactItems], pc0[kCompactItems];
   unsigned long long hmask[kCompactItems];  // the wave's head flags of step i
   unsigned int heads = 0;
 #pragma unroll
@@ -153,6 +159,12 @@ __global__ __launch_bounds__(256) void coalesce_compact_kernel(
     const int64_t e = tile0 + i * 256 + tid;
     r[i] = e < n ? row[e] : 0;
     c[i] = e < n ? col[e] : 0;
+    pr0[i] = 0;
+    pc0[i] = 0;
+    if (lane == 0 && e < n && e > 0) {  // (the predecessor of the wave's first entry: in flight with the loads above)
+      pr0[i] = row[e - 1];
+      pc0[i] = col[e - 1];
+    }
   }
 #pragma unroll
   for (int i = 0; i < kCompactItems; ++i) {
@@ -161,8 +173,8 @@ __global__ __launch_bounds__(256) void coalesce_compact_kernel(
     bool h = false;
     if (e < n) {
       if (lane == 0 && e > 0) {
-        pr = row[e - 1];
-        pc = col[e - 1];
+        pr = pr0[i];
+        pc = pc0[i];
       }
       h = e == 0 || r[i] != pr || c[i] != pc;
     }

@@ -23,6 +23,7 @@ __global__ void ind2ptr_kernel(const int64_t *__restrict__ ind, int64_t *__restr
   int64_t hi = t == E ? M : ind[t];
   lo = lo < 0 ? 0 : lo;
   hi = hi > M ? M : hi;
+  if (t == E) out[M] = E;  // (always: the pre-set below may stop one word short of it)
   if (hi - lo >= kLongRun) return;
   for (int64_t i = lo; i <= hi; ++i) out[i] = t;
 }
@@ -77,8 +78,9 @@ extern "C" int tsamd_ind2ptr(const int64_t *ind, int64_t M, int64_t E, int64_t *
     return TSAMD_OK;
   }
   const int64_t n = E + 1;
-  // -1 = unset.  (As 32-bit words: a byte fill of a length that is not a multiple of 16 is TWO fill kernels.)
-  TSAMD_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out), -1, 2 * (size_t)(M + 1), stream));
+  // -1 = unset.  A fill whose length is not a multiple of 16 bytes is TWO fill kernels (bulk + tail, ~5 us each): the
+  // pre-set covers the multiple of 16 below (M + 1) * 8 and the kernel writes out[M] itself.
+  TSAMD_HIP_TRY(hipMemsetAsync(out, 0xff, (sizeof(int64_t) * (size_t)(M + 1)) & ~(size_t)15, stream));
   hipLaunchKernelGGL(ind2ptr_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream,
                      ind, out, M, E);
   TSAMD_LAUNCH_CHECK();

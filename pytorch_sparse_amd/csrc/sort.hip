@@ -147,11 +147,12 @@ struct SortBits {
 // build: words (or keys) + every pass's digit histogram (+ the order probe) in one read of (row, col)
 // ---------------------------------------------------------------------------
 constexpr int kBuildThreads = 1024;
+constexpr int kBuildMaxWgs = 512;
 __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
     const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t n, KeyLayout L,
     unsigned long long *__restrict__ words, unsigned long long *__restrict__ hist /* [passes][256] */,
     unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo, int probe, BucketPlan B,
-    unsigned int *__restrict__ bhist) {
+    unsigned int *__restrict__ bhist, unsigned long long *__restrict__ wgstat /* [gridDim.x][4], with a bucket plan */) {
   if (todo != nullptr && *todo == 0) return;
   __shared__ unsigned int cnt[kMaxPasses][kRadix];
   __shared__ unsigned int bcnt[kBkMaxHist];
@@ -174,13 +175,20 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
   constexpr int kB = 4;  // entries per thread and step: the loads of a step are all in flight together
   for (int64_t base = (int64_t)blockIdx.x * (kBuildThreads * kB); base < n; base += (int64_t)gridDim.x * (kBuildThreads * kB)) {
     int64_t r[kB], c[kB];
-    bool ok[kB];
+    int64_t pr0[kB], pc0[kB];  // lane 0: the entry before its own (the last lane of the wave before), requested WITH the
+    bool ok[kB];               // step's other loads -- as a load inside the probe below it was a round trip per step
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
       const int64_t i = base + u * kBuildThreads + threadIdx.x;
       ok[u] = i < n;
       r[u] = ok[u] ? row[i] : 0;
       c[u] = ok[u] ? col[i] : 0;
+      pr0[u] = 0;
+      pc0[u] = 0;
+      if (probe && lane == 0 && ok[u] && i > 0) {
+        pr0[u] = row[i - 1];
+        pc0[u] = col[i - 1];
+      }
     }
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
@@ -201,8 +209,8 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
         }
         if (probe && i > 0) {
           if (lane == 0) {
-            pr = row[i - 1];
-            pc = col[i - 1];
+            pr = pr0[u];
+            pc = pc0[u];
           }
           desc += (r[u] < pr) || (r[u] == pr && c[u] < pc);
           dup += (r[u] == pr) && (c[u] == pc);
@@ -250,10 +258,13 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
       s_cnt[1][threadIdx.x >> 6] = dup;
     }
     __syncthreads();
-    if (threadIdx.x < 2) {  // one pair of atomics per workgroup: the two words are hot addresses
+    if (threadIdx.x < 2) {
       unsigned int t = 0;
       for (int ww = 0; ww < kBuildThreads / 64; ++ww) t += s_cnt[threadIdx.x][ww];
-      if (t) atomicAdd(&hdr[threadIdx.x == 0 ? kHdrDescents : kHdrDups], (unsigned long long)t);
+      // with a bucket plan: one slot per workgroup, added up by the plan kernel (the four result words are hot
+      // addresses: 512 workgroups finishing together queued ~15 us on them); else one pair of atomics per workgroup
+      if (B.on) wgstat[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+      else if (t) atomicAdd(&hdr[threadIdx.x == 0 ? kHdrDescents : kHdrDups], (unsigned long long)t);
     }
     if (probe == 2) {
       for (int off = 32; off > 0; off >>= 1) {
@@ -270,7 +281,8 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
       if (threadIdx.x < 2) {
         unsigned long long t = 0;
         for (int ww = 0; ww < kBuildThreads / 64; ++ww) t = s_max[threadIdx.x][ww] > t ? s_max[threadIdx.x][ww] : t;
-        if (t > hdr[kHdrMaxRow + threadIdx.x]) atomicMax(&hdr[kHdrMaxRow + threadIdx.x], t);
+        if (B.on) wgstat[(size_t)blockIdx.x * 4 + 2 + threadIdx.x] = t;
+        else if (t > hdr[kHdrMaxRow + threadIdx.x]) atomicMax(&hdr[kHdrMaxRow + threadIdx.x], t);
       }
     }
   }
@@ -293,9 +305,40 @@ __global__ __launch_bounds__(kBuildThreads) void sort_build_kernel(
 __global__ __launch_bounds__(kBuildThreads) void bucket_plan_kernel(
     const unsigned int *__restrict__ bhist, unsigned int *__restrict__ boff, unsigned int *__restrict__ cursor,
     unsigned int *__restrict__ cursor1, unsigned long long *__restrict__ hdr, const int64_t *__restrict__ todo,
-    int probe, BucketPlan B, int64_t n) {
+    int probe, BucketPlan B, int64_t n, const unsigned long long *__restrict__ wgstat, int build_wgs) {
   if (todo != nullptr && *todo == 0) return;  // (hdr[kHdrFast] stays 0: the passes write the copy + identity)
   const int lane = (int)(threadIdx.x & 63);
+  if (probe) {  // the probe's results: one slot per build workgroup -> hdr (sums of descents / duplicates, maxima of ids)
+    unsigned long long v[4] = {0, 0, 0, 0};
+    for (int g = (int)threadIdx.x; g < build_wgs; g += kBuildThreads) {
+      v[0] += wgstat[(size_t)g * 4];
+      v[1] += wgstat[(size_t)g * 4 + 1];
+      if (probe == 2) {
+        v[2] = wgstat[(size_t)g * 4 + 2] > v[2] ? wgstat[(size_t)g * 4 + 2] : v[2];
+        v[3] = wgstat[(size_t)g * 4 + 3] > v[3] ? wgstat[(size_t)g * 4 + 3] : v[3];
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      v[0] += (unsigned long long)lane_xor((int64_t)v[0], off);
+      v[1] += (unsigned long long)lane_xor((int64_t)v[1], off);
+      const unsigned long long a = (unsigned long long)lane_xor((int64_t)v[2], off), b = (unsigned long long)lane_xor((int64_t)v[3], off);
+      v[2] = a > v[2] ? a : v[2];
+      v[3] = b > v[3] ? b : v[3];
+    }
+    __shared__ unsigned long long s_st[4][kBuildThreads / 64];
+    if (lane == 0)
+      for (int q = 0; q < 4; ++q) s_st[q][threadIdx.x >> 6] = v[q];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      unsigned long long t = 0;
+      for (int ww = 0; ww < kBuildThreads / 64; ++ww) {
+        const unsigned long long x = s_st[threadIdx.x][ww];
+        t = threadIdx.x < 2 ? t + x : (x > t ? x : t);
+      }
+      hdr[threadIdx.x == 0 ? kHdrDescents : (threadIdx.x == 1 ? kHdrDups : kHdrMaxRow + (int)threadIdx.x - 2)] = t;
+    }
+    __syncthreads();
+  }
   __shared__ unsigned int sc[kBkMaxHist];
   for (int b = (int)threadIdx.x; b < B.nb; b += kBuildThreads) {  // (coalesced; the copies' loads in flight together)
     unsigned int part[kBkHistCopies], t = 0;
@@ -1419,6 +1462,7 @@ struct SortWs {
   unsigned long long *hdr, *hist, *tile_state, *a, *b;
   unsigned int *ia, *ib;
   unsigned int *bhist, *boff, *cursor, *cursor1;
+  unsigned long long *wgstat;  // [kBuildMaxWgs][4]: the probe's per-workgroup results (with a bucket plan)
   size_t zero_bytes;  // hdr + hist + tile_state (+ the used part of bhist) are contiguous: one memset
 };
 
@@ -1441,6 +1485,7 @@ size_t carve_sort(void *base, int64_t E, SortWs *ws) {
   w.boff = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * (kBkMaxHist + 1)));
   w.cursor = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxHist));
   w.cursor1 = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * kBkMaxBuckets));
+  w.wgstat = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * 4 * kBuildMaxWgs));
   w.a = reinterpret_cast<unsigned long long *>(take(12 * n));  // built words / keys; level 2's output (12-byte records with values)
   w.b = reinterpret_cast<unsigned long long *>(take(12 * n));  // words, or the 12-byte records of the bucket path
   w.ia = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int) * n));
@@ -1532,15 +1577,17 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
   if (co != nullptr && B.on && !B.strip && B.shift < L.idx_bits) B.on = 0;
   const bool ballot = sort_rank_mode(stream) == 1;
   TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes + (B.on ? sizeof(unsigned int) * (size_t)B.nb * kBkHistCopies : 0), stream));
+  int build_wgs = 1;
   {
     const int64_t nb = ceil_div(E, kBuildThreads * 4);
-    hipLaunchKernelGGL(sort_build_kernel, dim3((unsigned int)(nb < 512 ? nb : 512)), dim3(kBuildThreads), 0, stream,
-                       row, col, E, L, ws.a, ws.hist, ws.hdr, todo, probe ? (check4 ? 2 : 1) : 0, B, ws.bhist);
+    build_wgs = (int)(nb < kBuildMaxWgs ? nb : kBuildMaxWgs);
+    hipLaunchKernelGGL(sort_build_kernel, dim3((unsigned int)build_wgs), dim3(kBuildThreads), 0, stream,
+                       row, col, E, L, ws.a, ws.hist, ws.hdr, todo, probe ? (check4 ? 2 : 1) : 0, B, ws.bhist, ws.wgstat);
     TSAMD_LAUNCH_CHECK();
   }
   if (B.on) {
     hipLaunchKernelGGL(bucket_plan_kernel, dim3(1), dim3(kBuildThreads), 0, stream, ws.bhist, ws.boff, ws.cursor,
-                       ws.cursor1, ws.hdr, todo, probe ? 1 : 0, B, E);
+                       ws.cursor1, ws.hdr, todo, probe ? (check4 ? 2 : 1) : 0, B, E, ws.wgstat, build_wgs);
     TSAMD_LAUNCH_CHECK();
     // bucket path: scatter into ws.b (two levels: on into ws.a), sort every bucket in LDS, write the outputs.  These
     // kernels return at once unless the plan kernel raised hdr[kHdrFast]; the passes below return at once when it did (~5 us
