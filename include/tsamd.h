@@ -612,6 +612,30 @@ int tsamd_set_diag_apply(const int64_t *pos, const int64_t *row, const int64_t *
  *                       of node ids) and rank[T + 1] are scratch the caller provides; info[0] =
  *                       number of new nodes, info[1] = #ids outside [0, M).  _apply writes
  *                       local[T] and n_id[n + info[0]] (either may be NULL).
+ * tsamd_relabel_seed / _extend   the same numbering for MULTI-HOP samplers (neighbor_sample_cpu.cpp:23-133,
+ *                       135-400: one std::unordered_map per node type that lives across hops and relations):
+ *                       slot[M] is set up ONCE per call and node type (_seed: seeds idx[n] hold -(i + 1), *count
+ *                       (device) = n, *err (device) = #ids outside [0, M)); every _extend numbers the ids of
+ *                       nbr[T] that are new (n_id[*count + rank] = id, first-occurrence order), turns their slots
+ *                       into -(id + 1), writes local[T] (may be NULL) and adds the number of new nodes to *count --
+ *                       all on the device: n_id is a buffer of `capacity` ids (the caller knows *count + T as an
+ *                       upper bound), *err counts bad ids and appends beyond the capacity.  No host read-back, no
+ *                       M-sized fill and no re-seeding per hop.  rank[T + 1] scratch, workspace as _relabel_plan.
+ * tsamd_temporal_*    the building blocks of hetero_temporal_neighbor_sample (neighbor_sample_cpu.cpp:222-340: one
+ *                     computation tree per root, nodes are (node, root) PAIRS, a neighbour v may be drawn for a node of
+ *                     root time t only if node_time[v] <= t).  The constraint is a FLAG per draw (keep[T], int64 0 / 1)
+ *                     until the end; one size read-back (info) per relation and hop.
+ *   _mark             keep[t] = src_time[nbr[t]] <= f_time[seg[t]] (src_time == NULL: 1); seg[t] = frontier node of draw t.
+ *   _redraw           sampling WITH replacement (:268-300): k uniform picks per frontier node among its draws with
+ *                     keep = 1 (nbr / e / keep list ALL its neighbours, out_ptr[F + 1] delimits them) -> nbr2, e2, seg2,
+ *                     keep2 of F * k entries (keep2 = 0 for a node without a valid neighbour).
+ *   _relabel          first-occurrence numbering of the pairs (nbr[t], f_root[seg[t]]) with keep[t] = 1 behind the n pairs
+ *                     (old_node, old_root) already numbered (distinct): local[T] (undefined where keep = 0),
+ *                     keep_rank[T + 1] / open_rank[T + 1] = exclusive ranks of the kept draws / of the draws that open a new
+ *                     pair, info[0] = #kept, info[1] = #new pairs (device).  One stable sort of n + T pairs
+ *                     (tsamd_sort_coo); node ids < num_nodes, roots < num_roots.
+ *   _emit             after the caller has read info: rows / cols / edges [info[0]] = (local, seg + begin, e) of the kept
+ *                     draws, node_out / root_out / time_out [info[1]] = (nbr, f_root[seg], f_time[seg]) of the new pairs.
  * tsamd_subset_assoc  assoc[M] = position of every node in idx, -1 elsewhere (the association
  *                     array of subgraph_cpu, csrc/cpu/saint_cpu.cpp:17-18); *err = #bad ids.
  *                     SAINT sub-graphs are then select + filter(TSAMD_KEEP_COL_MAPPED).
@@ -633,6 +657,26 @@ int tsamd_relabel_plan(const int64_t *idx, int64_t n, const int64_t *nbr, int64_
 int tsamd_relabel_apply(const int64_t *idx, int64_t n, const int64_t *nbr, int64_t T, int64_t M,
                         const int64_t *slot, const int64_t *rank, int64_t *local, int64_t *n_id,
                         void *stream);
+int tsamd_relabel_seed(const int64_t *idx, int64_t n, int64_t M, int64_t *slot, int64_t *count,
+                       int64_t *err, void *stream);
+int tsamd_relabel_extend(const int64_t *nbr, int64_t T, int64_t M, int64_t *slot, int64_t *rank,
+                         int64_t *count, int64_t *local, int64_t *n_id, int64_t capacity, int64_t *err,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int tsamd_temporal_mark(const int64_t *nbr, const int64_t *seg, int64_t T, const int64_t *src_time,
+                        const int64_t *f_time, int64_t *keep, void *stream);
+size_t tsamd_temporal_redraw_workspace_bytes(int64_t T);
+int tsamd_temporal_redraw(const int64_t *out_ptr, int64_t F, int64_t T, int64_t k, uint64_t seed,
+                          const int64_t *nbr, const int64_t *e, const int64_t *keep, int64_t *nbr2, int64_t *e2,
+                          int64_t *seg2, int64_t *keep2, void *workspace, size_t workspace_bytes, void *stream);
+size_t tsamd_temporal_relabel_workspace_bytes(int64_t n, int64_t T);
+int tsamd_temporal_relabel(const int64_t *old_node, const int64_t *old_root, int64_t n, const int64_t *nbr,
+                           const int64_t *seg, const int64_t *f_root, const int64_t *keep, int64_t T,
+                           int64_t num_nodes, int64_t num_roots, int64_t *local, int64_t *keep_rank,
+                           int64_t *open_rank, int64_t *info, void *workspace, size_t workspace_bytes, void *stream);
+int tsamd_temporal_emit(const int64_t *nbr, const int64_t *e, const int64_t *seg, const int64_t *f_root,
+                        const int64_t *f_time, const int64_t *keep_rank, const int64_t *open_rank,
+                        const int64_t *local, int64_t T, int64_t begin, int64_t *rows, int64_t *cols, int64_t *edges,
+                        int64_t *node_out, int64_t *root_out, int64_t *time_out, void *stream);
 int tsamd_subset_assoc(const int64_t *idx, int64_t n, int64_t M, int64_t *assoc, int64_t *err,
                        void *stream);
 

@@ -36,7 +36,9 @@ SYMBOLS = [
     'tsamd_scatter_rows',
     'tsamd_num_diag', 'tsamd_non_diag_mask', 'tsamd_insert_diag', 'tsamd_set_diag_apply',
     'tsamd_random_walk', 'tsamd_sample_workspace_bytes', 'tsamd_sample_plan', 'tsamd_sample_draw',
-    'tsamd_relabel_workspace_bytes', 'tsamd_relabel_plan', 'tsamd_relabel_apply', 'tsamd_subset_assoc',
+    'tsamd_relabel_workspace_bytes', 'tsamd_relabel_plan', 'tsamd_relabel_apply', 'tsamd_relabel_seed',
+    'tsamd_relabel_extend', 'tsamd_temporal_mark', 'tsamd_temporal_redraw_workspace_bytes', 'tsamd_temporal_redraw',
+    'tsamd_temporal_relabel_workspace_bytes', 'tsamd_temporal_relabel', 'tsamd_temporal_emit', 'tsamd_subset_assoc',
 ]
 
 DTYPES = {

@@ -221,13 +221,165 @@ std::tuple<Tensor, Tensor, Tensor> saint_subgraph(Tensor idx, Tensor rowptr, Ten
   return induced_entries(idx, rowptr, col);
 }
 
+// ---- heterogeneous multi-hop sampling (csrc/cpu/neighbor_sample_cpu.cpp:135-507) --------------------------------
+using node_t = std::string;
+using rel_t = std::string;
+using edge_t = std::tuple<std::string, std::string, std::string>;
+using TensorDict = c10::Dict<std::string, Tensor>;
+
+// one hop over one CSC in two steps, so that a caller can plan SEVERAL draws, read their sizes back in ONE transfer and
+// only then allocate and draw (the frontier slices of a hop do not depend on one another)
+struct Drawn {
+  Tensor frontier, colptr, row;
+  Tensor out_ptr, info;  // per frontier node: segment pointer; info = (total, #bad ids), on the device
+  Tensor nbr, e;         // per draw: the neighbour id and its position in `row`
+  int64_t k = 0, F = 0, T = 0;
+  bool replace = false;
+  uint64_t seed = 0;
+};
+
+Drawn plan_neighbors(const Tensor &colptr, const Tensor &row, const Tensor &frontier, int64_t k, bool replace, uint64_t seed) {
+  const int64_t M = colptr.numel() - 1, F = frontier.numel();
+  auto iopt = colptr.options().requires_grad(false);
+  Drawn d;
+  d.frontier = frontier;
+  d.colptr = colptr;
+  d.row = row;
+  d.k = k;
+  d.F = F;
+  d.replace = replace;
+  d.seed = seed;
+  d.out_ptr = torch::empty({F + 1}, iopt);
+  d.info = torch::empty({2}, iopt);
+  Tensor ws = workspace(tsamd_sample_workspace_bytes(F), colptr);
+  check_status(tsamd_sample_plan(colptr.data_ptr<int64_t>(), M, frontier.data_ptr<int64_t>(), F, k, replace ? 1 : 0,
+                                 d.out_ptr.data_ptr<int64_t>(), d.info.data_ptr<int64_t>(), ws.data_ptr(),
+                                 (size_t)ws.numel(), current_stream(colptr)),
+               "tsamd_sample_plan");
+  return d;
+}
+
+// ONE host read-back for the sizes of all planned draws
+void read_plans(std::vector<Drawn> &plans) {
+  if (plans.empty()) return;
+  std::vector<Tensor> infos;
+  for (auto &d : plans) infos.push_back(d.info);
+  const Tensor host = (infos.size() == 1 ? infos[0] : torch::cat(infos)).cpu();  // host sync
+  const int64_t *h = host.data_ptr<int64_t>();
+  for (size_t i = 0; i < plans.size(); ++i) {
+    plans[i].T = h[2 * i];
+    const int64_t bad = h[2 * i + 1];
+    TORCH_CHECK_INDEX(bad == 0, "index out of range: ", bad, " node ids are outside [0, ", plans[i].colptr.numel() - 1, ")");
+  }
+}
+
+void draw_planned(Drawn &d) {
+  const int64_t M = d.colptr.numel() - 1;
+  auto iopt = d.colptr.options().requires_grad(false);
+  void *stream = current_stream(d.colptr);
+  d.e = torch::empty({d.T}, iopt);
+  d.nbr = torch::empty({d.T}, iopt);
+  if (d.k < 0)
+    check_status(tsamd_select_fill(d.colptr.data_ptr<int64_t>(), M, d.row.data_ptr<int64_t>(), d.frontier.data_ptr<int64_t>(),
+                                   d.F, d.out_ptr.data_ptr<int64_t>(), d.T, nullptr, d.nbr.data_ptr<int64_t>(),
+                                   d.e.data_ptr<int64_t>(), stream),
+                 "tsamd_select_fill");
+  else
+    check_status(tsamd_sample_draw(d.colptr.data_ptr<int64_t>(), d.row.data_ptr<int64_t>(), d.frontier.data_ptr<int64_t>(),
+                                   d.F, d.k, d.replace ? 1 : 0, d.seed, d.out_ptr.data_ptr<int64_t>(),
+                                   d.e.data_ptr<int64_t>(), d.nbr.data_ptr<int64_t>(), stream),
+                 "tsamd_sample_draw");
+}
+
+Tensor segment_ids(const Tensor &out_ptr, int64_t F, int64_t T) {
+  Tensor seg = torch::empty({T}, out_ptr.options());
+  check_status(tsamd_ptr2ind(out_ptr.data_ptr<int64_t>(), F, T, seg.data_ptr<int64_t>(), current_stream(out_ptr)),
+               "tsamd_ptr2ind");
+  return seg;
+}
+
+// The node list of one node type while a multi-hop sampler runs: ids in a capacity buffer, the length in a DEVICE
+// counter, and the dense slot[] array of the relabel alive for the whole call (tsamd_relabel_seed / _extend): a hop
+// appends without any host read-back; the host learns the lengths once per hop (read_counts), for all types together.
+struct NodeList {
+  Tensor buf, slot, state;  // state (device) = (length of the list, #bad ids + appends beyond the capacity)
+  int64_t n = 0, M = 0;     // n: the length as of the last read-back
+  bool seeded = false;
+
+  void init(const Tensor &seeds, int64_t num_nodes) {
+    buf = seeds.contiguous();
+    n = buf.numel();
+    M = num_nodes;
+  }
+  // the first use as a source type: slot[] is filled and the seeds are entered (legal while count == n)
+  void seed() {
+    if (seeded) return;
+    auto iopt = buf.options().requires_grad(false);
+    slot = torch::empty({M}, iopt);
+    state = torch::empty({2}, iopt);
+    check_status(tsamd_relabel_seed(buf.data_ptr<int64_t>(), n, M, slot.data_ptr<int64_t>(), state.data_ptr<int64_t>(),
+                                    state.data_ptr<int64_t>() + 1, current_stream(buf)),
+                 "tsamd_relabel_seed");
+    seeded = true;
+  }
+  // room for `extra` more ids (called between hops, while count == n)
+  void reserve(int64_t extra) {
+    if (buf.numel() >= n + extra) return;
+    Tensor grown = torch::empty({n + extra}, buf.options());
+    if (n > 0) grown.narrow(0, 0, n).copy_(buf.narrow(0, 0, n));
+    buf = grown;
+  }
+  // numbers the ids of nbr (first-occurrence order behind everything listed so far) -> their local ids (or nothing)
+  Tensor extend(const Tensor &nbr, bool want_local) {
+    const int64_t T = nbr.numel();
+    auto iopt = buf.options().requires_grad(false);
+    Tensor local = torch::empty({want_local ? T : 0}, iopt);
+    if (T == 0) return local;
+    Tensor rank = torch::empty({T + 1}, iopt);
+    Tensor ws = workspace(tsamd_relabel_workspace_bytes(T), buf);
+    check_status(tsamd_relabel_extend(nbr.data_ptr<int64_t>(), T, M, slot.data_ptr<int64_t>(), rank.data_ptr<int64_t>(),
+                                      state.data_ptr<int64_t>(), want_local ? local.data_ptr<int64_t>() : nullptr,
+                                      buf.data_ptr<int64_t>(), buf.numel(), state.data_ptr<int64_t>() + 1, ws.data_ptr(),
+                                      (size_t)ws.numel(), current_stream(buf)),
+                 "tsamd_relabel_extend");
+    return local;
+  }
+  // (a view while the buffer is at most twice the list: the copy would cost more than the slack)
+  Tensor nodes() const { return buf.numel() == n ? buf : (buf.numel() <= 2 * n ? buf.narrow(0, 0, n) : buf.narrow(0, 0, n).clone()); }
+};
+
+// ONE host read-back for the lengths (and error counts) of all lists that were extended
+void read_counts(std::vector<NodeList *> lists) {
+  std::vector<Tensor> words;
+  std::vector<NodeList *> live;
+  for (NodeList *l : lists)
+    if (l->seeded) {
+      words.push_back(l->state);
+      live.push_back(l);
+    }
+  if (live.empty()) return;
+  const Tensor host = (words.size() == 1 ? words[0] : torch::cat(words)).cpu();  // host sync
+  const int64_t *h = host.data_ptr<int64_t>();
+  for (size_t i = 0; i < live.size(); ++i) {
+    TORCH_CHECK_INDEX(h[2 * i + 1] == 0, "node id out of range: ", h[2 * i + 1], " ids are outside [0, ", live[i]->M, ")");
+    live[i]->n = h[2 * i];
+  }
+}
+
+uint64_t host_seed() {  // from torch's CPU generator: torch.manual_seed() makes the draws reproducible
+  return (uint64_t)torch::randint(0, std::numeric_limits<int64_t>::max(), {1}, torch::TensorOptions().dtype(torch::kLong))
+      .item<int64_t>();
+}
+
 // torch_sparse::neighbor_sample(Tensor colptr, Tensor row, Tensor input_node, int[] num_neighbors,
 //                               bool replace, bool directed) -> (Tensor node, Tensor row, Tensor col, Tensor edge)
 // (reference schema, csrc/neighbor_sample.cpp:18-27; CPU-only there).  Multi-hop sampling on the
 // CSC view: hop l draws num_neighbors[l] in-neighbours of every node discovered in hop l-1; nodes
 // are numbered in first-occurrence order across hops; an edge is (local id of the drawn source,
 // local id of the frontier node, position in `row`).  directed=false returns instead every stored
-// edge between the sampled nodes.  Two host syncs per hop.
+// edge between the sampled nodes.  Two host read-backs per hop (size of the draw; length of the node list); the
+// relabel's slot array is set up once per call (round 6; before: an M x 8-byte fill and a re-seeding of every node
+// sampled so far in every hop).
 std::tuple<Tensor, Tensor, Tensor, Tensor> neighbor_sample(const Tensor &colptr_, const Tensor &row_,
                                                            const Tensor &input_node,
                                                            std::vector<int64_t> num_neighbors,
@@ -240,52 +392,33 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> neighbor_sample(const Tensor &colptr_
   Tensor colptr = colptr_.contiguous(), row = row_.contiguous();
   const int64_t M = colptr.numel() - 1;
   auto iopt = colptr.options().requires_grad(false);
-  void *stream = current_stream(colptr);
-  Tensor samples = input_node.contiguous();
-  int64_t begin = 0, end = samples.numel();
+  NodeList list;
+  list.init(input_node, M);
+  int64_t begin = 0, end = list.n;
   std::vector<Tensor> rows, cols, edges;
-  const uint64_t seed0 = (uint64_t)torch::randint(0, std::numeric_limits<int64_t>::max(), {1},
-                                                  torch::TensorOptions().dtype(torch::kLong))
-                             .item<int64_t>();
+  const uint64_t seed0 = host_seed();
   for (size_t ell = 0; ell < num_neighbors.size(); ++ell) {
     const int64_t k = num_neighbors[ell], F = end - begin;
-    Tensor frontier = samples.narrow(0, begin, F);
-    Tensor out_ptr = torch::empty({F + 1}, iopt), info = torch::empty({2}, iopt);
-    Tensor ws = workspace(tsamd_sample_workspace_bytes(F), colptr);
-    check_status(tsamd_sample_plan(colptr.data_ptr<int64_t>(), M, frontier.data_ptr<int64_t>(), F, k,
-                                   replace ? 1 : 0, out_ptr.data_ptr<int64_t>(),
-                                   info.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
-                 "tsamd_sample_plan");
-    Tensor h = info.cpu();  // sync 1
-    const int64_t T = h.data_ptr<int64_t>()[0], bad = h.data_ptr<int64_t>()[1];
-    TORCH_CHECK_INDEX(bad == 0, "index out of range: ", bad, " node ids are outside [0, ", M, ")");
-    Tensor e = torch::empty({T}, iopt), nbr = torch::empty({T}, iopt);
-    if (k < 0) {
-      check_status(tsamd_select_fill(colptr.data_ptr<int64_t>(), M, row.data_ptr<int64_t>(),
-                                     frontier.data_ptr<int64_t>(), F, out_ptr.data_ptr<int64_t>(), T,
-                                     nullptr, nbr.data_ptr<int64_t>(), e.data_ptr<int64_t>(), stream),
-                   "tsamd_select_fill");
-    } else {
-      check_status(tsamd_sample_draw(colptr.data_ptr<int64_t>(), row.data_ptr<int64_t>(),
-                                     frontier.data_ptr<int64_t>(), F, k, replace ? 1 : 0,
-                                     seed0 + 0x9E3779B97F4A7C15ull * (uint64_t)(ell + 1),
-                                     out_ptr.data_ptr<int64_t>(), e.data_ptr<int64_t>(),
-                                     nbr.data_ptr<int64_t>(), stream),
-                   "tsamd_sample_draw");
-    }
-    Relabelled r = relabel_impl(samples, nbr, M, directed);  // sync 2
+    std::vector<Drawn> plan;
+    plan.push_back(plan_neighbors(colptr, row, list.buf.narrow(0, begin, F), k, replace,
+                                  seed0 + 0x9E3779B97F4A7C15ull * (uint64_t)(ell + 1)));
+    read_plans(plan);  // sync 1
+    Drawn &d = plan[0];
+    list.seed();
+    list.reserve(d.T);
+    draw_planned(d);
+    Tensor local = list.extend(d.nbr, directed);
     if (directed) {
-      Tensor seg = torch::empty({T}, iopt);
-      check_status(tsamd_ptr2ind(out_ptr.data_ptr<int64_t>(), F, T, seg.data_ptr<int64_t>(), stream),
-                   "tsamd_ptr2ind");
-      rows.push_back(r.local);
+      Tensor seg = segment_ids(d.out_ptr, F, d.T);
+      rows.push_back(local);
       cols.push_back(begin > 0 ? seg + begin : seg);
-      edges.push_back(e);
+      edges.push_back(d.e);
     }
-    samples = r.n_id;
+    read_counts({&list});  // sync 2
     begin = end;
-    end = samples.numel();
+    end = list.n;
   }
+  Tensor samples = list.nodes();
   if (!directed) {
     auto sub = induced_entries(samples, colptr, row);
     return std::make_tuple(samples, std::get<1>(sub), std::get<0>(sub), std::get<2>(sub));
@@ -293,61 +426,6 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> neighbor_sample(const Tensor &colptr_
   Tensor none = torch::empty({0}, iopt);
   return std::make_tuple(samples, rows.empty() ? none : torch::cat(rows), cols.empty() ? none : torch::cat(cols),
                          edges.empty() ? none : torch::cat(edges));
-}
-
-// ---- heterogeneous multi-hop sampling (csrc/cpu/neighbor_sample_cpu.cpp:135-507) --------------------------------
-using node_t = std::string;
-using rel_t = std::string;
-using edge_t = std::tuple<std::string, std::string, std::string>;
-using TensorDict = c10::Dict<std::string, Tensor>;
-
-struct Drawn {
-  Tensor out_ptr, nbr, e;  // per frontier node: segment pointer; per draw: the neighbour id and its position in `row`
-  int64_t T;
-};
-
-// one hop over one CSC: k in-neighbours of every frontier node (k < 0: all) -- the plan / draw pair of neighbor_sample
-Drawn draw_neighbors(const Tensor &colptr, const Tensor &row, const Tensor &frontier, int64_t k, bool replace, uint64_t seed) {
-  const int64_t M = colptr.numel() - 1, F = frontier.numel();
-  auto iopt = colptr.options().requires_grad(false);
-  void *stream = current_stream(colptr);
-  Drawn d;
-  d.out_ptr = torch::empty({F + 1}, iopt);
-  Tensor info = torch::empty({2}, iopt);
-  Tensor ws = workspace(tsamd_sample_workspace_bytes(F), colptr);
-  check_status(tsamd_sample_plan(colptr.data_ptr<int64_t>(), M, frontier.data_ptr<int64_t>(), F, k, replace ? 1 : 0,
-                                 d.out_ptr.data_ptr<int64_t>(), info.data_ptr<int64_t>(), ws.data_ptr(),
-                                 (size_t)ws.numel(), stream),
-               "tsamd_sample_plan");
-  Tensor h = info.cpu();  // host sync
-  d.T = h.data_ptr<int64_t>()[0];
-  const int64_t bad = h.data_ptr<int64_t>()[1];
-  TORCH_CHECK_INDEX(bad == 0, "index out of range: ", bad, " node ids are outside [0, ", M, ")");
-  d.e = torch::empty({d.T}, iopt);
-  d.nbr = torch::empty({d.T}, iopt);
-  if (k < 0)
-    check_status(tsamd_select_fill(colptr.data_ptr<int64_t>(), M, row.data_ptr<int64_t>(), frontier.data_ptr<int64_t>(), F,
-                                   d.out_ptr.data_ptr<int64_t>(), d.T, nullptr, d.nbr.data_ptr<int64_t>(),
-                                   d.e.data_ptr<int64_t>(), stream),
-                 "tsamd_select_fill");
-  else
-    check_status(tsamd_sample_draw(colptr.data_ptr<int64_t>(), row.data_ptr<int64_t>(), frontier.data_ptr<int64_t>(), F, k,
-                                   replace ? 1 : 0, seed, d.out_ptr.data_ptr<int64_t>(), d.e.data_ptr<int64_t>(),
-                                   d.nbr.data_ptr<int64_t>(), stream),
-                 "tsamd_sample_draw");
-  return d;
-}
-
-Tensor segment_ids(const Tensor &out_ptr, int64_t F, int64_t T) {
-  Tensor seg = torch::empty({T}, out_ptr.options());
-  check_status(tsamd_ptr2ind(out_ptr.data_ptr<int64_t>(), F, T, seg.data_ptr<int64_t>(), current_stream(out_ptr)),
-               "tsamd_ptr2ind");
-  return seg;
-}
-
-uint64_t host_seed() {  // from torch's CPU generator: torch.manual_seed() makes the draws reproducible
-  return (uint64_t)torch::randint(0, std::numeric_limits<int64_t>::max(), {1}, torch::TensorOptions().dtype(torch::kLong))
-      .item<int64_t>();
 }
 
 struct HeteroSetup {
@@ -494,39 +572,63 @@ std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> hetero_neighbor_sampl
   HeteroSetup hs = hetero_setup(node_types, edge_types, colptr_dict, row_dict, input_node_dict, num_neighbors_dict);
   c10::hip::HIPGuard guard(hs.any.get_device());
   auto iopt = hs.any.options().requires_grad(false);
-  std::map<node_t, Tensor> samples;
+  std::map<node_t, NodeList> lists;
   std::map<node_t, std::pair<int64_t, int64_t>> slice;
+  std::vector<NodeList *> all_lists;
   for (const auto &t : node_types) {
-    samples[t] = input_node_dict.contains(t) ? input_node_dict.at(t).contiguous() : torch::empty({0}, iopt);
-    slice[t] = {0, samples[t].numel()};
+    lists[t].init(input_node_dict.contains(t) ? input_node_dict.at(t) : torch::empty({0}, iopt), hs.num_nodes.at(t));
+    slice[t] = {0, lists[t].n};
   }
+  for (auto &kv : lists) all_lists.push_back(&kv.second);
   std::map<rel_t, std::vector<Tensor>> rows, cols, edges;
   const uint64_t seed0 = host_seed();
   uint64_t draw_no = 0;
+  // Per hop: every relation's draw is PLANNED first (the frontier slices are fixed for the hop), ONE transfer reads all
+  // their sizes; the draws and relabels of the hop then run back to back on the device (NodeList); a second transfer at
+  // the end of the hop reads the new length of every node list.  Two host read-backs per hop whatever the number of
+  // relations (round 5: two per relation and hop).
   for (int64_t ell = 0; ell < num_hops; ++ell) {
+    std::vector<Drawn> plans;
+    std::vector<const rel_t *> plan_rel;
     for (const auto &rel : hs.rels_sorted) {
       const edge_t &et = hs.to_edge_type.at(rel);
-      const node_t &src_t = std::get<0>(et), &dst_t = std::get<2>(et);
+      const node_t &dst_t = std::get<2>(et);
       const auto &fan = num_neighbors_dict.at(rel);
       TORCH_CHECK((int64_t)fan.size() > ell, "num_neighbors_dict[", rel, "] has fewer than num_hops entries");
-      const int64_t k = fan[ell];
       const int64_t begin = slice.at(dst_t).first, F = slice.at(dst_t).second - begin;
       ++draw_no;
       if (F == 0) continue;
-      Tensor colptr = colptr_dict.at(rel).contiguous(), row = row_dict.at(rel).contiguous();
-      Tensor frontier = samples.at(dst_t).narrow(0, begin, F);
-      Drawn d = draw_neighbors(colptr, row, frontier, k, replace, seed0 + 0x9E3779B97F4A7C15ull * draw_no);
-      Relabelled r = relabel_impl(samples.at(src_t), d.nbr, hs.num_nodes.at(src_t), directed);
+      plans.push_back(plan_neighbors(colptr_dict.at(rel).contiguous(), row_dict.at(rel).contiguous(),
+                                     lists.at(dst_t).buf.narrow(0, begin, F), fan[ell], replace,
+                                     seed0 + 0x9E3779B97F4A7C15ull * draw_no));
+      plan_rel.push_back(&rel);
+    }
+    read_plans(plans);  // host sync 1 of the hop
+    std::map<node_t, int64_t> extra;
+    for (size_t i = 0; i < plans.size(); ++i) extra[std::get<0>(hs.to_edge_type.at(*plan_rel[i]))] += plans[i].T;
+    for (const auto &kv : extra) {
+      lists.at(kv.first).seed();
+      lists.at(kv.first).reserve(kv.second);
+    }
+    for (size_t i = 0; i < plans.size(); ++i) {
+      Drawn &d = plans[i];
+      const rel_t &rel = *plan_rel[i];
+      const edge_t &et = hs.to_edge_type.at(rel);
+      const int64_t begin = slice.at(std::get<2>(et)).first;
+      draw_planned(d);
+      Tensor local = lists.at(std::get<0>(et)).extend(d.nbr, directed);
       if (directed) {
-        Tensor seg = segment_ids(d.out_ptr, F, d.T);
-        rows[rel].push_back(r.local);
+        Tensor seg = segment_ids(d.out_ptr, d.F, d.T);
+        rows[rel].push_back(local);
         cols[rel].push_back(begin > 0 ? seg + begin : seg);
         edges[rel].push_back(d.e);
       }
-      samples[src_t] = r.n_id;
     }
-    for (const auto &t : node_types) slice[t] = {slice[t].second, samples[t].numel()};
+    if (!plans.empty()) read_counts(all_lists);  // host sync 2 of the hop
+    for (const auto &t : node_types) slice[t] = {slice[t].second, lists[t].n};
   }
+  std::map<node_t, Tensor> samples;
+  for (const auto &t : node_types) samples[t] = lists[t].nodes();
   if (!directed) {  // every stored edge between the sampled nodes, relation by relation (neighbor_sample_cpu.cpp:366-397)
     for (const auto &kv : colptr_dict) {
       const edge_t &et = hs.to_edge_type.at(kv.key());
@@ -542,30 +644,6 @@ std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> hetero_neighbor_sampl
   return pack_hetero(node_types, colptr_dict, samples, rows, cols, edges, hs.any);
 }
 
-// First-occurrence relabel of (node, root) PAIRS (the temporal sampler keeps one computation tree per root,
-// neighbor_sample_cpu.cpp:255-266): `old_key` are the pairs already numbered 0 .. n-1 (distinct), `new_key` the
-// candidates in draw order.  -> (local id of every candidate, mask of the candidates that open a new id, in order).
-// The key space (nodes x roots) is far too large for the dense slot array of relabel_impl: a device sort (ATen unique) and a
-// scatter-min of the positions instead -- this variant is the tail of SURVEY 8f rank 4, not a hot path.
-std::pair<Tensor, Tensor> relabel_pairs(const Tensor &old_key, const Tensor &new_key) {
-  const int64_t n = old_key.numel(), T = new_key.numel();
-  auto iopt = new_key.options().requires_grad(false);
-  if (T == 0) return {torch::empty({0}, iopt), torch::empty({0}, iopt.dtype(torch::kBool))};
-  Tensor all = torch::cat({old_key, new_key});
-  auto uq = at::_unique2(all, /*sorted=*/true, /*return_inverse=*/true, /*return_counts=*/false);
-  Tensor inverse = std::get<1>(uq);
-  const int64_t U = std::get<0>(uq).numel();
-  Tensor pos = torch::arange(n + T, iopt);
-  Tensor first = torch::full({U}, std::numeric_limits<int64_t>::max(), iopt).scatter_reduce_(0, inverse, pos, "amin", true);
-  Tensor opens = torch::zeros({n + T}, iopt.dtype(torch::kBool));
-  opens.index_fill_(0, first, true);                 // positions that are the first occurrence of their pair
-  Tensor opens_new = opens.narrow(0, n, T);          // ... among the candidates (the old pairs open themselves)
-  Tensor rank = opens_new.to(torch::kLong).cumsum(0) - 1;  // id - n of the pair a first occurrence opens
-  Tensor first_of = first.index_select(0, inverse.narrow(0, n, T));  // first position of every candidate's pair
-  Tensor local = torch::where(first_of < n, first_of, rank.index_select(0, (first_of - n).clamp_min(0)) + n);
-  return {local, opens_new};
-}
-
 // torch_sparse::hetero_temporal_neighbor_sample(..., Dict(str, Tensor) node_time_dict, int num_hops, bool replace,
 //     bool directed)                               (reference schema, csrc/neighbor_sample.cpp:47-63; directed only)
 // The hetero sampler with a time constraint: a neighbour v of type src may be drawn for a node of root time t only if
@@ -575,6 +653,10 @@ std::pair<Tensor, Tensor> relabel_pairs(const Tensor &old_key, const Tensor &new
 //       neighbor_sample_cpu.cpp:240-262, 305-330: fewer than num_neighbors may remain);
 //   with replacement: num_neighbors uniform draws among the neighbours that satisfy the constraint (the reference
 //       redraws until one does, :268-300 -- and never returns when none does; here such a node draws nothing).
+// Device-driven inside a (relation, hop) (csrc/sample.hip, tsamd_temporal_*): the constraint is a FLAG per draw, the
+// (node, root) pairs are numbered by one stable sort of old pairs + candidates, and only then ONE transfer reads
+// (#draws kept, #new pairs) and one kernel writes the compacted outputs.  Host read-backs: one per hop (the sizes of all
+// the hop's draws) + one per relation and hop.  (Round 5: an ATen composition with four to five per relation and hop.)
 std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> hetero_temporal_neighbor_sample(
     const std::vector<node_t> &node_types, const std::vector<edge_t> &edge_types, const TensorDict &colptr_dict,
     const TensorDict &row_dict, const TensorDict &input_node_dict,
@@ -586,12 +668,13 @@ std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> hetero_temporal_neigh
   auto iopt = hs.any.options().requires_grad(false);
   std::map<node_t, Tensor> tnode, troot, ttime;
   std::map<node_t, std::pair<int64_t, int64_t>> slice;
-  int64_t R = 1;  // stride of the root index inside a pair key
+  int64_t R = 1;  // number of roots
   for (const auto &kv : input_node_dict) R = std::max<int64_t>(R, kv.value().numel());
   for (const auto &t : node_types) {
     if (input_node_dict.contains(t)) {
       TORCH_CHECK(node_time_dict.contains(t), "hetero_temporal_neighbor_sample: no node_time for input type ", t);
       Tensor x = input_node_dict.at(t).contiguous();
+      check_index(node_time_dict.at(t), "node_time");
       tnode[t] = x;
       troot[t] = torch::arange(x.numel(), iopt);
       ttime[t] = node_time_dict.at(t).index_select(0, x);
@@ -606,55 +689,104 @@ std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> hetero_temporal_neigh
   const uint64_t seed0 = host_seed();
   uint64_t draw_no = 0;
   for (int64_t ell = 0; ell < num_hops; ++ell) {
+    std::vector<Drawn> plans;
+    std::vector<const rel_t *> plan_rel;
     for (const auto &rel : hs.rels_sorted) {
       const edge_t &et = hs.to_edge_type.at(rel);
-      const node_t &src_t = std::get<0>(et), &dst_t = std::get<2>(et);
+      const node_t &dst_t = std::get<2>(et);
       const auto &fan = num_neighbors_dict.at(rel);
       TORCH_CHECK((int64_t)fan.size() > ell, "num_neighbors_dict[", rel, "] has fewer than num_hops entries");
       const int64_t k = fan[ell];
       const int64_t begin = slice.at(dst_t).first, F = slice.at(dst_t).second - begin;
       ++draw_no;
       if (F == 0) continue;
-      Tensor colptr = colptr_dict.at(rel).contiguous(), row = row_dict.at(rel).contiguous();
-      Tensor frontier = tnode.at(dst_t).narrow(0, begin, F).contiguous();
-      Tensor f_root = troot.at(dst_t).narrow(0, begin, F), f_time = ttime.at(dst_t).narrow(0, begin, F);
-      const bool timed = node_time_dict.contains(src_t);
-      const bool redraw = replace && k >= 0;  // draws with replacement are made among the VALID neighbours
-      Drawn d = draw_neighbors(colptr, row, frontier, redraw ? -1 : k, false, seed0 + 0x9E3779B97F4A7C15ull * draw_no);
-      Tensor seg = segment_ids(d.out_ptr, F, d.T), nbr = d.nbr, e = d.e;
-      if (timed && d.T > 0) {
-        Tensor keep = node_time_dict.at(src_t).index_select(0, nbr) <= f_time.index_select(0, seg);
-        Tensor idx = torch::nonzero(keep).view(-1);  // host sync
-        nbr = nbr.index_select(0, idx);
-        e = e.index_select(0, idx);
-        seg = seg.index_select(0, idx);
+      const bool redraw = replace && k >= 0;  // draws with replacement are made among the VALID neighbours: list them all
+      plans.push_back(plan_neighbors(colptr_dict.at(rel).contiguous(), row_dict.at(rel).contiguous(),
+                                     tnode.at(dst_t).narrow(0, begin, F).contiguous(), redraw ? -1 : k, false,
+                                     seed0 + 0x9E3779B97F4A7C15ull * draw_no));
+      plan_rel.push_back(&rel);
+    }
+    read_plans(plans);  // the hop's one read-back of draw sizes
+    for (size_t i = 0; i < plans.size(); ++i) {
+      Drawn &d = plans[i];
+      const rel_t &rel = *plan_rel[i];
+      const edge_t &et = hs.to_edge_type.at(rel);
+      const node_t &src_t = std::get<0>(et), &dst_t = std::get<2>(et);
+      const int64_t k = num_neighbors_dict.at(rel)[ell];
+      const int64_t begin = slice.at(dst_t).first, F = d.F;
+      const bool redraw = replace && k >= 0;
+      if (d.T == 0) continue;
+      draw_planned(d);
+      void *stream = current_stream(d.colptr);
+      Tensor f_root = troot.at(dst_t).narrow(0, begin, F).contiguous(), f_time = ttime.at(dst_t).narrow(0, begin, F).contiguous();
+      Tensor src_time;
+      if (node_time_dict.contains(src_t)) {
+        src_time = node_time_dict.at(src_t).contiguous();
+        check_index(src_time, "node_time");
       }
-      if (redraw && nbr.numel() > 0) {
-        Tensor cnt = torch::bincount(seg, {}, F);                       // valid neighbours per frontier node
-        Tensor vptr = torch::cumsum(cnt, 0) - cnt;                      // ... and where their list starts
-        Tensor has = torch::nonzero(cnt > 0).view(-1);                  // host sync
-        Tensor u = torch::rand({has.numel(), k}, iopt.dtype(torch::kDouble));
-        Tensor c_h = cnt.index_select(0, has).view({-1, 1});
-        Tensor pick = torch::minimum((u * c_h.to(torch::kDouble)).to(torch::kLong), c_h - 1) + vptr.index_select(0, has).view({-1, 1});
-        pick = pick.view(-1);
-        nbr = nbr.index_select(0, pick);
-        e = e.index_select(0, pick);
-        seg = has.view({-1, 1}).expand({has.numel(), k}).reshape(-1);
-      } else if (redraw) {
-        seg = seg.narrow(0, 0, 0);
+      int64_t T = d.T;
+      Tensor seg = segment_ids(d.out_ptr, F, T), nbr = d.nbr, e = d.e;
+      Tensor keep = torch::empty({T}, iopt);
+      check_status(tsamd_temporal_mark(nbr.data_ptr<int64_t>(), seg.data_ptr<int64_t>(), T,
+                                       src_time.defined() ? src_time.data_ptr<int64_t>() : nullptr,
+                                       f_time.data_ptr<int64_t>(), keep.data_ptr<int64_t>(), stream),
+                   "tsamd_temporal_mark");
+      if (redraw) {
+        if (k == 0) continue;
+        const int64_t T2 = F * k;
+        Tensor nbr2 = torch::empty({T2}, iopt), e2 = torch::empty({T2}, iopt), seg2 = torch::empty({T2}, iopt),
+               keep2 = torch::empty({T2}, iopt);
+        Tensor ws = workspace(tsamd_temporal_redraw_workspace_bytes(T), nbr);
+        check_status(tsamd_temporal_redraw(d.out_ptr.data_ptr<int64_t>(), F, T, k, d.seed ^ 0xA5A5A5A55A5A5A5Aull,
+                                           nbr.data_ptr<int64_t>(), e.data_ptr<int64_t>(), keep.data_ptr<int64_t>(),
+                                           nbr2.data_ptr<int64_t>(), e2.data_ptr<int64_t>(), seg2.data_ptr<int64_t>(),
+                                           keep2.data_ptr<int64_t>(), ws.data_ptr(), (size_t)ws.numel(), stream),
+                     "tsamd_temporal_redraw");
+        nbr = nbr2;
+        e = e2;
+        seg = seg2;
+        keep = keep2;
+        T = T2;
       }
-      Tensor c_root = f_root.index_select(0, seg), c_time = f_time.index_select(0, seg);
-      auto rel_new = relabel_pairs(tnode.at(src_t) * R + troot.at(src_t), nbr * R + c_root);
-      Tensor opens = rel_new.second;
-      rows[rel].push_back(rel_new.first);
-      cols[rel].push_back(begin > 0 ? seg + begin : seg);
-      edges[rel].push_back(e);
-      if (nbr.numel() > 0) {
-        Tensor sel = torch::nonzero(opens).view(-1);  // host sync
-        tnode[src_t] = torch::cat({tnode.at(src_t), nbr.index_select(0, sel)});
-        troot[src_t] = torch::cat({troot.at(src_t), c_root.index_select(0, sel)});
-        ttime[src_t] = torch::cat({ttime.at(src_t), c_time.index_select(0, sel)});
+      const int64_t n_old = tnode.at(src_t).numel();
+      Tensor local = torch::empty({T}, iopt), keep_rank = torch::empty({T + 1}, iopt), open_rank = torch::empty({T + 1}, iopt);
+      Tensor info = torch::empty({2}, iopt);
+      Tensor ws = workspace(tsamd_temporal_relabel_workspace_bytes(n_old, T), nbr);
+      check_status(tsamd_temporal_relabel(tnode.at(src_t).data_ptr<int64_t>(), troot.at(src_t).data_ptr<int64_t>(), n_old,
+                                          nbr.data_ptr<int64_t>(), seg.data_ptr<int64_t>(), f_root.data_ptr<int64_t>(),
+                                          keep.data_ptr<int64_t>(), T, hs.num_nodes.at(src_t), R,
+                                          local.data_ptr<int64_t>(), keep_rank.data_ptr<int64_t>(),
+                                          open_rank.data_ptr<int64_t>(), info.data_ptr<int64_t>(), ws.data_ptr(),
+                                          (size_t)ws.numel(), stream),
+                   "tsamd_temporal_relabel");
+      const Tensor host = info.cpu();  // the relation's one read-back
+      const int64_t n_keep = host.data_ptr<int64_t>()[0], n_open = host.data_ptr<int64_t>()[1];
+      if (n_keep == 0) continue;
+      Tensor r_out = torch::empty({n_keep}, iopt), c_out = torch::empty({n_keep}, iopt), e_out = torch::empty({n_keep}, iopt);
+      Tensor node_new = tnode.at(src_t), root_new = troot.at(src_t), time_new = ttime.at(src_t);
+      if (n_open > 0) {
+        node_new = torch::empty({n_old + n_open}, iopt);
+        root_new = torch::empty({n_old + n_open}, iopt);
+        time_new = torch::empty({n_old + n_open}, iopt);
+        if (n_old > 0) {
+          node_new.narrow(0, 0, n_old).copy_(tnode.at(src_t));
+          root_new.narrow(0, 0, n_old).copy_(troot.at(src_t));
+          time_new.narrow(0, 0, n_old).copy_(ttime.at(src_t));
+        }
       }
+      check_status(tsamd_temporal_emit(nbr.data_ptr<int64_t>(), e.data_ptr<int64_t>(), seg.data_ptr<int64_t>(),
+                                       f_root.data_ptr<int64_t>(), f_time.data_ptr<int64_t>(), keep_rank.data_ptr<int64_t>(),
+                                       open_rank.data_ptr<int64_t>(), local.data_ptr<int64_t>(), T, begin,
+                                       r_out.data_ptr<int64_t>(), c_out.data_ptr<int64_t>(), e_out.data_ptr<int64_t>(),
+                                       node_new.data_ptr<int64_t>() + n_old, root_new.data_ptr<int64_t>() + n_old,
+                                       time_new.data_ptr<int64_t>() + n_old, stream),
+                   "tsamd_temporal_emit");
+      rows[rel].push_back(r_out);
+      cols[rel].push_back(c_out);
+      edges[rel].push_back(e_out);
+      tnode[src_t] = node_new;
+      troot[src_t] = root_new;
+      ttime[src_t] = time_new;
     }
     for (const auto &t : node_types) slice[t] = {slice[t].second, tnode[t].numel()};
   }

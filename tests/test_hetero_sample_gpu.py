@@ -158,3 +158,57 @@ def test_temporal_constraint_holds_on_every_drawn_edge(ops):
                 cnt = torch.bincount(c, minlength=roots.numel())
                 assert torch.equal(cnt, torch.where(valid > 0, torch.full_like(valid, 5), torch.zeros_like(valid)))
         assert seen > 0
+
+
+def _count_syncs(fn):
+    """Number of synchronising device -> host operations `fn` performs: torch's sync debug mode warns on each -- as a
+    Python warning when the operation is called from Python, on the process's stderr from inside a C++ operator (file
+    descriptor 2 is captured around the call)."""
+    import sys
+    import tempfile
+    import warnings
+    torch.cuda.synchronize()
+    sys.stderr.flush()
+    saved = os.dup(2)
+    with tempfile.TemporaryFile(mode='w+b') as tmp, warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        os.dup2(tmp.fileno(), 2)
+        torch.cuda.set_sync_debug_mode('warn')
+        try:
+            out = fn()
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+            sys.stderr.flush()
+            os.dup2(saved, 2)
+            os.close(saved)
+        tmp.seek(0)
+        text = tmp.read().decode(errors='replace')
+        n_py = sum('synchronizing' in str(w.message) for w in caught)
+    return out, text.count('synchronizing') + n_py
+
+
+@pytest.mark.parametrize('temporal', [False, True])
+def test_host_read_backs_per_hop(ops, temporal):
+    """The samplers are device-driven inside a hop: the untimed one reads back twice per hop (the sizes of all the hop's
+    draws; the new lengths of all node lists) however many relations there are, the temporal one once per hop + once per
+    (relation, hop) -- round 5: two resp. four to five per (relation, hop).  + one transfer for the set-up."""
+    sizes = {'paper': 5000, 'author': 2000, 'venue': 30}
+    colptr, row, times, g = _random_graph(9, sizes)
+    inp = {'paper': torch.randperm(sizes['paper'], generator=g)[:100], 'venue': torch.tensor([1, 2])}
+    hops = 3
+    fan = {r: [3] * hops for r in RELS}
+    todev = lambda d: {k: v.to(DEV) for k, v in d.items()}  # noqa: E731
+    C, Rw, In, Tm = todev(colptr), todev(row), todev(inp), todev(times)
+    if temporal:
+        call = lambda: ops.hetero_temporal_neighbor_sample(NODE_TYPES, EDGE_TYPES, C, Rw, In, fan, Tm, hops, False, True)  # noqa: E731
+    else:
+        call = lambda: ops.hetero_neighbor_sample(NODE_TYPES, EDGE_TYPES, C, Rw, In, fan, hops, False, True)  # noqa: E731
+    call()  # first call: fills the cache of the graph's id maxima
+    _, probe = _count_syncs(lambda: torch.ones(3, device=DEV).sum().item())
+    assert probe >= 1  # the counter sees a read-back
+    out, n_sync = _count_syncs(call)
+    assert sum(out[1][r].numel() for r in RELS) > 0
+    if temporal:
+        assert n_sync <= 1 + hops * (1 + len(RELS)), n_sync
+    else:
+        assert n_sync <= 1 + 2 * hops, n_sync

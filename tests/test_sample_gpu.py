@@ -388,3 +388,62 @@ def test_sample_adj_every_subset_equally_likely(D, k):
     chi2 = ((cnt - expect) ** 2 / expect).sum()
     dof = nsub - 1
     assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof) + 5, (chi2, dof)
+
+
+def test_relabel_seed_extend_cabi_matches_a_sequential_map():
+    """tsamd_relabel_seed / tsamd_relabel_extend (the multi-hop samplers' persistent relabel, include/tsamd.h): three
+    successive extends against the sequential std::unordered_map walk of neighbor_sample_cpu.cpp:41-103 restated as a
+    Python dict -- ids, list order and the device counter, with no read-back between the calls."""
+    import ctypes
+    from pytorch_sparse_amd import _native as nat
+    L = nat.lib()
+    L.tsamd_relabel_workspace_bytes.restype = ctypes.c_size_t
+    g = torch.Generator().manual_seed(7)
+    M = 5000
+    seeds = torch.randperm(M, generator=g)[:300]
+    draws = [torch.randint(0, M, (n, ), generator=g) for n in (2000, 1, 7000)]
+    # host restatement
+    to_local = {int(v): i for i, v in enumerate(seeds.tolist())}
+    order = seeds.tolist()
+    want_local = []
+    for d in draws:
+        loc = []
+        for v in d.tolist():
+            if v not in to_local:
+                to_local[v] = len(order)
+                order.append(v)
+            loc.append(to_local[v])
+        want_local.append(loc)
+    # device
+    cap = seeds.numel() + sum(d.numel() for d in draws)
+    buf = torch.empty(cap, dtype=torch.long, device=DEV)
+    buf[:seeds.numel()] = seeds.to(DEV)
+    slot = torch.empty(M, dtype=torch.long, device=DEV)
+    count = torch.empty(1, dtype=torch.long, device=DEV)
+    err = torch.empty(1, dtype=torch.long, device=DEV)
+    st = nat.stream_ptr(buf.device)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    I = lambda x: ctypes.c_int64(int(x))  # noqa: E731
+    nat.check(L.tsamd_relabel_seed(P(buf), I(seeds.numel()), I(M), P(slot), P(count), P(err), st), 'seed')
+    got_local = []
+    for d in draws:
+        dd = d.to(DEV)
+        T = dd.numel()
+        rank = torch.empty(T + 1, dtype=torch.long, device=DEV)
+        local = torch.empty(T, dtype=torch.long, device=DEV)
+        ws = nat.workspace(L.tsamd_relabel_workspace_bytes(I(T)), buf.device)
+        nat.check(L.tsamd_relabel_extend(P(dd), I(T), I(M), P(slot), P(rank), P(count), P(local), P(buf), I(cap), P(err),
+                                         P(ws), ctypes.c_size_t(ws.numel()), st), 'extend')
+        got_local.append(local)
+    assert int(err.item()) == 0
+    assert int(count.item()) == len(order)
+    assert buf[:len(order)].cpu().tolist() == order
+    for gl, wl in zip(got_local, want_local):
+        assert gl.cpu().tolist() == wl
+    # an id outside [0, M) and an append beyond the capacity are counted, not written
+    bad = torch.tensor([M, -1, 3], dtype=torch.long, device=DEV)
+    rank = torch.empty(4, dtype=torch.long, device=DEV)
+    ws = nat.workspace(L.tsamd_relabel_workspace_bytes(I(3)), buf.device)
+    nat.check(L.tsamd_relabel_extend(P(bad), I(3), I(M), P(slot), P(rank), P(count), None, P(buf), I(cap), P(err), P(ws),
+                                     ctypes.c_size_t(ws.numel()), st), 'extend')
+    assert int(err.item()) == 2
