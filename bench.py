@@ -194,14 +194,14 @@ def compact_row(r):
     if 'error' in r:
         return dict(config=r.get('config', '?'), error=_short(r['error'], 80))
     o = dict(config=r['config'] + ('_val' if r.get('has_value') else ''))
-    o.update(_pick(r, ('ms', 'fw_ms', 'bw_ms', 'bw_atomic_ms', 'matmul_fw_ms', 'matmul_fw_bw_ms', 'value_bw_ms', 'fw_bw_ms', 'fw_bw_fixed_weights_ms',
+    o.update(_pick(r, ('ms', 'fw_ms', 'bw_ms', 'bw_records_ms', 'bw_atomic_ms', 'matmul_fw_ms', 'matmul_fw_bw_ms', 'value_bw_ms', 'fw_bw_ms', 'fw_bw_fixed_weights_ms',
                        'gedges_per_s', 'gproducts_per_s')))
     roof = r.get('roofline') or {}
     if 'frac' in roof:
         o['frac'] = roof['frac']
     elif roof:  # construct: one roofline per call
         o['frac'] = {k: v.get('frac') for k, v in roof.items() if isinstance(v, dict)}
-    for extra in ('roofline_bw', 'roofline_fw_bw'):
+    for extra in ('roofline_bw', 'roofline_bw_records', 'roofline_fw_bw'):
         if isinstance(r.get(extra), dict) and 'frac' in r[extra]:
             o['frac_' + extra[9:]] = r[extra]['frac']
     cb = r.get('cpu_baseline')

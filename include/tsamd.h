@@ -315,6 +315,38 @@ int tsamd_spmm_minmax_bw_csc_arg32(int dtype, const int64_t *rowptr, const int64
                                    void *grad_value, void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
                                    int64_t E, void *workspace, size_t workspace_bytes, void *stream);
 
+/* min / max whose forward leaves the WINNER RECORDS of the pull backward instead of the winner ids (round 6): for a
+ * caller that keeps the winners only for its own backward (SparseTensor.matmul(x, 'max') with x.requires_grad:
+ * torch_sparse/matmul.py:60-77 -> csrc/spmm.cpp:183-242) the backward's first step -- re-reading the ids and writing one
+ * 32-byte record per entry, 0.30 of the 1.36 ms at configs[2] -- is done by the forward where the winners still sit in
+ * registers: at the end of every row that one wave finishes by itself it writes the row's records and does not store
+ * the ids at all; rows cut between waves get theirs from the ids right behind the forward (a pass that skips every
+ * 64-entry chunk without such a row).  Same records bit for bit as tsamd_spmm_minmax_winrec makes from the ids, hence
+ * the same gradients bit for bit.  The forward writes records itself for f32 / f16 / bf16 rows of 97..128 features;
+ * any other float shape works too (ids to the workspace, then every record from them).
+ *   tsamd_spmm_minmax_records_bytes        size of `records` ([B][E] records of 8..  32-bit words, see csrc/spmm_internal.h)
+ *   tsamd_spmm_minmax_records              out [B, M, K] and records; row [E] = COO row ids; E < 2^31
+ *   tsamd_spmm_minmax_winrec               records from int32 ids (what tsamd_spmm_minmax_bw_csc_arg32 does first)
+ *   tsamd_spmm_minmax_bw_csc_records       tsamd_spmm_minmax_bw_csc on such records: grad_mat (required) and grad_value
+ *                                          (optional; TSAMD_ERR_UNSUPPORTED unless the rows are 16-byte packets);
+ *                                          has_value: the matrix had values (they are in the records) */
+int tsamd_spmm_minmax_records_in_forward(int dtype, int64_t B, int64_t M, int64_t K, int64_t E); /* 1: the merge kernel writes them */
+size_t tsamd_spmm_minmax_records_bytes(int64_t B, int64_t K, int64_t E);
+size_t tsamd_spmm_minmax_records_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M, int64_t N, int64_t K,
+                                                 int64_t E);
+int tsamd_spmm_minmax_records(int dtype, int reduce, const int64_t *rowptr, const int64_t *col, const void *value,
+                              const void *mat, void *out, const int64_t *row, uint32_t *records, int64_t B, int64_t M,
+                              int64_t N, int64_t K, int64_t E, void *workspace, size_t workspace_bytes, void *stream);
+int tsamd_spmm_minmax_winrec(int dtype, const int64_t *row, const void *value, const int32_t *arg_out32,
+                             uint32_t *records, int64_t B, int64_t M, int64_t K, int64_t E, void *stream);
+size_t tsamd_spmm_minmax_bw_csc_records_workspace_bytes(int dtype, int64_t B, int64_t M, int64_t N, int64_t K,
+                                                        int64_t E);
+int tsamd_spmm_minmax_bw_csc_records(int dtype, const int64_t *rowptr, const int64_t *col, int has_value,
+                                     const void *mat, const void *grad_out, const uint32_t *records,
+                                     const int64_t *colptr, const int64_t *csr2csc, const int64_t *row,
+                                     void *grad_value, void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K,
+                                     int64_t E, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * COO row ids <-> CSR row pointer.  Replace ind2ptr_cuda / ptr2ind_cuda
  * (csrc/cuda/convert_cuda.cu:26-67, csrc/cpu/convert_cpu.cpp:7-57).

@@ -19,6 +19,8 @@ SYMBOLS = [
     'tsamd_spmm_partial_workspace_bytes', 'tsamd_spmm_partial',
     'tsamd_spmm_operand_cache_bytes', 'tsamd_spmm_cached_workspace_bytes', 'tsamd_spmm_cached',
     'tsamd_spmm_minmax_arg32', 'tsamd_spmm_minmax_bw_csc_arg32',
+    'tsamd_spmm_minmax_records_in_forward', 'tsamd_spmm_minmax_records_bytes', 'tsamd_spmm_minmax_records_workspace_bytes', 'tsamd_spmm_minmax_records',
+    'tsamd_spmm_minmax_winrec', 'tsamd_spmm_minmax_bw_csc_records_workspace_bytes', 'tsamd_spmm_minmax_bw_csc_records',
     'tsamd_gather_rows', 'tsamd_relabel_ids', 'tsamd_spmm_relabelled_workspace_bytes', 'tsamd_spmm_relabelled',
     'tsamd_spmm_coo_small_supported', 'tsamd_spmm_coo_small',
     'tsamd_spmm_value_bw',
@@ -70,6 +72,9 @@ def lib():
         L.tsamd_spmm_partial_workspace_bytes.restype = ctypes.c_size_t
         L.tsamd_spmm_minmax_bw_workspace_bytes.restype = ctypes.c_size_t
         L.tsamd_spmm_minmax_bw_csc_workspace_bytes.restype = ctypes.c_size_t
+        L.tsamd_spmm_minmax_records_bytes.restype = ctypes.c_size_t
+        L.tsamd_spmm_minmax_records_workspace_bytes.restype = ctypes.c_size_t
+        L.tsamd_spmm_minmax_bw_csc_records_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 
@@ -272,6 +277,69 @@ def spmm_minmax_bw_csc(rowptr, col, value, mat, grad_out, arg_out, colptr, csr2c
                 _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
                 ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
     check(st, 'tsamd_spmm_minmax_bw_csc')
+    return gv, gm
+
+
+def spmm_minmax_records(rowptr, col, value, mat, reduce, row, zero=False):
+    """C-ABI ``tsamd_spmm_minmax_records``: min / max forward that leaves the winner records of the pull backward
+    -> (out, records as int32 words).  zero: the buffer starts as zeros (padding words of a record are never written)."""
+    require_gpu(rowptr, col, value, mat, row)
+    mat = mat.contiguous()
+    M, E = rowptr.numel() - 1, col.numel()
+    N, K = mat.size(-2), mat.size(-1)
+    B = mat.numel() // (N * K) if N * K > 0 else 1
+    red = REDUCES[reduce]
+    dt = dtype_code(mat.dtype)
+    out = torch.empty(list(mat.shape[:-2]) + [M, K], dtype=mat.dtype, device=mat.device)
+    L = lib()
+    rec = (torch.zeros if zero else torch.empty)(L.tsamd_spmm_minmax_records_bytes(_i64(B), _i64(K), _i64(E)) // 4,
+                                                 dtype=torch.int32, device=mat.device)
+    ws = workspace(L.tsamd_spmm_minmax_records_workspace_bytes(dt, red, _i64(B), _i64(M), _i64(N), _i64(K), _i64(E)),
+                   mat.device)
+    with torch.cuda.device(mat.device):
+        st = L.tsamd_spmm_minmax_records(dt, red, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat), _ptr(out), _ptr(row),
+                                         _ptr(rec), _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
+                                         ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
+    check(st, 'tsamd_spmm_minmax_records')
+    return out, rec
+
+
+def spmm_minmax_winrec(row, value, arg32, K):
+    """C-ABI ``tsamd_spmm_minmax_winrec``: the winner records of int32 winner ids [B, M, K] -> int32 words."""
+    require_gpu(row, value, arg32)
+    arg32 = arg32.contiguous()
+    E, M = row.numel(), arg32.size(-2)
+    B = arg32.numel() // (M * K) if M * K > 0 else 1
+    L = lib()
+    rec = torch.zeros(L.tsamd_spmm_minmax_records_bytes(_i64(B), _i64(K), _i64(E)) // 4, dtype=torch.int32, device=row.device)
+    dt = dtype_code(value.dtype) if value is not None else 0
+    with torch.cuda.device(row.device):
+        st = L.tsamd_spmm_minmax_winrec(dt, _ptr(row), _ptr(value), _ptr(arg32), _ptr(rec), _i64(B), _i64(M), _i64(K),
+                                        _i64(E), stream_ptr(row.device))
+    check(st, 'tsamd_spmm_minmax_winrec')
+    return rec
+
+
+def spmm_minmax_bw_csc_records(rowptr, col, has_value, mat, grad_out, records, colptr, csr2csc, row, want_value=False):
+    """C-ABI ``tsamd_spmm_minmax_bw_csc_records``: the pull backward on records -> (grad_value or None, grad_mat)."""
+    require_gpu(rowptr, col, mat, grad_out, records, colptr, csr2csc, row)
+    dt = dtype_code(mat.dtype)
+    mat, grad_out = mat.contiguous(), grad_out.contiguous()
+    E = col.numel()
+    N, K = mat.size(-2), mat.size(-1)
+    M = grad_out.size(-2)
+    B = mat.numel() // (N * K) if N * K > 0 else 1
+    gv = torch.empty(E, dtype=mat.dtype, device=mat.device) if want_value else None
+    gm = torch.empty_like(mat)
+    L = lib()
+    ws = workspace(L.tsamd_spmm_minmax_bw_csc_records_workspace_bytes(dt, _i64(B), _i64(M), _i64(N), _i64(K), _i64(E)),
+                   mat.device)
+    with torch.cuda.device(mat.device):
+        st = L.tsamd_spmm_minmax_bw_csc_records(dt, _ptr(rowptr), _ptr(col), ctypes.c_int(1 if has_value else 0), _ptr(mat),
+                                                _ptr(grad_out), _ptr(records), _ptr(colptr), _ptr(csr2csc), _ptr(row),
+                                                _ptr(gv), _ptr(gm), _i64(B), _i64(M), _i64(N), _i64(K), _i64(E), _ptr(ws),
+                                                ctypes.c_size_t(ws.numel()), stream_ptr(mat.device))
+    check(st, 'tsamd_spmm_minmax_bw_csc_records')
     return gv, gm
 
 

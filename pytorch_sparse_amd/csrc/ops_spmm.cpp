@@ -485,9 +485,56 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
                                Tensor mat, bool has_value, bool is_max, OptTensor opt_colptr,
                                OptTensor opt_csr2csc, OptTensor opt_row, bool arg32) {
     OptTensor v = has_value ? OptTensor(value) : std::nullopt;
-    auto res = spmm_fw_cached(rowptr, col, v, mat, is_max ? "max" : "min", arg32);
-    Tensor out = std::get<0>(res), arg_out = std::get<1>(res).value();
     const bool has_csc = opt_colptr.has_value() && opt_csr2csc.has_value() && opt_row.has_value();
+    // Round 6: when the winners stay inside this node (arg32) and the pull backward is going to run (CSC arrays handed
+    // over, a gradient w.r.t. mat recorded), the forward leaves the pull's winner RECORDS instead of ids
+    // (tsamd_spmm_minmax_records: the merge kernel writes them where the winners sit in registers) and the backward
+    // starts at the masked sum: configs[2] forward + backward 2.26 -> 2.15 ms, gradients bit-identical
+    // (profiles/r06_ab_fwd_winrec.md).  Only when the records (32 bytes per entry) are at most twice the ids they replace
+    // (4 bytes per output element) -- they are what the node holds until the backward.
+    Tensor records;
+    bool use_records = false;
+    // (grad mode is off inside a Function's forward; the front-end hands the CSC arrays over only when it was on)
+    if (arg32 && has_csc && needs_grad(mat) && !operand_cache_state().enabled &&
+        mat.device().is_cuda() && mat.dim() >= 2 && rowptr.dim() == 1 && col.dim() == 1 &&
+        (mat.scalar_type() == at::kFloat || mat.scalar_type() == at::kHalf || mat.scalar_type() == at::kBFloat16) &&
+        (!has_value || value.scalar_type() == mat.scalar_type()) && opt_row.value().numel() == col.numel() &&
+        !stream_is_capturing(current_stream(mat))) {
+      const int64_t M = rowptr.numel() - 1, E = col.numel(), N = mat.size(-2), K = mat.size(-1);
+      const int64_t B = (N * K) > 0 ? mat.numel() / (N * K) : 1;
+      const int dt = dtype_code(mat);
+      const bool value_grad_ok = !(has_value && needs_grad(value)) || (K * (int64_t)mat.element_size()) % 16 == 0;
+      use_records = M > 0 && E > 0 && value_grad_ok && tsamd_spmm_minmax_records_in_forward(dt, B, M, K, E) == 1 &&
+                    tsamd_spmm_minmax_records_bytes(B, K, E) <= (size_t)(2 * 4 * B * M * K);
+    }
+    Tensor out, arg_out;
+    if (use_records) {
+      check_index(rowptr, "rowptr");
+      check_index(col, "col");
+      check_index(opt_row.value(), "row");
+      c10::hip::HIPGuard guard(mat.get_device());
+      Tensor m = mat.contiguous(), rp = rowptr.contiguous(), c = col.contiguous(), r = opt_row.value().contiguous();
+      OptTensor vc = has_value ? OptTensor(value.contiguous()) : std::nullopt;
+      const int64_t M = rp.numel() - 1, E = c.numel(), N = m.size(-2), K = m.size(-1);
+      const int64_t B = (N * K) > 0 ? m.numel() / (N * K) : 1;
+      const int dt = dtype_code(m), red = is_max ? TSAMD_MAX : TSAMD_MIN;
+      if (has_value) TORCH_CHECK(value.dim() == 1 && value.size(0) == E, "Input mismatch");
+      auto sizes = m.sizes().vec();
+      sizes[m.dim() - 2] = M;
+      out = torch::empty(sizes, m.options().requires_grad(false));
+      records = torch::empty({(int64_t)(tsamd_spmm_minmax_records_bytes(B, K, E) / 4)}, rp.options().dtype(at::kInt));
+      Tensor ws = workspace(tsamd_spmm_minmax_records_workspace_bytes(dt, red, B, M, N, K, E), m);
+      check_status(tsamd_spmm_minmax_records(dt, red, rp.data_ptr<int64_t>(), c.data_ptr<int64_t>(), ptr_or_null(vc),
+                                             m.data_ptr(), out.data_ptr(), r.data_ptr<int64_t>(),
+                                             reinterpret_cast<uint32_t *>(records.data_ptr<int32_t>()), B, M, N, K, E,
+                                             ws.data_ptr(), (size_t)ws.numel(), current_stream(m)),
+                   "tsamd_spmm_minmax_records");
+      arg_out = records;  // (what this mode returns in the ids' place: the caller asked not to see them)
+    } else {
+      auto res = spmm_fw_cached(rowptr, col, v, mat, is_max ? "max" : "min", arg32);
+      out = std::get<0>(res);
+      arg_out = std::get<1>(res).value();
+    }
     if (has_csc) {
       check_index(opt_colptr.value(), "colptr");
       check_index(opt_csr2csc.value(), "csr2csc");
@@ -498,6 +545,7 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
     }
     ctx->saved_data["has_value"] = has_value;
     ctx->saved_data["has_csc"] = has_csc;
+    ctx->saved_data["records"] = use_records;
     // the reference saves {col, value, mat, arg_out} (spmm.cpp:199); rowptr is kept as well so that
     // grad_value can be accumulated row by row (tsamd.h)
     ctx->save_for_backward({col, value, mat, arg_out, rowptr, opt_colptr.value_or(col),
@@ -531,6 +579,20 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
       // for deterministic algorithms again and sent the with-values case down the scatter route although the
       // front-end had built the CSC arrays for it).
       const bool pull = has_csc && want_mat;
+      if (ctx->saved_data["records"].toBool()) {  // the forward left the pull's winner records (see forward)
+        Tensor colptr = s[5].contiguous(), csr2csc = s[6].contiguous(), row = s[7].contiguous();
+        if (!want_mat) grad_mat = torch::empty_like(mat, mat.options().requires_grad(false));  // (the entry needs it)
+        Tensor ws = workspace(tsamd_spmm_minmax_bw_csc_records_workspace_bytes(dt, B, M, N, K, E), mat);
+        check_status(tsamd_spmm_minmax_bw_csc_records(
+                         dt, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(), has_value ? 1 : 0, mat.data_ptr(),
+                         grad_out.data_ptr(), reinterpret_cast<const uint32_t *>(arg_out.data_ptr<int32_t>()),
+                         colptr.data_ptr<int64_t>(), csr2csc.data_ptr<int64_t>(), row.data_ptr<int64_t>(),
+                         want_value ? grad_value.data_ptr() : nullptr, grad_mat.data_ptr(), B, M, N, K, E, ws.data_ptr(),
+                         (size_t)ws.numel(), current_stream(mat)),
+                     "tsamd_spmm_minmax_bw_csc_records");
+        if (!want_mat) grad_mat = Tensor();
+        return {Tensor(), Tensor(), grad_value, grad_mat, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+      }
       if (pull && arg_out.scalar_type() == at::kInt) {  // the winners were kept as 32-bit ids (forward, arg32)
         Tensor colptr = s[5].contiguous(), csr2csc = s[6].contiguous(), row = s[7].contiguous();
         Tensor ws = workspace(tsamd_spmm_minmax_bw_csc_workspace_bytes(dt, B, M, N, K, E), mat);

@@ -153,6 +153,16 @@ struct Workspace {
   // min / max: the winners are stored as 32-bit entry ids (tsamd_spmm_minmax_arg32: callers that keep them only
   // for their own backward -- half the bytes of the API's int64 arg_out in the forward store and the backward read)
   int arg32;
+  // winner records written by the forward (tsamd_spmm_minmax_records: rows of 97..128 features, 4-byte accumulators,
+  // int32 winners): at the end of every row that lies inside ONE partition the wave writes the 32-byte record (WinRecord
+  // in spmm_internal.h, what minmax_winrec_kernel derives from arg_out) of each of its entries -- the winners are in
+  // registers there.  Rows cut between partitions: every piece gets records without winners from the wave that
+  // holds it, and the fix-up kernel -- it learns the winners -- writes the whole records of a short row again
+  // (<= kFixupRecordMax entries) or enters the winners into the at most K records of a long one that have any.  No ids
+  // are stored anywhere.
+  uint32_t *rec_out;      // [B][E][8] or nullptr
+  const void *rec_value;  // the matrix's values (or nullptr) for the fix-up kernel's records
+  int64_t snap;           // see spmm_partition_kernel
 };
 
 // ---------------------------------------------------------------------------
@@ -295,7 +305,15 @@ __global__ void spmm_partition_kernel(const int64_t *__restrict__ rowptr, int64_
     if (rowptr[mid + 1] <= d - mid - 1) lo = mid + 1;
     else hi = mid;
   }
-  ws.table[p] = Coord{lo, d - lo};
+  int64_t e = d - lo;
+  // record-writing forward (Workspace::rec_out): a split that falls into the first `snap` entries of a row moves back to
+  // the row's start, so that rows of up to `snap` entries are never cut (a cut row's records cost a second pass);
+  // partitions then hold items .. items + snap items.  snap <= items / 2 keeps the table monotonic.
+  if (ws.snap > 0 && lo < M) {
+    const int64_t rs = rowptr[lo];
+    if (e > rs && e - rs <= ws.snap) e = rs;
+  }
+  ws.table[p] = Coord{lo, e};
 }
 
 // ---------------------------------------------------------------------------
@@ -657,7 +675,7 @@ __device__ __forceinline__ void write_row_partial(T *__restrict__ outk, int64_t 
 
 // A32: the ids go out as int32 (tsamd_spmm_minmax_arg32) -- a compile-time variant: as a run-time branch the second
 // packet of ids spilled the fp32 min / max kernel (63 VGPRs at 8 waves per SIMD)
-template <typename T, int VEC, int RED, bool A32 = false>
+template <typename T, int VEC, int RED, bool A32 = false, bool STORE_ARG = true>
 __device__ __forceinline__ void write_row(T *__restrict__ out_base, int64_t *__restrict__ arg_base, uint64_t arg_off,
                                           typename Traits<T>::acc_t (&val)[VEC],
                                           int64_t (&arg)[VEC], int64_t deg, bool mean,
@@ -706,10 +724,10 @@ __device__ __forceinline__ void write_row(T *__restrict__ out_base, int64_t *__r
         o.v[j] = Traits<T>::from_acc(val[j]);
         // no entry beat the init value (NaN-only / +-max inputs): the reference
         // leaves a stale index here; we report E ("no winner").
-        a.v[j] = arg[j] == kNoArg ? E : arg[j];
+        if constexpr (STORE_ARG) a.v[j] = arg[j] == kNoArg ? E : arg[j];
       } else {
         o.v[j] = Traits<T>::from_acc(A(0));
-        a.v[j] = E;
+        if constexpr (STORE_ARG) a.v[j] = E;
       }
     }
     // written once, never re-read here: keep them out of L2 (1.3 GB of arg ids at config-3 size
@@ -718,7 +736,8 @@ __device__ __forceinline__ void write_row(T *__restrict__ out_base, int64_t *__r
     nt_store(outk, o);
 #endif
 #if !defined(TSAMD_EXP_NO_ARG_STORE)
-    if constexpr (a32) {
+    if constexpr (!STORE_ARG) {  // the caller keeps the winners in another form (Workspace::rec_out)
+    } else if constexpr (a32) {
       Pack<int32_t, VEC> an;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) an.v[j] = (int32_t)a.v[j];
@@ -761,17 +780,37 @@ __device__ __forceinline__ void write_carry(void *cval, uint32_t *carg, uint64_t
 #define TSAMD_MINMAX_WAVES 8
 #endif
 // (partial build: the sum's row sink costs 6 SGPRs -- ask for 8 waves there; the min / max sink needs the VGPRs)
-template <int RED, bool SHORT, bool MASKED>
-constexpr int kMinWavesPerEU = kPartial ? ((RED == RED_ADD && !SHORT && !MASKED) ? 8 : 0)
-                                        : ((RED != RED_ADD && !SHORT && !MASKED) ? TSAMD_MINMAX_WAVES : 0);
+// cut rows of at most this many entries get their whole records from the fix-up wave (64 entries per step through an LDS
+// tile); in longer ones it only enters the winners into the records the merge kernel left without any
+#ifndef TSAMD_RECORD_SNAP
+#define TSAMD_RECORD_SNAP 64
+#endif
+#ifndef TSAMD_FIXUP_RECORD_MAX
+#define TSAMD_FIXUP_RECORD_MAX 256
+#endif
+constexpr int64_t kFixupRecordMax = TSAMD_FIXUP_RECORD_MAX;
 
-template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false, bool A32 = false>
-__global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, MASKED>)) void spmm_merge_kernel(
+#ifndef TSAMD_RECORD_WAVES
+#define TSAMD_RECORD_WAVES 7
+#endif
+template <int RED, bool SHORT, bool MASKED, bool REC = false>
+constexpr int kMinWavesPerEU = kPartial ? ((RED == RED_ADD && !SHORT && !MASKED) ? 8 : 0)
+                                        : ((RED != RED_ADD && !SHORT && !MASKED) ? (REC ? TSAMD_RECORD_WAVES : TSAMD_MINMAX_WAVES) : 0);
+
+// REC (with A32): the kernel writes the winner records of the rows it finishes instead of their ids (Workspace::rec_out)
+// -- its own instantiation: as a run-time branch of the A32 kernel the record writer cost that kernel 52 bytes of
+// scratch per lane (it sits at its register limit), here the int64 ids of the row store are gone instead
+template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false, bool A32 = false, bool REC = false>
+__global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, MASKED, REC>)) void spmm_merge_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
     const T *__restrict__ value, const T *__restrict__ mat, T *__restrict__ out,
     int64_t *__restrict__ arg_out, int64_t M, int64_t N, uint32_t K, int64_t E,
     uint32_t ktiles, int lgG, bool mean, Workspace ws) {
   using A = typename Traits<T>::acc_t;
+  // (see Workspace::rec_out) one feature tile, 32 lanes per row: the host asks for records only when 96 < K <= 128
+  constexpr bool kEmitRecords = REC && A32 && RED != RED_ADD && !MASKED && !SHORT && VEC == 4 && sizeof(A) == 4 && !kPartial;
+  static_assert(!REC || kEmitRecords, "record-writing merge kernel: int32 ids, min / max, four-element packets, 4-byte accumulators");
+  __shared__ uint32_t rec_tile_[kEmitRecords ? kWavesPerBlock * kWave * 4 : 1];
   const int lane = (int)(threadIdx.x & 63);
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wib;
@@ -806,6 +845,15 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
 
   // the first row may have been started by an earlier partition
   const bool incoming = r0 < M && e0 > rowptr[r0];
+  // record-writing forward: are the partition's first / last row long ones (blank_records below)?  Asked for HERE: at the
+  // end of the partition the two dependent scalar loads were a round trip on every wave's critical path (+0.09 ms)
+  int rec_long = 0;
+  if constexpr (kEmitRecords) {
+    const int64_t ra = r0 < M ? r0 : M - 1, rb = r1 < M ? r1 : M - 1;
+    const int64_t da = rowptr[ra + 1] - rowptr[ra], db = rowptr[rb + 1] - rowptr[rb];
+    rec_long = (da > kFixupRecordMax ? 1 : 0) | (db > kFixupRecordMax ? 2 : 0);
+    asm volatile("" : "+v"(rec_long));
+  }
 
   // (col, value) windows: [wbase, wbase+64) current, the next one in flight
   int64_t wbase = e0;
@@ -996,6 +1044,24 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
     return true;
   };
 
+  // record-writing forward: the entries [from, to) of a piece of the cut row `rr` get records WITHOUT winners (row id,
+  // value, empty masks); the fix-up kernel, which learns the row's winners, sets them in the few records that have any
+  auto blank_records = [&](int64_t from, int64_t to, int64_t rr) __attribute__((always_inline)) {
+    if constexpr (kEmitRecords) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      if (!(rec_long & (rr == r0 ? 1 : 2))) return;  // a short row: the fix-up wave writes its records whole
+      for (int64_t qb = from + lane; qb < to; qb += kWave) {
+        A wv = A(1);
+        if (has_value) wv = Traits<T>::to_acc(value[qb]);
+        uint32_t wbits;
+        __builtin_memcpy(&wbits, &wv, 4);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)qb) * 8u);
+        dst[0] = u32x4{0u, 0u, 0u, 0u};
+        dst[1] = u32x4{(uint32_t)rr, wbits, 0u, 0u};
+      }
+    }
+  };
+
   // rows (or row pieces) inside the window [wbase, wbase + 64): 0 = window exhausted, 1 = partition done,
   // 2 = a batch of short rows was processed side by side and the windows were re-based (start over)
   auto process_window = [&](const uint32_t c_w, const A w_w, const uint32_t e_w, const uint32_t z_w) __attribute__((always_inline)) -> int {
@@ -1030,13 +1096,54 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
         if (incoming && r == r0) {  // head of a cut row: the fix-up kernel finishes it
           write_carry<T, VEC, RED>(ws.head_val, ws.head_arg, carry_off, val, arg);
         } else {
-          if constexpr (RED != RED_ADD) widen_args();
+          if constexpr (RED != RED_ADD && !kEmitRecords) widen_args();
           const uint64_t o = out_b + out_position(ws, r, M) * K;
           int64_t deg_w = rend - estart;
           if constexpr (kPartial && RED == RED_ADD) {
             if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[r + 1] - ws.deg_rowptr[r];
           }
-          write_row<T, VEC, RED, A32>(out, arg_out, o, val, arg64, deg_w, mean, E, ws);
+          write_row<T, VEC, RED, A32, !kEmitRecords>(out, arg_out, o, val, arg64, deg_w, mean, E, ws);
+        }
+      }
+      if constexpr (kEmitRecords) {
+        if (incoming && r == r0) {
+          blank_records(estart, rend, r);  // the last piece of a cut row: the fix-up kernel enters the winners
+        } else if (estart < rend) {
+          // the row lies inside this partition: its winners are final -- every entry gets its record, 64 entries per step:
+          // the group-0 lanes (they hold the reduced winners of features k0 .. k0 + 3) set their four bits in the LDS
+          // tile of the winning entries, then lane u writes the record of the step's u-th entry
+          uint32_t *tile = rec_tile_ + wib * (kWave * 4);
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          for (int64_t qb = estart; qb < rend; qb += kWave) {
+            const uint32_t nq = (uint32_t)(rend - qb < (int64_t)kWave ? rend - qb : (int64_t)kWave);
+            if ((uint32_t)lane < nq) *reinterpret_cast<u32x4 *>(tile + lane * 4) = u32x4{0u, 0u, 0u, 0u};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (writer) {
+              const uint32_t q0 = (uint32_t)(qb - e0), word = k0 >> 5, sh = k0 & 31u;
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) {
+                const uint32_t rel = arg[j] - q0;  // (kNoArg32 and earlier / later steps' entries fall outside [0, nq))
+                if (arg[j] != kNoArg32 && rel < nq && k0 + (uint32_t)j < K) atomicOr(tile + rel * 4 + word, 1u << (sh + (uint32_t)j));
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane < nq) {
+              const int64_t eid = qb + lane;
+              const u32x4 m = *reinterpret_cast<const u32x4 *>(tile + lane * 4);
+              const uint32_t z = (m.x != 0u ? 1u : 0u) | (m.y != 0u ? 2u : 0u) | (m.z != 0u ? 4u : 0u) | (m.w != 0u ? 8u : 0u);
+              A wv = A(1);
+              if (has_value) wv = Traits<T>::to_acc(value[eid]);
+              uint32_t wbits;
+              __builtin_memcpy(&wbits, &wv, 4);
+              u32x4 *dst = reinterpret_cast<u32x4 *>(ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)eid) * 8u);
+              dst[0] = m;
+              dst[1] = u32x4{(uint32_t)r, wbits, 0u, z};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
         }
       }
       init_acc<T, VEC, RED>(val, arg);
@@ -1063,6 +1170,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
     reduce_groups<A, VEC, RED>(lgG, val, arg);
     if (writer) write_carry<T, VEC, RED>(ws.tail_val, ws.tail_arg, carry_off, val, arg);
     trow = r1;
+    blank_records(estart, e1, r1);
   }
   if (y == 0 && lane == 0) {
     ws.tail_row[p] = trow;
@@ -1082,11 +1190,16 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
 //    row's degree, the head record and the FIRST tail record (a cut row always has one, in q-1) --
 //    is requested at once and waited for once.
 // ---------------------------------------------------------------------------
-template <typename T, int RED, bool A32 = false>
+
+template <typename T, int RED, bool A32 = false, bool REC = false>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
     const int64_t *__restrict__ rowptr, T *__restrict__ out, int64_t *__restrict__ arg_out,
     int64_t M, uint32_t K, int64_t E, bool mean, Workspace ws) {
   using A = typename Traits<T>::acc_t;
+  constexpr bool kEmitRecords = REC && A32 && RED != RED_ADD && sizeof(A) == 4 && !kPartial;
+  static_assert(!REC || kEmitRecords, "record-writing fix-up kernel: int32 ids, min / max, 4-byte accumulators");
+  __shared__ uint32_t rec_tile_[kEmitRecords ? kWavesPerBlock * kWave * 4 : 1];
+  uint32_t rec_rel[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // REC: the row's winners (offsets from its first entry) of features lane, lane + 64
   const int lane = (int)(threadIdx.x & 63);
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t q = (int64_t)blockIdx.x * kWavesPerBlock + wib;
@@ -1215,12 +1328,79 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
       if constexpr (kPartial && RED == RED_ADD) {
         if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[R + 1] - ws.deg_rowptr[R];
       }
-      write_row<T, 1, RED, A32>(out, arg_out, o, val, arg, deg_w, mean, E, ws);
+      if constexpr (kEmitRecords) rec_rel[u] = (arg[0] == kNoArg || deg <= 0) ? 0xFFFFFFFFu : (uint32_t)(arg[0] - rs);
+      write_row<T, 1, RED, A32, !kEmitRecords>(out, arg_out, o, val, arg, deg_w, mean, E, ws);
     }
     kb += (uint32_t)(kCols * kWave);
     if (kb >= K) break;
     fetch(kb);
     pin();
+  }
+  if constexpr (kEmitRecords) {  // (K <= 128: the loop above ran once, rec_rel holds every feature's winner)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (deg > kFixupRecordMax) {
+      // a long row: at most K of its entries win anything.  Every piece of the row already has records without winners
+      // (merge kernel); the wave walks the DISTINCT winners -- the lanes (features) that share one are found by a ballot,
+      // which is that entry's mask -- and rewrites only those records' masks: cost independent of the row's length
+      const bool v0 = (uint32_t)lane < K && rec_rel[0] != 0xFFFFFFFFu, v1 = (uint32_t)(kWave + lane) < K && rec_rel[1] != 0xFFFFFFFFu;
+      unsigned long long todo0 = __ballot(v0), todo1 = __ballot(v1);
+      while ((todo0 | todo1) != 0ull) {
+        // up to 64 distinct winners per round: lane i keeps the i-th one's entry and mask, then all of them store at once
+        uint32_t my_w = 0, my_m0 = 0, my_m1 = 0, my_m2 = 0, my_m3 = 0;
+        int cnt = 0;
+        while ((todo0 | todo1) != 0ull && cnt < kWave) {
+          uint32_t w;
+          if (todo0 != 0ull) w = (uint32_t)__builtin_amdgcn_readlane((int)rec_rel[0], (int)__builtin_ctzll(todo0));
+          else w = (uint32_t)__builtin_amdgcn_readlane((int)rec_rel[1], (int)__builtin_ctzll(todo1));
+          const unsigned long long m0 = __ballot(v0 && rec_rel[0] == w), m1 = __ballot(v1 && rec_rel[1] == w);
+          todo0 &= ~m0;
+          todo1 &= ~m1;
+          const bool me = lane == cnt;
+          my_w = me ? w : my_w;
+          my_m0 = me ? (uint32_t)m0 : my_m0;
+          my_m1 = me ? (uint32_t)(m0 >> 32) : my_m1;
+          my_m2 = me ? (uint32_t)m1 : my_m2;
+          my_m3 = me ? (uint32_t)(m1 >> 32) : my_m3;
+          ++cnt;
+        }
+        if (lane < cnt) {
+          const uint32_t z = (my_m0 != 0u ? 1u : 0u) | (my_m1 != 0u ? 2u : 0u) | (my_m2 != 0u ? 4u : 0u) | (my_m3 != 0u ? 8u : 0u);
+          uint32_t *dst = ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)(rs + (int64_t)my_w)) * 8u;
+          *reinterpret_cast<u32x4 *>(dst) = u32x4{my_m0, my_m1, my_m2, my_m3};
+          dst[7] = z;
+        }
+      }
+      return;
+    }
+    uint32_t *tile = rec_tile_ + wib * (kWave * 4);
+    const T *value = reinterpret_cast<const T *>(ws.rec_value);
+    for (int64_t q0 = 0; q0 < deg; q0 += kWave) {
+      const uint32_t nq = (uint32_t)(deg - q0 < (int64_t)kWave ? deg - q0 : (int64_t)kWave);
+      if ((uint32_t)lane < nq) *reinterpret_cast<u32x4 *>(tile + lane * 4) = u32x4{0u, 0u, 0u, 0u};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < kCols; ++u) {
+        const uint32_t k = (uint32_t)(u * kWave + lane), rel = rec_rel[u] - (uint32_t)q0;
+        if (k < K && rec_rel[u] != 0xFFFFFFFFu && rel < nq) atomicOr(tile + rel * 4 + (k >> 5), 1u << (k & 31u));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if ((uint32_t)lane < nq) {
+        const int64_t eid = rs + q0 + lane;
+        const u32x4 m = *reinterpret_cast<const u32x4 *>(tile + lane * 4);
+        const uint32_t z = (m.x != 0u ? 1u : 0u) | (m.y != 0u ? 2u : 0u) | (m.z != 0u ? 4u : 0u) | (m.w != 0u ? 8u : 0u);
+        A wv = A(1);
+        if (value != nullptr) wv = Traits<T>::to_acc(value[eid]);
+        uint32_t wbits;
+        __builtin_memcpy(&wbits, &wv, 4);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)eid) * 8u);
+        dst[0] = m;
+        dst[1] = u32x4{(uint32_t)R, wbits, 0u, z};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -1337,6 +1517,9 @@ size_t carve(void *base, int dtype, int reduce, int64_t B, int64_t M, int64_t N,
   w.arg_none = 0;
   w.deg_rowptr = nullptr;
   w.arg32 = 0;
+  w.rec_out = nullptr;
+  w.rec_value = nullptr;
+  w.snap = 0;
   w.ohash_bits = 1;
   while (w.ohash_bits < 32 && ((uint64_t)1 << w.ohash_bits) < (uint64_t)(M > 1 ? M : 2)) ++w.ohash_bits;
   w.ohash_shift = w.ohash_bits > 1 ? w.ohash_bits / 2 : 1;
@@ -1424,7 +1607,17 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
       return TSAMD_ERR_UNSUPPORTED;
   } else if (kArg32able && ws.arg32) {
     if constexpr (kArg32able) {
-      if (lgG >= 3)
+      constexpr bool kRecordable = VEC == 4 && sizeof(typename Traits<T>::acc_t) == 4;
+      if (ws.rec_out != nullptr) {
+        if constexpr (kRecordable) {
+          if (lgG != 1 || ktiles != 1) return TSAMD_ERR_UNSUPPORTED;  // (spmm_emits_records: 97..128 features)
+          hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, false, false, true, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                             dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N, (uint32_t)K, E,
+                             ktiles, lgG, mean, ws);
+        } else {
+          return TSAMD_ERR_UNSUPPORTED;
+        }
+      } else if (lgG >= 3)
         hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, true, false, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
                            dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N, (uint32_t)K, E,
                            ktiles, lgG, mean, ws);
@@ -1447,9 +1640,17 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
   if (ev) TSAMD_HIP_TRY(hipEventRecord(ev[2], stream));
   if (ws.P > 1) {
     if (kArg32able && ws.arg32) {
-      if constexpr (kArg32able)
-        hipLaunchKernelGGL((spmm_fixup_kernel<T, RED, true>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
-                           stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+      if constexpr (kArg32able) {
+        constexpr bool kRecordable = VEC == 4 && sizeof(typename Traits<T>::acc_t) == 4;
+        if (ws.rec_out != nullptr) {
+          if constexpr (kRecordable)
+            hipLaunchKernelGGL((spmm_fixup_kernel<T, RED, true, true>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
+                               stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+        } else {
+          hipLaunchKernelGGL((spmm_fixup_kernel<T, RED, true>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
+                             stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+        }
+      }
     } else {
       hipLaunchKernelGGL((spmm_fixup_kernel<T, RED>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
                          stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
@@ -1564,7 +1765,8 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
                       size_t workspace_bytes_given, hipStream_t stream, hipEvent_t *ev,
                       bool relabelled = false, const int64_t *perm = nullptr,
                       const uint32_t *wmask = nullptr, void *cache = nullptr, size_t cache_bytes = 0,
-                      int cache_valid = 0, const PartialOpts *partial = nullptr, bool arg32 = false) {
+                      int cache_valid = 0, const PartialOpts *partial = nullptr, bool arg32 = false,
+                      uint32_t *rec_out = nullptr) {
   if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype_size(dtype) == 0) return TSAMD_ERR_UNSUPPORTED;
@@ -1602,6 +1804,11 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
   if (arg32) {  // E itself ("no winner") must fit a non-negative int32
     if (!minmax || partial != nullptr || E >= (int64_t)1 << 31) return TSAMD_ERR_UNSUPPORTED;
     ws.arg32 = 1;
+    if (rec_out != nullptr) {  // (tsamd_spmm_minmax_records checked the shape: spmm_emits_records)
+      ws.rec_out = rec_out;
+      ws.rec_value = value;
+      ws.snap = TSAMD_RECORD_SNAP < ws.items / 2 ? TSAMD_RECORD_SNAP : ws.items / 2;
+    }
   }
   if (partial != nullptr) {
     if (reduce == TSAMD_MEAN && partial->deg_rowptr == nullptr) return TSAMD_ERR_INVALID;
@@ -1694,6 +1901,62 @@ extern "C" int tsamd_spmm_minmax_arg32(int dtype, int reduce, const int64_t *row
   return spmm_entry(dtype, reduce, rowptr, col, value, mat, out, reinterpret_cast<int64_t *>(arg_out32), B, M, N, K,
                     E, workspace, workspace_bytes_given, reinterpret_cast<hipStream_t>(stream_), nullptr, false,
                     nullptr, nullptr, cache, cache_bytes, cache_valid, nullptr, true);
+}
+
+// min / max whose forward leaves the winner RECORDS of the pull backward instead of the winner ids (include/tsamd.h).
+// The merge kernel writes the records of the rows it finishes by itself (Workspace::rec_out) when the row shape allows
+// it; the rows cut between partitions -- or every row, when it does not -- get theirs from the ids
+// (minmax_winrec_kernel, csrc/spmm_bw.hip), which only live in the workspace.
+static bool spmm_emits_records(int dtype, int64_t B, int64_t M, int64_t K, int64_t E, const void *mat, const void *out) {
+  if (dtype != TSAMD_F32 && dtype != TSAMD_F16 && dtype != TSAMD_BF16) return false;
+  if (K <= 96 || K > 128 || K % 4 != 0 || E >= (int64_t)1 << 31 || M >= (int64_t)1 << 32 || B < 1) return false;
+  const size_t packet = 4 * dtype_size(dtype);  // the four-element packets the record writer's lane layout assumes
+  if (mat != nullptr && (((uintptr_t)mat % packet) != 0 || ((uintptr_t)out % packet) != 0)) return false;
+  return !spmm_reference_order_on();
+}
+
+static size_t records_arg_bytes(int64_t B, int64_t M, int64_t K) { return align_up(sizeof(int32_t) * (size_t)(B * M * K), 256); }
+
+extern "C" int tsamd_spmm_minmax_records_in_forward(int dtype, int64_t B, int64_t M, int64_t K, int64_t E) {
+  return spmm_emits_records(dtype, B, M, K, E, nullptr, nullptr) ? 1 : 0;
+}
+
+extern "C" size_t tsamd_spmm_minmax_records_bytes(int64_t B, int64_t K, int64_t E) {
+  if (B < 0 || K < 0 || E < 0) return 0;
+  return align_up(sizeof(uint32_t) * (size_t)(B * E) * win_record_stride(K), 256);
+}
+
+// (the ids only exist -- in the workspace -- for the shapes whose records the forward does not write itself)
+extern "C" size_t tsamd_spmm_minmax_records_workspace_bytes(int dtype, int reduce, int64_t B, int64_t M, int64_t N,
+                                                            int64_t K, int64_t E) {
+  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
+  return records_arg_bytes(B, M, K) + carve(nullptr, dtype, reduce, B, M, N, K, E, nullptr);
+}
+
+extern "C" int tsamd_spmm_minmax_records(int dtype, int reduce, const int64_t *rowptr, const int64_t *col,
+                                         const void *value, const void *mat, void *out, const int64_t *row,
+                                         uint32_t *records, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E,
+                                         void *workspace, size_t workspace_bytes_given, void *stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (reduce != TSAMD_MIN && reduce != TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
+  if (dtype != TSAMD_F32 && dtype != TSAMD_F64 && dtype != TSAMD_F16 && dtype != TSAMD_BF16) return TSAMD_ERR_UNSUPPORTED;
+  if (B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
+  if (E >= (int64_t)1 << 31 || M >= (int64_t)1 << 32) return TSAMD_ERR_UNSUPPORTED;
+  if (B * M * K == 0) return TSAMD_OK;
+  if (E > 0 && (!records || !row)) return TSAMD_ERR_INVALID;
+  const size_t arg_b = records_arg_bytes(B, M, K);
+  if (!workspace || workspace_bytes_given < tsamd_spmm_minmax_records_workspace_bytes(dtype, reduce, B, M, N, K, E) ||
+      (uintptr_t)workspace % 256 != 0)
+    return TSAMD_ERR_WORKSPACE;
+  char *w = reinterpret_cast<char *>(workspace);
+  int32_t *arg32 = reinterpret_cast<int32_t *>(w);
+  void *inner = w + arg_b;
+  const bool emit = E > 0 && spmm_emits_records(dtype, B, M, K, E, mat, out);
+  int st = spmm_entry(dtype, reduce, rowptr, col, value, mat, out, reinterpret_cast<int64_t *>(arg32), B, M, N, K, E,
+                      inner, workspace_bytes_given - arg_b, stream, nullptr, false, nullptr, nullptr, nullptr, 0, 0,
+                      nullptr, true, emit ? records : nullptr);
+  if (st != TSAMD_OK || E == 0 || emit) return st;
+  return minmax_winrec_from_ids(dtype, row, value, arg32, records, B, M, K, E, stream);
 }
 
 // ---------------------------------------------------------------------------

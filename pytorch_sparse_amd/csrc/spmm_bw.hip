@@ -959,12 +959,18 @@ extern "C" size_t tsamd_spmm_minmax_bw_csc_workspace_bytes(int dtype, int64_t B,
 }
 
 // arg32: arg_any holds int32 ids (tsamd_spmm_minmax_arg32); only the record route reads them in that width
+// records_in: the winner records are there already (tsamd_spmm_minmax_records wrote them in the forward): no ids, the
+// whole workspace belongs to the masked sum; `value` is then only asked for presence
 static int minmax_bw_csc_impl(int dtype, const int64_t *rowptr, const int64_t *col, const void *value,
                               const void *mat, const void *grad_out, const void *arg_any, bool arg32,
                               const int64_t *colptr, const int64_t *csr2csc, const int64_t *row, void *grad_value,
                               void *grad_mat, int64_t B, int64_t M, int64_t N, int64_t K, int64_t E, void *workspace,
-                              size_t workspace_bytes, void *stream_) {
+                              size_t workspace_bytes, void *stream_, const uint32_t *records_in = nullptr) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (records_in != nullptr) {
+    arg_any = records_in;  // (never dereferenced as ids: every id-reading route below returns UNSUPPORTED first)
+    arg32 = true;
+  }
   const int64_t *arg_out = arg32 ? nullptr : reinterpret_cast<const int64_t *>(arg_any);
   if (arg32 && arg_any == nullptr && B * M * K > 0) return TSAMD_ERR_INVALID;
   if (arg32) arg_out = reinterpret_cast<const int64_t *>(arg_any);  // (never dereferenced at this width below)
@@ -1007,18 +1013,19 @@ static int minmax_bw_csc_impl(int dtype, const int64_t *rowptr, const int64_t *c
     if (grad_value && sddmm_ok && E > 0) TSAMD_HIP_TRY(hipMemsetAsync(grad_value, 0, es * (size_t)E, stream));
     return TSAMD_OK;
   }
-  const size_t rec_b = winrec_bytes(B, K, E);
+  const size_t rec_b = records_in != nullptr ? 0 : winrec_bytes(B, K, E);
   const size_t spmm_b = spmm_masked_sum_workspace_bytes(dtype, B, N, M, K, E);
   if (!workspace || workspace_bytes < rec_b + spmm_b || (uintptr_t)workspace % 256 != 0)
     return TSAMD_ERR_WORKSPACE;
-  uint32_t *rec = reinterpret_cast<uint32_t *>(workspace);
+  uint32_t *rec = records_in != nullptr ? const_cast<uint32_t *>(records_in) : reinterpret_cast<uint32_t *>(workspace);
   const uint32_t W = (uint32_t)ceil_div(K, 32), S = win_record_stride(K);
   const unsigned int blocks = (unsigned int)ceil_div(ceil_div(E, kWave), kWavesPerBlock);
   int st = TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
     if constexpr (std::is_integral<scalar_t>::value) {
       return (int)TSAMD_ERR_UNSUPPORTED;
     } else {
-      if (arg32)
+      if (records_in != nullptr) {
+      } else if (arg32)
         hipLaunchKernelGGL((minmax_winrec_kernel<scalar_t, int32_t>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0,
                            stream, row, reinterpret_cast<const scalar_t *>(value),
                            reinterpret_cast<const int32_t *>(arg_any), rec, B, M, (uint32_t)K, E, W, S);
@@ -1059,4 +1066,54 @@ extern "C" int tsamd_spmm_minmax_bw_csc_arg32(int dtype, const int64_t *rowptr, 
   if (E >= (int64_t)1 << 31) return TSAMD_ERR_UNSUPPORTED;
   return minmax_bw_csc_impl(dtype, rowptr, col, value, mat, grad_out, arg_out32, true, colptr, csr2csc, row,
                             grad_value, grad_mat, B, M, N, K, E, workspace, workspace_bytes, stream_);
+}
+
+// ---- the pull backward on records the forward left (tsamd_spmm_minmax_records, include/tsamd.h) ------------------
+namespace tsamd {
+int minmax_winrec_from_ids(int dtype, const int64_t *row, const void *value, const int32_t *arg32, uint32_t *records,
+                           int64_t B, int64_t M, int64_t K, int64_t E, hipStream_t stream) {
+  if (E == 0 || B * M * K == 0) return TSAMD_OK;
+  if (!row || !arg32 || !records) return TSAMD_ERR_INVALID;
+  const uint32_t W = (uint32_t)ceil_div(K, 32), S = win_record_stride(K);
+  const unsigned int blocks = (unsigned int)ceil_div(ceil_div(E, kWave), kWavesPerBlock);
+  return TSAMD_DISPATCH_DTYPE(dtype, [&]() -> int {
+    if constexpr (std::is_integral<scalar_t>::value) {
+      return (int)TSAMD_ERR_UNSUPPORTED;
+    } else {
+      hipLaunchKernelGGL((minmax_winrec_kernel<scalar_t, int32_t>), dim3(blocks), dim3(kWavesPerBlock * kWave), 0, stream,
+                         row, reinterpret_cast<const scalar_t *>(value), arg32, records, B, M, (uint32_t)K, E, W, S);
+      TSAMD_LAUNCH_CHECK();
+      return (int)TSAMD_OK;
+    }
+  });
+}
+}  // namespace tsamd
+
+extern "C" int tsamd_spmm_minmax_winrec(int dtype, const int64_t *row, const void *value, const int32_t *arg_out32,
+                                        uint32_t *records, int64_t B, int64_t M, int64_t K, int64_t E, void *stream_) {
+  if (B < 0 || M < 0 || K < 0 || E < 0) return TSAMD_ERR_INVALID;
+  if (E >= (int64_t)1 << 31 || M >= (int64_t)1 << 32) return TSAMD_ERR_UNSUPPORTED;
+  return tsamd::minmax_winrec_from_ids(dtype, row, value, arg_out32, records, B, M, K, E,
+                                       reinterpret_cast<hipStream_t>(stream_));
+}
+
+extern "C" size_t tsamd_spmm_minmax_bw_csc_records_workspace_bytes(int dtype, int64_t B, int64_t M, int64_t N, int64_t K,
+                                                                   int64_t E) {
+  if (dtype_size(dtype) == 0 || B < 0 || M < 0 || N < 0 || K < 0 || E < 0) return 0;
+  return spmm_masked_sum_workspace_bytes(dtype, B, N, M, K, E);
+}
+
+extern "C" int tsamd_spmm_minmax_bw_csc_records(int dtype, const int64_t *rowptr, const int64_t *col, int has_value,
+                                                const void *mat, const void *grad_out, const uint32_t *records,
+                                                const int64_t *colptr, const int64_t *csr2csc, const int64_t *row,
+                                                void *grad_value, void *grad_mat, int64_t B, int64_t M, int64_t N,
+                                                int64_t K, int64_t E, void *workspace, size_t workspace_bytes,
+                                                void *stream_) {
+  if (!grad_mat) return TSAMD_ERR_UNSUPPORTED;  // (grad_value alone reads ids: tsamd_spmm_minmax_bw)
+  if (E > 0 && B * M * K > 0 && !records) return TSAMD_ERR_INVALID;
+  if (E >= (int64_t)1 << 31) return TSAMD_ERR_UNSUPPORTED;
+  // `value` is only tested for presence on this route (the records carry the values): any non-null pointer will do
+  return minmax_bw_csc_impl(dtype, rowptr, col, has_value ? mat : nullptr, mat, grad_out, records, true, colptr, csr2csc,
+                            row, grad_value, grad_mat, B, M, N, K, E, workspace, workspace_bytes, stream_,
+                            records ? records : reinterpret_cast<const uint32_t *>(mat));
 }

@@ -30,6 +30,10 @@ int spmm_masked_sum(int dtype, const int64_t *rowptr, bool has_value, const int6
                     const uint32_t *records, const void *mat, void *out, int64_t B, int64_t M, int64_t N,
                     int64_t K, int64_t E, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
+// Winner records from int32 winner ids (csrc/spmm_bw.hip: minmax_winrec_kernel); row = COO row ids [E].
+int minmax_winrec_from_ids(int dtype, const int64_t *row, const void *value, const int32_t *arg32, uint32_t *records,
+                           int64_t B, int64_t M, int64_t K, int64_t E, hipStream_t stream);
+
 // Verification mode (csrc/spmm_ref_order.hip): the reference CPU kernel's order of operations, bit-identical results.
 bool spmm_reference_order_on();
 int spmm_reference_order_run(int dtype, int reduce, const int64_t *rowptr, const int64_t *col, const void *value,

@@ -395,6 +395,17 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     bw = lambda: nat.spmm_minmax_bw_csc(rp, c, v, x, g, arg, colptr, perm, row, want_value=has_value, want_mat=True)  # noqa: E731
     bw_ms = gpu_ms(bw, iters=iters)
     gval, gmat = bw()
+    # round 6: the backward as the matmul node runs it -- on the winner records its forward left (tsamd_spmm_minmax_records)
+    out_rec, rec = nat.spmm_minmax_records(rp, c, v, x, 'max', row)
+    bw_rec = lambda: nat.spmm_minmax_bw_csc_records(rp, c, has_value, x, g, rec, colptr, perm, row, want_value=has_value)  # noqa: E731
+    bw_rec_ms = gpu_ms(bw_rec, iters=iters)
+    with operand_cache(False):
+        fw_rec_ms = gpu_ms_stream(lambda: nat.spmm_minmax_records(rp, c, v, x, 'max', row), iters=iters)
+    gval_r, gmat_r = bw_rec()
+    records_same = bool(torch.equal(out_rec.view(torch.int16), out.view(torch.int16)) and
+                        torch.equal(gmat_r.view(torch.int16), gmat.view(torch.int16)) and
+                        (not has_value or torch.equal(gval_r.view(torch.int16), gval.view(torch.int16))))
+    del rec, out_rec, gval_r, gmat_r
     bw_atomic = lambda: nat.spmm_minmax_bw(rp, c, v, x, g, arg, want_value=has_value, want_mat=True)  # noqa: E731
     bw_atomic_ms = gpu_ms(bw_atomic, iters=iters)
     gval_a, gmat_a = bw_atomic()
@@ -441,6 +452,12 @@ def run_c3(dev, has_value, cpu=True, iters=10):
                    E, 'with values' if has_value else 'value-less'),
                dtype='bf16', fw_ms=round(fw_ms, 4), fw_ms_back_to_back=round(fw_b2b, 4), bw_ms=round(bw_ms, 4), gedges_per_s_fw=round(E / fw_ms / 1e6, 3),
                matmul_fw_ms=round(train_fw_ms, 4), matmul_fw_bw_ms=round(train_step_ms, 4),
+               bw_records_ms=round(bw_rec_ms, 4), fw_records_ms_back_to_back=round(fw_rec_ms, 4),
+               roofline_bw_records=dict(bound='hbm', algorithmic_bytes=ba_bw, achieved=round(ba_bw / bw_rec_ms / 1e6, 1),
+                                        peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ba_bw / bw_rec_ms / 1e6 / HBM_PEAK_GBS, 4),
+                                        scope='the pull backward inside SparseTensor.matmul (round 6): the forward left the '
+                                              'winner records (fw_records_ms_back_to_back against fw_ms_back_to_back), the '
+                                              'backward starts at the masked sum'),
                roofline=dict(bound='hbm', algorithmic_bytes=ba_fw, achieved=round(ba_fw / fw_ms / 1e6, 1),
                              peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ba_fw / fw_ms / 1e6 / HBM_PEAK_GBS, 4),
                              scope='forward, whole op', **pmc_traffic('c3_max_fw_bf16_F128', 'spmm_merge_kernel')),
@@ -466,6 +483,7 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     par['grad_mat_autograd_equal_bound'] = float(((xr.grad.double() - exact).abs() / bound).max())
     par['grad_mat_atomic_route_max_err_over_bound'] = float(((gmat_a.double() - exact).abs() / bound).max())
     par['grad_mat_bare_op_autograd_max_err_over_bound'] = float(((xr2.grad.double() - exact).abs() / bound).max())
+    par['grad_records_route_bit_identical_to_ids_route'] = records_same
     par['grad_mat_pull_deterministic'] = deterministic
     par['grad_mat_autograd_bit_identical_to_c_abi'] = same_as_op
     par['matmul_step_int32_ids_bit_identical_to_c_abi'] = train_same
@@ -497,7 +515,7 @@ def run_c3(dev, has_value, cpu=True, iters=10):
     par['ok'] = bool(par.get('arg_out_mismatches', 0) == 0 and par.get('out_bit_mismatches', 0) == 0 and
                      par['grad_mat_max_err_over_bound'] <= 1.0 and par['grad_mat_autograd_equal_bound'] <= 1.0 and
                      par['grad_mat_atomic_route_max_err_over_bound'] <= 1.0 and deterministic and same_as_op and
-                     train_same and
+                     train_same and records_same and
                      par['grad_mat_bare_op_autograd_max_err_over_bound'] <= 1.0 and
                      par.get('grad_value_max_err_over_bound', 0.0) <= 1.0 and
                      par.get('grad_value_autograd_max_err_over_bound', 0.0) <= 1.0)
