@@ -322,8 +322,9 @@ int tsamd_spmm_minmax_bw_csc_arg32(int dtype, const int64_t *rowptr, const int64
  * registers: at the end of every row that one wave finishes by itself it writes the row's records and does not store
  * the ids at all; rows cut between waves get theirs from the ids right behind the forward (a pass that skips every
  * 64-entry chunk without such a row).  Same records bit for bit as tsamd_spmm_minmax_winrec makes from the ids, hence
- * the same gradients bit for bit.  The forward writes records itself for f32 / f16 / bf16 rows of 97..128 features;
- * any other float shape works too (ids to the workspace, then every record from them).
+ * the same gradients bit for bit.  The forward writes records itself for f16 / bf16 rows of 33..256 features and f32 rows
+ * of 65..256 (multiples of 4; 97..128 features -- 32-byte records -- have their own, faster kernel instantiation); any other
+ * float shape works too (ids to the workspace, then every record from them).
  *   tsamd_spmm_minmax_records_bytes        size of `records` ([B][E] records of 8..  32-bit words, see csrc/spmm_internal.h)
  *   tsamd_spmm_minmax_records              out [B, M, K] and records; row [E] = COO row ids; E < 2^31
  *   tsamd_spmm_minmax_winrec               records from int32 ids (what tsamd_spmm_minmax_bw_csc_arg32 does first)

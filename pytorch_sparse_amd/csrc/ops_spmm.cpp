@@ -490,8 +490,8 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
     // over, a gradient w.r.t. mat recorded), the forward leaves the pull's winner RECORDS instead of ids
     // (tsamd_spmm_minmax_records: the merge kernel writes them where the winners sit in registers) and the backward
     // starts at the masked sum: configs[2] forward + backward 2.26 -> 2.15 ms, gradients bit-identical
-    // (profiles/r06_ab_fwd_winrec.md).  Only when the records (32 bytes per entry) are at most twice the ids they replace
-    // (4 bytes per output element) -- they are what the node holds until the backward.
+    // (profiles/r06_ab_fwd_winrec.md).  Only when the records (32 bytes per entry up to 128 features, 48 up to 256) are at
+    // most three times the ids they replace (4 bytes per output element) -- they are what the node holds until the backward.
     Tensor records;
     bool use_records = false;
     // (grad mode is off inside a Function's forward; the front-end hands the CSC arrays over only when it was on)
@@ -505,7 +505,7 @@ class SpmmMinMaxFunction : public torch::autograd::Function<SpmmMinMaxFunction> 
       const int dt = dtype_code(mat);
       const bool value_grad_ok = !(has_value && needs_grad(value)) || (K * (int64_t)mat.element_size()) % 16 == 0;
       use_records = M > 0 && E > 0 && value_grad_ok && tsamd_spmm_minmax_records_in_forward(dt, B, M, K, E) == 1 &&
-                    tsamd_spmm_minmax_records_bytes(B, K, E) <= (size_t)(2 * 4 * B * M * K);
+                    tsamd_spmm_minmax_records_bytes(B, K, E) <= (size_t)(3 * 4 * B * M * K);
     }
     Tensor out, arg_out;
     if (use_records) {

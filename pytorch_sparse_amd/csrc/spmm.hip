@@ -780,6 +780,65 @@ __device__ __forceinline__ void write_carry(void *cval, uint32_t *carg, uint64_t
 #define TSAMD_MINMAX_WAVES 8
 #endif
 // (partial build: the sum's row sink costs 6 SGPRs -- ask for 8 waves there; the min / max sink needs the VGPRs)
+// ---- record-writing forward: the steps the merge and the fix-up kernel share (Workspace::rec_out) ------------------------
+// A wave's LDS tile holds the records of up to 64 consecutive entries of one row exactly as they lie in memory (S words
+// each: W mask words, row id, value, [segment bitmap], padding): cleared, the winners' bits entered by `ds_or`, completed
+// by the entry's own lane, then copied out as one contiguous block in 16-byte packets.
+constexpr int kRecTileWords = kWave * 12;  // K <= 256: records of at most 12 words
+
+__device__ __forceinline__ void records_clear(uint32_t *tile, int lane, uint32_t nq, uint32_t S) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  for (uint32_t w = (uint32_t)lane * 4u; w < nq * S; w += (uint32_t)kWave * 4u)
+    *reinterpret_cast<u32x4 *>(tile + w) = u32x4{0u, 0u, 0u, 0u};
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// entries first .. first + nq - 1 (ids inside the matrix) of row r; rec_b = the batch's records
+template <typename T>
+__device__ __forceinline__ void records_finish(uint32_t *tile, int lane, uint32_t nq, int64_t first, uint32_t r,
+                                               const T *value, uint32_t *rec_b, uint32_t W, uint32_t S, bool has_z) {
+  using A = typename Traits<T>::acc_t;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if ((uint32_t)lane < nq) {
+    uint32_t *slot = tile + (uint32_t)lane * S;
+    // (words past W are still zero here: the slot was cleared and only mask words have been set)
+    const u32x4 m0 = *reinterpret_cast<const u32x4 *>(slot);
+    const u32x4 m1 = W > 4u ? *reinterpret_cast<const u32x4 *>(slot + 4) : u32x4{0u, 0u, 0u, 0u};
+    const uint32_t z = (m0.x != 0u ? 1u : 0u) | (m0.y != 0u ? 2u : 0u) | (m0.z != 0u ? 4u : 0u) | (m0.w != 0u ? 8u : 0u) |
+                       (m1.x != 0u ? 16u : 0u) | (m1.y != 0u ? 32u : 0u) | (m1.z != 0u ? 64u : 0u) | (m1.w != 0u ? 128u : 0u);
+    A wv = A(1);
+    if (value != nullptr) wv = Traits<T>::to_acc(value[first + lane]);
+    uint32_t wbits;
+    __builtin_memcpy(&wbits, &wv, 4);
+    slot[W] = r;
+    slot[W + 1u] = wbits;
+    if (has_z) slot[W + 3u] = z;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  u32x4 *dst = reinterpret_cast<u32x4 *>(rec_b + (uint64_t)first * S);
+  const uint32_t npk = nq * S / 4u;
+  for (uint32_t pk = (uint32_t)lane; pk < npk; pk += (uint32_t)kWave) dst[pk] = *reinterpret_cast<const u32x4 *>(tile + pk * 4u);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// a record without winners (pieces of long cut rows): S / 4 packets, the row id and the value in their places
+__device__ __forceinline__ void record_blank(uint32_t *dst, uint32_t r, uint32_t wbits, uint32_t W, uint32_t S) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  for (uint32_t j = 0; j < S; j += 4u) {
+    u32x4 pk;
+    pk.x = j == W ? r : (j == W + 1u ? wbits : 0u);
+    pk.y = j + 1u == W ? r : (j == W ? wbits : 0u);
+    pk.z = j + 2u == W ? r : (j + 1u == W ? wbits : 0u);
+    pk.w = j + 3u == W ? r : (j + 2u == W ? wbits : 0u);
+    *reinterpret_cast<u32x4 *>(dst + j) = pk;
+  }
+}
+
 // cut rows of at most this many entries get their whole records from the fix-up wave (64 entries per step through an LDS
 // tile); in longer ones it only enters the winners into the records the merge kernel left without any
 #ifndef TSAMD_RECORD_SNAP
@@ -793,24 +852,28 @@ constexpr int64_t kFixupRecordMax = TSAMD_FIXUP_RECORD_MAX;
 #ifndef TSAMD_RECORD_WAVES
 #define TSAMD_RECORD_WAVES 7
 #endif
-template <int RED, bool SHORT, bool MASKED, bool REC = false>
+template <int RED, bool SHORT, bool MASKED, int REC = 0>
 constexpr int kMinWavesPerEU = kPartial ? ((RED == RED_ADD && !SHORT && !MASKED) ? 8 : 0)
-                                        : ((RED != RED_ADD && !SHORT && !MASKED) ? (REC ? TSAMD_RECORD_WAVES : TSAMD_MINMAX_WAVES) : 0);
+                                        : ((RED != RED_ADD && !SHORT && !MASKED) ? (REC == 1 ? TSAMD_RECORD_WAVES : (REC == 2 ? TSAMD_RECORD_WAVES - 1 : TSAMD_MINMAX_WAVES)) : 0);
 
-// REC (with A32): the kernel writes the winner records of the rows it finishes instead of their ids (Workspace::rec_out)
+// REC = 1 | 2 (with A32): the kernel writes the winner records of the rows it finishes instead of their ids
+// (Workspace::rec_out); 1 = the 32-byte records of 97..128 features (one 16-byte mask per entry in the LDS tile, two direct
+// stores per lane), 2 = any record shape up to 256 features (the tile holds whole records, copied out in packets: 0.11 ms
+// slower at 128 features -- more live registers, more LDS traffic -- which is why the common case keeps its own code)
 // -- its own instantiation: as a run-time branch of the A32 kernel the record writer cost that kernel 52 bytes of
 // scratch per lane (it sits at its register limit), here the int64 ids of the row store are gone instead
-template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false, bool A32 = false, bool REC = false>
+template <typename T, int VEC, int RED, bool SHORT, bool MASKED = false, bool A32 = false, int REC = 0>
 __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, MASKED, REC>)) void spmm_merge_kernel(
     const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
     const T *__restrict__ value, const T *__restrict__ mat, T *__restrict__ out,
     int64_t *__restrict__ arg_out, int64_t M, int64_t N, uint32_t K, int64_t E,
     uint32_t ktiles, int lgG, bool mean, Workspace ws) {
   using A = typename Traits<T>::acc_t;
-  // (see Workspace::rec_out) one feature tile, 32 lanes per row: the host asks for records only when 96 < K <= 128
-  constexpr bool kEmitRecords = REC && A32 && RED != RED_ADD && !MASKED && !SHORT && VEC == 4 && sizeof(A) == 4 && !kPartial;
-  static_assert(!REC || kEmitRecords, "record-writing merge kernel: int32 ids, min / max, four-element packets, 4-byte accumulators");
-  __shared__ uint32_t rec_tile_[kEmitRecords ? kWavesPerBlock * kWave * 4 : 1];
+  // (see Workspace::rec_out) one feature tile of four-element packets: the host asks for records only when K <= 256
+  constexpr bool kEmitRecords = REC != 0 && A32 && RED != RED_ADD && !MASKED && !SHORT && VEC == 4 && sizeof(A) == 4 && !kPartial;
+  constexpr bool kRec32 = REC == 1;  // 32-byte records (97..128 features): straight from the tile's 16-byte masks
+  static_assert(REC == 0 || kEmitRecords, "record-writing merge kernel: int32 ids, min / max, four-element packets, 4-byte accumulators");
+  __shared__ alignas(16) uint32_t rec_tile_[REC == 1 ? kWavesPerBlock * kWave * 4 : (REC == 2 ? kWavesPerBlock * kRecTileWords : 4)];
   const int lane = (int)(threadIdx.x & 63);
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t p = (int64_t)blockIdx.x * kWavesPerBlock + wib;
@@ -1050,14 +1113,25 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
     if constexpr (kEmitRecords) {
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       if (!(rec_long & (rr == r0 ? 1 : 2))) return;  // a short row: the fix-up wave writes its records whole
-      for (int64_t qb = from + lane; qb < to; qb += kWave) {
-        A wv = A(1);
-        if (has_value) wv = Traits<T>::to_acc(value[qb]);
-        uint32_t wbits;
-        __builtin_memcpy(&wbits, &wv, 4);
-        u32x4 *dst = reinterpret_cast<u32x4 *>(ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)qb) * 8u);
-        dst[0] = u32x4{0u, 0u, 0u, 0u};
-        dst[1] = u32x4{(uint32_t)rr, wbits, 0u, 0u};
+      if constexpr (kRec32) {
+        for (int64_t qb = from + lane; qb < to; qb += kWave) {
+          A wv = A(1);
+          if (has_value) wv = Traits<T>::to_acc(value[qb]);
+          uint32_t wbits;
+          __builtin_memcpy(&wbits, &wv, 4);
+          u32x4 *dst = reinterpret_cast<u32x4 *>(ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)qb) * 8u);
+          dst[0] = u32x4{0u, 0u, 0u, 0u};
+          dst[1] = u32x4{(uint32_t)rr, wbits, 0u, 0u};
+        }
+      } else {
+        for (int64_t qb = from + lane; qb < to; qb += kWave) {
+          A wv = A(1);
+          if (has_value) wv = Traits<T>::to_acc(value[qb]);
+          uint32_t wbits;
+          __builtin_memcpy(&wbits, &wv, 4);
+          record_blank(ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)qb) * ws.rec_stride, (uint32_t)rr, wbits, ws.rec_meta,
+                       ws.rec_stride);
+        }
       }
     }
   };
@@ -1112,37 +1186,56 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
           // the row lies inside this partition: its winners are final -- every entry gets its record, 64 entries per step:
           // the group-0 lanes (they hold the reduced winners of features k0 .. k0 + 3) set their four bits in the LDS
           // tile of the winning entries, then lane u writes the record of the step's u-th entry
-          uint32_t *tile = rec_tile_ + wib * (kWave * 4);
-          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          for (int64_t qb = estart; qb < rend; qb += kWave) {
-            const uint32_t nq = (uint32_t)(rend - qb < (int64_t)kWave ? rend - qb : (int64_t)kWave);
-            if ((uint32_t)lane < nq) *reinterpret_cast<u32x4 *>(tile + lane * 4) = u32x4{0u, 0u, 0u, 0u};
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (writer) {
-              const uint32_t q0 = (uint32_t)(qb - e0), word = k0 >> 5, sh = k0 & 31u;
-#pragma unroll
-              for (int j = 0; j < VEC; ++j) {
-                const uint32_t rel = arg[j] - q0;  // (kNoArg32 and earlier / later steps' entries fall outside [0, nq))
-                if (arg[j] != kNoArg32 && rel < nq && k0 + (uint32_t)j < K) atomicOr(tile + rel * 4 + word, 1u << (sh + (uint32_t)j));
+          if constexpr (kRec32) {
+            uint32_t *tile = rec_tile_ + wib * (kWave * 4);
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            for (int64_t qb = estart; qb < rend; qb += kWave) {
+              const uint32_t nq = (uint32_t)(rend - qb < (int64_t)kWave ? rend - qb : (int64_t)kWave);
+              if ((uint32_t)lane < nq) *reinterpret_cast<u32x4 *>(tile + lane * 4) = u32x4{0u, 0u, 0u, 0u};
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (writer) {
+                const uint32_t q0 = (uint32_t)(qb - e0), word = k0 >> 5, sh = k0 & 31u;
+  #pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                  const uint32_t rel = arg[j] - q0;  // (kNoArg32 and earlier / later steps' entries fall outside [0, nq))
+                  if (arg[j] != kNoArg32 && rel < nq && k0 + (uint32_t)j < K) atomicOr(tile + rel * 4 + word, 1u << (sh + (uint32_t)j));
+                }
               }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if ((uint32_t)lane < nq) {
+                const int64_t eid = qb + lane;
+                const u32x4 m = *reinterpret_cast<const u32x4 *>(tile + lane * 4);
+                const uint32_t z = (m.x != 0u ? 1u : 0u) | (m.y != 0u ? 2u : 0u) | (m.z != 0u ? 4u : 0u) | (m.w != 0u ? 8u : 0u);
+                A wv = A(1);
+                if (has_value) wv = Traits<T>::to_acc(value[eid]);
+                uint32_t wbits;
+                __builtin_memcpy(&wbits, &wv, 4);
+                u32x4 *dst = reinterpret_cast<u32x4 *>(ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)eid) * 8u);
+                dst[0] = m;
+                dst[1] = u32x4{(uint32_t)r, wbits, 0u, z};
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if ((uint32_t)lane < nq) {
-              const int64_t eid = qb + lane;
-              const u32x4 m = *reinterpret_cast<const u32x4 *>(tile + lane * 4);
-              const uint32_t z = (m.x != 0u ? 1u : 0u) | (m.y != 0u ? 2u : 0u) | (m.z != 0u ? 4u : 0u) | (m.w != 0u ? 8u : 0u);
-              A wv = A(1);
-              if (has_value) wv = Traits<T>::to_acc(value[eid]);
-              uint32_t wbits;
-              __builtin_memcpy(&wbits, &wv, 4);
-              u32x4 *dst = reinterpret_cast<u32x4 *>(ws.rec_out + ((uint64_t)b * (uint64_t)E + (uint64_t)eid) * 8u);
-              dst[0] = m;
-              dst[1] = u32x4{(uint32_t)r, wbits, 0u, z};
+          } else {
+            uint32_t *tile = rec_tile_ + wib * kRecTileWords;
+            const uint32_t W = ws.rec_meta, S = ws.rec_stride;
+            uint32_t *rec_b = ws.rec_out + (uint64_t)b * (uint64_t)E * S;
+            for (int64_t qb = estart; qb < rend; qb += kWave) {
+              const uint32_t nq = (uint32_t)(rend - qb < (int64_t)kWave ? rend - qb : (int64_t)kWave);
+              records_clear(tile, lane, nq, S);
+              if (writer) {
+                const uint32_t q0 = (uint32_t)(qb - e0), word = k0 >> 5, sh = k0 & 31u;
+  #pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                  const uint32_t rel = arg[j] - q0;  // (kNoArg32 and earlier / later steps' entries fall outside [0, nq))
+                  if (arg[j] != kNoArg32 && rel < nq && k0 + (uint32_t)j < K) atomicOr(tile + rel * S + word, 1u << (sh + (uint32_t)j));
+                }
+              }
+              records_finish<T>(tile, lane, nq, qb, (uint32_t)r, has_value ? value : nullptr, rec_b, W, S, ws.rec_has_z != 0);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
           }
         }
       }
@@ -1191,15 +1284,16 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave, (kMinWavesPerEU<RED, SHORT, 
 //    is requested at once and waited for once.
 // ---------------------------------------------------------------------------
 
-template <typename T, int RED, bool A32 = false, bool REC = false>
+template <typename T, int RED, bool A32 = false, int REC = 0>
 __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
     const int64_t *__restrict__ rowptr, T *__restrict__ out, int64_t *__restrict__ arg_out,
     int64_t M, uint32_t K, int64_t E, bool mean, Workspace ws) {
   using A = typename Traits<T>::acc_t;
-  constexpr bool kEmitRecords = REC && A32 && RED != RED_ADD && sizeof(A) == 4 && !kPartial;
-  static_assert(!REC || kEmitRecords, "record-writing fix-up kernel: int32 ids, min / max, 4-byte accumulators");
-  __shared__ uint32_t rec_tile_[kEmitRecords ? kWavesPerBlock * kWave * 4 : 1];
-  uint32_t rec_rel[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // REC: the row's winners (offsets from its first entry) of features lane, lane + 64
+  constexpr bool kEmitRecords = REC != 0 && A32 && RED != RED_ADD && sizeof(A) == 4 && !kPartial;
+  static_assert(REC == 0 || kEmitRecords, "record-writing fix-up kernel: int32 ids, min / max, 4-byte accumulators");
+  __shared__ alignas(16) uint32_t rec_tile_[REC == 1 ? kWavesPerBlock * kWave * 4 : (REC == 2 ? kWavesPerBlock * kRecTileWords : 4)];
+  // REC: the row's winners (offsets from its first entry) of features lane, lane + 64, lane + 128, lane + 192
+  uint32_t rec_rel[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   const int lane = (int)(threadIdx.x & 63);
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t q = (int64_t)blockIdx.x * kWavesPerBlock + wib;
@@ -1328,7 +1422,11 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
       if constexpr (kPartial && RED == RED_ADD) {
         if (mean && ws.deg_rowptr != nullptr) deg_w = ws.deg_rowptr[R + 1] - ws.deg_rowptr[R];
       }
-      if constexpr (kEmitRecords) rec_rel[u] = (arg[0] == kNoArg || deg <= 0) ? 0xFFFFFFFFu : (uint32_t)(arg[0] - rs);
+      if constexpr (kEmitRecords) {
+        const uint32_t rl = (arg[0] == kNoArg || deg <= 0) ? 0xFFFFFFFFu : (uint32_t)(arg[0] - rs);
+        if (kb == 0) rec_rel[u] = rl;
+        else rec_rel[2 + u] = rl;
+      }
       write_row<T, 1, RED, A32, !kEmitRecords>(out, arg_out, o, val, arg, deg_w, mean, E, ws);
     }
     kb += (uint32_t)(kCols * kWave);
@@ -1336,7 +1434,7 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
     fetch(kb);
     pin();
   }
-  if constexpr (kEmitRecords) {  // (K <= 128: the loop above ran once, rec_rel holds every feature's winner)
+  if constexpr (REC == 1) {  // 32-byte records, K <= 128: the loop above ran once, rec_rel[0..1] hold every feature's winner
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     if (deg > kFixupRecordMax) {
       // a long row: at most K of its entries win anything.  Every piece of the row already has records without winners
@@ -1400,6 +1498,68 @@ __global__ __launch_bounds__(kWavesPerBlock *kWave) void spmm_fixup_kernel(
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if constexpr (REC == 2) {  // any record shape, K <= 256: rec_rel holds every feature's winner
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t W = ws.rec_meta, S = ws.rec_stride;
+    uint32_t *rec_b = ws.rec_out + (uint64_t)b * (uint64_t)E * S;
+    if (deg > kFixupRecordMax) {
+      // a long row: at most K of its entries win anything.  Every piece of the row already has records without winners
+      // (merge kernel); the wave walks the DISTINCT winners -- the lanes (features) that share one are found by a ballot,
+      // which is that entry's mask -- and rewrites only those records' masks: cost independent of the row's length
+      bool v[4];
+      unsigned long long todo[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v[c] = (uint32_t)(c * kWave + lane) < K && rec_rel[c] != 0xFFFFFFFFu;
+        todo[c] = __ballot(v[c]);
+      }
+      while ((todo[0] | todo[1] | todo[2] | todo[3]) != 0ull) {
+        // up to 64 distinct winners per round: lane i keeps the i-th one's entry and mask, then all of them store at once
+        uint32_t my_w = 0, my_m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        int cnt = 0;
+        while ((todo[0] | todo[1] | todo[2] | todo[3]) != 0ull && cnt < kWave) {
+          uint32_t w = 0;
+          if (todo[0] != 0ull) w = (uint32_t)__builtin_amdgcn_readlane((int)rec_rel[0], (int)__builtin_ctzll(todo[0]));
+          else if (todo[1] != 0ull) w = (uint32_t)__builtin_amdgcn_readlane((int)rec_rel[1], (int)__builtin_ctzll(todo[1]));
+          else if (todo[2] != 0ull) w = (uint32_t)__builtin_amdgcn_readlane((int)rec_rel[2], (int)__builtin_ctzll(todo[2]));
+          else w = (uint32_t)__builtin_amdgcn_readlane((int)rec_rel[3], (int)__builtin_ctzll(todo[3]));
+          const bool me = lane == cnt;
+          my_w = me ? w : my_w;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const unsigned long long m = __ballot(v[c] && rec_rel[c] == w);
+            todo[c] &= ~m;
+            my_m[2 * c] = me ? (uint32_t)m : my_m[2 * c];
+            my_m[2 * c + 1] = me ? (uint32_t)(m >> 32) : my_m[2 * c + 1];
+          }
+          ++cnt;
+        }
+        if (lane < cnt) {
+          uint32_t z = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z |= my_m[j] != 0u ? (1u << j) : 0u;
+          uint32_t *dst = rec_b + (uint64_t)(rs + (int64_t)my_w) * S;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if ((uint32_t)j < W) dst[j] = my_m[j];
+          if (ws.rec_has_z) dst[W + 3u] = z;
+        }
+      }
+      return;
+    }
+    uint32_t *tile = rec_tile_ + wib * kRecTileWords;
+    for (int64_t q0 = 0; q0 < deg; q0 += kWave) {
+      const uint32_t nq = (uint32_t)(deg - q0 < (int64_t)kWave ? deg - q0 : (int64_t)kWave);
+      records_clear(tile, lane, nq, S);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t k = (uint32_t)(c * kWave + lane), rel = rec_rel[c] - (uint32_t)q0;
+        if (k < K && rec_rel[c] != 0xFFFFFFFFu && rel < nq) atomicOr(tile + rel * S + (k >> 5), 1u << (k & 31u));
+      }
+      records_finish<T>(tile, lane, nq, rs + q0, (uint32_t)R, reinterpret_cast<const T *>(ws.rec_value), rec_b, W, S,
+                        ws.rec_has_z != 0);
     }
   }
 }
@@ -1610,10 +1770,15 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
       constexpr bool kRecordable = VEC == 4 && sizeof(typename Traits<T>::acc_t) == 4;
       if (ws.rec_out != nullptr) {
         if constexpr (kRecordable) {
-          if (lgG != 1 || ktiles != 1) return TSAMD_ERR_UNSUPPORTED;  // (spmm_emits_records: 97..128 features)
-          hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, false, false, true, true>), dim3(gx, (unsigned int)(B * ktiles), 1),
-                             dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N, (uint32_t)K, E,
-                             ktiles, lgG, mean, ws);
+          if (lgG > 2 || ktiles != 1) return TSAMD_ERR_UNSUPPORTED;  // (spmm_emits_records: 33..256 features)
+          if (ws.rec_meta == 4u && ws.rec_stride == 8u)
+            hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, false, false, true, 1>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                               dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N, (uint32_t)K, E,
+                               ktiles, lgG, mean, ws);
+          else
+            hipLaunchKernelGGL((spmm_merge_kernel<T, VEC, RED, false, false, true, 2>), dim3(gx, (unsigned int)(B * ktiles), 1),
+                               dim3(threads), 0, stream, rowptr, col, value, mat, out, arg_out, M, N, (uint32_t)K, E,
+                               ktiles, lgG, mean, ws);
         } else {
           return TSAMD_ERR_UNSUPPORTED;
         }
@@ -1643,9 +1808,14 @@ int launch_spmm(const int64_t *rowptr, const int64_t *col, const T *value, const
       if constexpr (kArg32able) {
         constexpr bool kRecordable = VEC == 4 && sizeof(typename Traits<T>::acc_t) == 4;
         if (ws.rec_out != nullptr) {
-          if constexpr (kRecordable)
-            hipLaunchKernelGGL((spmm_fixup_kernel<T, RED, true, true>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
-                               stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+          if constexpr (kRecordable) {
+            if (ws.rec_meta == 4u && ws.rec_stride == 8u)
+              hipLaunchKernelGGL((spmm_fixup_kernel<T, RED, true, 1>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
+                                 stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+            else
+              hipLaunchKernelGGL((spmm_fixup_kernel<T, RED, true, 2>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
+                                 stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
+          }
         } else {
           hipLaunchKernelGGL((spmm_fixup_kernel<T, RED, true>), dim3(gx, (unsigned int)B, 1), dim3(threads), 0,
                              stream, rowptr, out, arg_out, M, (uint32_t)K, E, mean, ws);
@@ -1807,6 +1977,9 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
     if (rec_out != nullptr) {  // (tsamd_spmm_minmax_records checked the shape: spmm_emits_records)
       ws.rec_out = rec_out;
       ws.rec_value = value;
+      ws.rec_stride = win_record_stride(K);
+      ws.rec_meta = (uint32_t)ceil_div(K, 32);
+      ws.rec_has_z = ((ws.rec_meta + 3u) & 3u) != 0u ? 1 : 0;
       ws.snap = TSAMD_RECORD_SNAP < ws.items / 2 ? TSAMD_RECORD_SNAP : ws.items / 2;
     }
   }
@@ -1909,7 +2082,8 @@ extern "C" int tsamd_spmm_minmax_arg32(int dtype, int reduce, const int64_t *row
 // (minmax_winrec_kernel, csrc/spmm_bw.hip), which only live in the workspace.
 static bool spmm_emits_records(int dtype, int64_t B, int64_t M, int64_t K, int64_t E, const void *mat, const void *out) {
   if (dtype != TSAMD_F32 && dtype != TSAMD_F16 && dtype != TSAMD_BF16) return false;
-  if (K <= 96 || K > 128 || K % 4 != 0 || E >= (int64_t)1 << 31 || M >= (int64_t)1 << 32 || B < 1) return false;
+  if (K <= 32 || K > 256 || K % 4 != 0 || E >= (int64_t)1 << 31 || M >= (int64_t)1 << 32 || B < 1) return false;
+  if (dtype == TSAMD_F32 && K <= 64) return false;  // measured even (profiles/r06_ab_fwd_winrec.md): the ids stay
   const size_t packet = 4 * dtype_size(dtype);  // the four-element packets the record writer's lane layout assumes
   if (mat != nullptr && (((uintptr_t)mat % packet) != 0 || ((uintptr_t)out % packet) != 0)) return false;
   return !spmm_reference_order_on();

@@ -21,6 +21,8 @@ E = c.numel()
 A = ts.SparseTensor(rowptr=rp, col=c, sparse_sizes=(n, n), is_sorted=True, trust_data=True)
 colptr, perm, row = A.storage.colptr(), A.storage.csr2csc(), A.storage.row()
 CASES = ((torch.bfloat16, 128), (torch.float32, 128), (torch.float16, 100))
+if os.environ.get("WIDE"):
+    CASES = ((torch.bfloat16, 256), (torch.bfloat16, 64), (torch.float32, 64), (torch.float32, 256))
 if os.environ.get("ONLY_FIRST"):
     CASES = CASES[:1]
 for dtype, K in CASES:

@@ -44,7 +44,7 @@ def _graphs():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32, torch.float64])
-@pytest.mark.parametrize('K', [128, 100, 96, 64, 132])
+@pytest.mark.parametrize('K', [128, 100, 96, 64, 36, 132, 160, 200, 256, 260])
 def test_records_equal_the_records_of_the_ids(dtype, K):
     for name, rp, c, n in _graphs():
         colptr, perm, row = _csc(rp, c, n)
@@ -94,7 +94,7 @@ def test_which_shapes_the_forward_records_itself():
     L = nat.lib()
     q = lambda dt, K: L.tsamd_spmm_minmax_records_in_forward(nat.dtype_code(dt), ctypes.c_int64(1), ctypes.c_int64(1000),  # noqa: E731
                                                              ctypes.c_int64(K), ctypes.c_int64(20000))
-    assert [q(torch.bfloat16, K) for K in (64, 96, 100, 128, 130, 132, 256)] == [0, 0, 1, 1, 0, 0, 0]
+    assert [q(torch.bfloat16, K) for K in (32, 36, 64, 96, 100, 128, 130, 132, 256, 260)] == [0, 1, 1, 1, 1, 1, 0, 1, 1, 0]
     assert q(torch.float32, 128) == 1 and q(torch.float16, 128) == 1 and q(torch.float64, 128) == 0
     nat.lib().tsamd_spmm_reference_order(1)
     try:
