@@ -103,6 +103,14 @@ if hasattr(nat, 'spmm_minmax_bw_csc'):
     run('c3_max_bw_pull_bf16_F128', lambda: nat.spmm_minmax_bw_csc(rp, c, None, xb, gb, arg, colptr, perm, row,
                                                                     want_value=False, want_mat=True),
         edges=E, algorithmic_bytes=n * 128 * (8 + 2 * 2) + 2 * n * 128 * 2)
+    if hasattr(nat, 'spmm_minmax_records'):
+        # round 6: the forward that leaves the backward's winner records, and the backward that starts on them
+        run('c3_max_fw_records_bf16_F128', lambda: nat.spmm_minmax_records(rp, c, None, xb, 'max', row), edges=E,
+            algorithmic_bytes=balg(E, n, 128, 2, False, True))
+        _, _rec = nat.spmm_minmax_records(rp, c, None, xb, 'max', row)
+        run('c3_max_bw_records_bf16_F128', lambda: nat.spmm_minmax_bw_csc_records(rp, c, False, xb, gb, _rec, colptr, perm, row),
+            edges=E, algorithmic_bytes=n * 128 * (8 + 2 * 2) + 2 * n * 128 * 2)
+        del _rec
     vb = synth.values(E, dtype=torch.bfloat16, device=dev)
     _, argv = nat.spmm(rp, c, vb, xb, 'max')
     run('c3_max_bw_pull_val_bf16_F128', lambda: nat.spmm_minmax_bw_csc(rp, c, vb, xb, gb, argv, colptr, perm, row,
