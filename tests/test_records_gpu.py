@@ -98,7 +98,16 @@ def test_which_shapes_the_forward_records_itself():
     assert q(torch.float32, 128) == 1 and q(torch.float16, 128) == 1 and q(torch.float64, 128) == 0
     nat.lib().tsamd_spmm_reference_order(1)
     try:
-        assert q(torch.bfloat16, 128) == 0  # the verification mode computes ids only
+        assert q(torch.bfloat16, 128) == 0  # the verification mode computes ids only ...
+        # ... and the entry still delivers the records (from those ids)
+        rp, c = synth.rmat_csr(10, 12, seed=2)
+        n = 1 << 10
+        _, _, row = _csc(rp, c, n)
+        x = synth.features(n, 128, seed=2, dtype=torch.bfloat16).to(DEV)
+        out_r, rec = nat.spmm_minmax_records(rp.to(DEV), c.to(DEV), None, x, 'max', row.to(DEV), zero=True)
+        out_a, arg = nat.spmm_minmax_arg32(rp.to(DEV), c.to(DEV), None, x, 'max')
+        assert torch.equal(out_r, out_a)
+        assert torch.equal(rec, _winrec_no_value(row.to(DEV), arg, 128, torch.bfloat16))
     finally:
         nat.lib().tsamd_spmm_reference_order(0)
 
