@@ -842,10 +842,10 @@ __device__ __forceinline__ void record_blank(uint32_t *dst, uint32_t r, uint32_t
 // cut rows of at most this many entries get their whole records from the fix-up wave (64 entries per step through an LDS
 // tile); in longer ones it only enters the winners into the records the merge kernel left without any
 #ifndef TSAMD_RECORD_SNAP
-#define TSAMD_RECORD_SNAP 64
+#define TSAMD_RECORD_SNAP 128
 #endif
 #ifndef TSAMD_FIXUP_RECORD_MAX
-#define TSAMD_FIXUP_RECORD_MAX 256
+#define TSAMD_FIXUP_RECORD_MAX 1024
 #endif
 constexpr int64_t kFixupRecordMax = TSAMD_FIXUP_RECORD_MAX;
 
