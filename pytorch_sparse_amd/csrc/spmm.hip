@@ -1983,6 +1983,11 @@ static int spmm_entry(int dtype, int reduce, const int64_t *rowptr, const int64_
       ws.snap = TSAMD_RECORD_SNAP < ws.items / 2 ? TSAMD_RECORD_SNAP : ws.items / 2;
     }
   }
+  // min / max: partition boundaries snap to row starts (spmm_partition_kernel) -- fewer cut rows, fewer carry records and
+  // fix-up waves: configs[2] forward 1.024-1.029 -> 1.000 ms (bf16), 1.57 -> 1.55 (fp32), same box
+  // (profiles/r06_ab_minmax_snap.jsonl).  The result does not depend on where a row is cut (no rounding in min / max);
+  // sums keep their partition: theirs does, in the last bits.
+  if (minmax && ws.snap == 0) ws.snap = TSAMD_RECORD_SNAP < ws.items / 2 ? TSAMD_RECORD_SNAP : ws.items / 2;
   if (partial != nullptr) {
     if (reduce == TSAMD_MEAN && partial->deg_rowptr == nullptr) return TSAMD_ERR_INVALID;
     ws.partial = 1;
