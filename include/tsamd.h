@@ -648,7 +648,8 @@ int tsamd_set_diag_apply(const int64_t *pos, const int64_t *row, const int64_t *
  * tsamd_relabel_seed / _extend   the same numbering for MULTI-HOP samplers (neighbor_sample_cpu.cpp:23-133,
  *                       135-400: one std::unordered_map per node type that lives across hops and relations):
  *                       slot[M] is set up ONCE per call and node type (_seed: seeds idx[n] hold -(i + 1), *count
- *                       (device) = n, *err (device) = #ids outside [0, M)); every _extend numbers the ids of
+ *                       (device) = n, *err (device) = #ids outside [0, M); a seed listed twice keeps its FIRST position
+ *                       with first_wins = 1 -- the map insert of neighbor_sample_cpu.cpp:31, 195 -- else its last); every _extend numbers the ids of
  *                       nbr[T] that are new (n_id[*count + rank] = id, first-occurrence order), turns their slots
  *                       into -(id + 1), writes local[T] (may be NULL) and adds the number of new nodes to *count --
  *                       all on the device: n_id is a buffer of `capacity` ids (the caller knows *count + T as an
@@ -691,7 +692,7 @@ int tsamd_relabel_apply(const int64_t *idx, int64_t n, const int64_t *nbr, int64
                         const int64_t *slot, const int64_t *rank, int64_t *local, int64_t *n_id,
                         void *stream);
 int tsamd_relabel_seed(const int64_t *idx, int64_t n, int64_t M, int64_t *slot, int64_t *count,
-                       int64_t *err, void *stream);
+                       int64_t *err, int first_wins, void *stream);
 int tsamd_relabel_extend(const int64_t *nbr, int64_t T, int64_t M, int64_t *slot, int64_t *rank,
                          int64_t *count, int64_t *local, int64_t *n_id, int64_t capacity, int64_t *err,
                          void *workspace, size_t workspace_bytes, void *stream);

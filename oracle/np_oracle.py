@@ -173,3 +173,78 @@ def neighbor_sample_all(colptr, row, input_node, num_hops, directed):
         return samples, v, i, pos
     cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)  # noqa: E731
     return samples, cat(rows), cat(cols), cat(edges)
+
+
+def hetero_neighbor_sample_det(node_types, edge_types, colptr, row, inputs, fan, num_hops, directed, node_time=None):
+    """csrc/cpu/neighbor_sample_cpu.cpp:135-430 (hetero_sample) for the draws that are NOT random: fan < 0, or at
+    least as many draws as the node has neighbours ("select all neighbors", :253-293) -- any other node raises.
+    colptr / row: {relation: array} with relation = 'src__rel__dst'; inputs: {node type: ids}; fan: {relation: [k per
+    hop]}; node_time: {node type: times} makes it the temporal sampler (:169-200, 263-280: nodes are (node, root)
+    pairs, a neighbour v counts only if time[v] <= root time of the node it is drawn for; types without times are
+    unconstrained, :119-130).  Sequential dict model, statement by statement: relations in sorted key order per hop
+    (:216-219), frontier slices moved at the end of a hop (:352-361), map INSERT semantics (a seed listed twice keeps
+    its first position, :192-195), the undirected edge list at the end (:366-412).
+    -> (node {type: ids}, row, col, edge {relation: ids})."""
+    temporal = node_time is not None
+    to_edge = {'__'.join(e): e for e in edge_types}
+    samples = {t: [] for t in node_types}          # ids, or (id, root) pairs when temporal
+    to_local = {t: {} for t in node_types}
+    root_time = {t: [] for t in node_types}
+    rows = {r: [] for r in colptr}
+    cols = {r: [] for r in colptr}
+    edges = {r: [] for r in colptr}
+    for t, x in inputs.items():
+        for i, v in enumerate(np.asarray(x, np.int64).tolist()):
+            key = (v, i) if temporal else v
+            samples[t].append(key)
+            to_local[t].setdefault(key, i)
+            if temporal:
+                root_time[t].append(int(node_time[t][v]))
+    slices = {t: (0, len(samples[t])) for t in node_types}
+    for ell in range(num_hops):
+        for rel in sorted(fan):
+            src_t, _, dst_t = to_edge[rel]
+            k = fan[rel][ell]
+            cp, rw = np.asarray(colptr[rel], np.int64), np.asarray(row[rel], np.int64)
+            begin, end = slices[dst_t]
+            for i in range(begin, end):
+                w = samples[dst_t][i][0] if temporal else samples[dst_t][i]
+                root_w = samples[dst_t][i][1] if temporal else -1
+                dst_time = root_time[dst_t][i] if temporal else 0
+                s, e = int(cp[w]), int(cp[w + 1])
+                if e == s:
+                    continue
+                if not (k < 0 or k >= e - s):
+                    raise ValueError('random draw: node %d of %s has %d neighbours, fan-out %d' % (w, dst_t, e - s, k))
+                for off in range(s, e):
+                    v = int(rw[off])
+                    if temporal:
+                        if src_t in node_time and not int(node_time[src_t][v]) <= dst_time:
+                            continue
+                        key = (v, root_w)
+                        if key not in to_local[src_t]:
+                            to_local[src_t][key] = len(samples[src_t])
+                            samples[src_t].append(key)
+                            root_time[src_t].append(dst_time)
+                        cols[rel].append(i), rows[rel].append(to_local[src_t][key]), edges[rel].append(off)
+                    else:
+                        if v not in to_local[src_t]:
+                            to_local[src_t][v] = len(samples[src_t])
+                            samples[src_t].append(v)
+                        if directed:
+                            cols[rel].append(i), rows[rel].append(to_local[src_t][v]), edges[rel].append(off)
+        slices = {t: (slices[t][1], len(samples[t])) for t in node_types}
+    if not directed:
+        assert not temporal
+        for rel in colptr:
+            src_t, _, dst_t = to_edge[rel]
+            cp, rw = np.asarray(colptr[rel], np.int64), np.asarray(row[rel], np.int64)
+            for i, w in enumerate(samples[dst_t]):
+                for off in range(int(cp[w]), int(cp[w + 1])):
+                    j = to_local[src_t].get(int(rw[off]))
+                    if j is not None:
+                        rows[rel].append(j), cols[rel].append(i), edges[rel].append(off)
+    arr = lambda x: np.asarray(x, np.int64)  # noqa: E731
+    node = {t: arr([p[0] for p in samples[t]] if temporal else samples[t]) for t in node_types}
+    return node, {r: arr(v) for r, v in rows.items()}, {r: arr(v) for r, v in cols.items()}, {r: arr(v) for r, v in edges.items()}
+

@@ -173,14 +173,23 @@ std::tuple<Tensor, Tensor, OptTensor, Tensor> relabel_one_hop(Tensor rowptr, Ten
 // -> (position of the segment in seg_idx, position of the index in map_idx, position of the entry), in
 // seg_idx order and stored order inside a segment.  Two host syncs.  (Homogeneous graphs: seg_idx == map_idx;
 // a relation of a heterogeneous graph: destination nodes select the segments, source nodes the entries.)
+// first_wins: a node listed twice in map_idx keeps its FIRST position (the map insert of the neighbour samplers,
+// neighbor_sample_cpu.cpp:31, 195) instead of its last (the assignment of subgraph_cpu, saint_cpu.cpp:17-18)
 std::tuple<Tensor, Tensor, Tensor> induced_entries_bipartite(Tensor seg_idx, Tensor map_idx, int64_t M_map, Tensor ptr,
-                                                             Tensor ind) {
+                                                             Tensor ind, bool first_wins = false) {
   seg_idx = seg_idx.contiguous();
   map_idx = map_idx.contiguous();
   const int64_t n = map_idx.numel();
   auto iopt = ptr.options().requires_grad(false);
   void *stream = current_stream(ptr);
   Tensor assoc = torch::empty({M_map}, iopt), err = torch::empty({1}, iopt);
+  if (first_wins && n > 1) {  // last position in the reversed list = first position in the list
+    Tensor rev = map_idx.flip(0).contiguous();
+    check_status(tsamd_subset_assoc(rev.data_ptr<int64_t>(), n, M_map, assoc.data_ptr<int64_t>(),
+                                    err.data_ptr<int64_t>(), stream),
+                 "tsamd_subset_assoc");
+    assoc = torch::where(assoc >= 0, (n - 1) - assoc, assoc);
+  } else
   check_status(tsamd_subset_assoc(map_idx.data_ptr<int64_t>(), n, M_map, assoc.data_ptr<int64_t>(),
                                   err.data_ptr<int64_t>(), stream),
                "tsamd_subset_assoc");
@@ -204,8 +213,8 @@ std::tuple<Tensor, Tensor, Tensor> induced_entries_bipartite(Tensor seg_idx, Ten
   return std::make_tuple(seg_out, map_out, pos.index_select(0, src));
 }
 
-std::tuple<Tensor, Tensor, Tensor> induced_entries(Tensor idx, Tensor ptr, Tensor ind) {
-  return induced_entries_bipartite(idx, idx, ptr.numel() - 1, ptr, ind);
+std::tuple<Tensor, Tensor, Tensor> induced_entries(Tensor idx, Tensor ptr, Tensor ind, bool first_wins = false) {
+  return induced_entries_bipartite(idx, idx, ptr.numel() - 1, ptr, ind, first_wins);
 }
 
 // torch_sparse::saint_subgraph(Tensor idx, Tensor rowptr, Tensor row, Tensor col)
@@ -279,6 +288,7 @@ void draw_planned(Drawn &d) {
   void *stream = current_stream(d.colptr);
   d.e = torch::empty({d.T}, iopt);
   d.nbr = torch::empty({d.T}, iopt);
+  if (d.T == 0) return;  // nothing to draw (e.g. a relation without entries: its `row` has no storage to pass on)
   if (d.k < 0)
     check_status(tsamd_select_fill(d.colptr.data_ptr<int64_t>(), M, d.row.data_ptr<int64_t>(), d.frontier.data_ptr<int64_t>(),
                                    d.F, d.out_ptr.data_ptr<int64_t>(), d.T, nullptr, d.nbr.data_ptr<int64_t>(),
@@ -318,7 +328,7 @@ struct NodeList {
     slot = torch::empty({M}, iopt);
     state = torch::empty({2}, iopt);
     check_status(tsamd_relabel_seed(buf.data_ptr<int64_t>(), n, M, slot.data_ptr<int64_t>(), state.data_ptr<int64_t>(),
-                                    state.data_ptr<int64_t>() + 1, current_stream(buf)),
+                                    state.data_ptr<int64_t>() + 1, /*first_wins=*/1, current_stream(buf)),
                  "tsamd_relabel_seed");
     seeded = true;
   }
@@ -420,7 +430,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> neighbor_sample(const Tensor &colptr_
   }
   Tensor samples = list.nodes();
   if (!directed) {
-    auto sub = induced_entries(samples, colptr, row);
+    auto sub = induced_entries(samples, colptr, row, /*first_wins=*/true);
     return std::make_tuple(samples, std::get<1>(sub), std::get<0>(sub), std::get<2>(sub));
   }
   Tensor none = torch::empty({0}, iopt);
@@ -635,7 +645,7 @@ std::tuple<TensorDict, TensorDict, TensorDict, TensorDict> hetero_neighbor_sampl
       const node_t &src_t = std::get<0>(et), &dst_t = std::get<2>(et);
       if (samples.at(dst_t).numel() == 0 || samples.at(src_t).numel() == 0) continue;
       auto sub = induced_entries_bipartite(samples.at(dst_t), samples.at(src_t), hs.num_nodes.at(src_t),
-                                           kv.value().contiguous(), row_dict.at(kv.key()).contiguous());
+                                           kv.value().contiguous(), row_dict.at(kv.key()).contiguous(), /*first_wins=*/true);
       rows[kv.key()].push_back(std::get<1>(sub));
       cols[kv.key()].push_back(std::get<0>(sub));
       edges[kv.key()].push_back(std::get<2>(sub));

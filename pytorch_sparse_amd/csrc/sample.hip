@@ -179,6 +179,18 @@ __global__ void relabel_seed_kernel(const int64_t *__restrict__ idx, int64_t n, 
   atomicMin(reinterpret_cast<long long *>(&slot[v]), (long long)(-(i + 1)));
 }
 
+// seeds listed twice, multi-hop samplers: neighbor_sample_cpu.cpp:31, 195 INSERT the seeds into the map, so the FIRST
+// position keeps the node (relabel_cpu / sample_cpu assign, so the last one does: relabel_seed_kernel).  Runs behind
+// relabel_seed_kernel: every seeded slot is negative by then, the largest -(i + 1) is the first position
+__global__ void relabel_seed_first_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t M,
+                                          int64_t *__restrict__ slot) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = idx[i];
+  if (v < 0 || v >= M) return;
+  atomicMax(reinterpret_cast<long long *>(&slot[v]), (long long)(-(i + 1)));
+}
+
 __global__ void relabel_first_kernel(const int64_t *__restrict__ nbr, int64_t T, int64_t M,
                                      int64_t *__restrict__ slot, unsigned long long *err) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -483,7 +495,7 @@ extern "C" int tsamd_relabel_apply(const int64_t *idx, int64_t n, const int64_t 
 }
 
 extern "C" int tsamd_relabel_seed(const int64_t *idx, int64_t n, int64_t M, int64_t *slot, int64_t *count,
-                                  int64_t *err, void *stream_) {
+                                  int64_t *err, int first_wins, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (n < 0 || M < 0 || !count || !err || (M > 0 && !slot) || (n > 0 && !idx)) return TSAMD_ERR_INVALID;
   hipLaunchKernelGGL(relabel_count_set_kernel, dim3(1), dim3(1), 0, stream, count, n, err);
@@ -493,6 +505,11 @@ extern "C" int tsamd_relabel_seed(const int64_t *idx, int64_t n, int64_t M, int6
     hipLaunchKernelGGL(relabel_seed_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream, idx, n, M,
                        slot, reinterpret_cast<unsigned long long *>(err));
     TSAMD_LAUNCH_CHECK();
+    if (first_wins) {
+      hipLaunchKernelGGL(relabel_seed_first_kernel, dim3((unsigned int)ceil_div(n, 256)), dim3(256), 0, stream, idx, n, M,
+                         slot);
+      TSAMD_LAUNCH_CHECK();
+    }
   }
   return TSAMD_OK;
 }

@@ -212,3 +212,73 @@ def test_host_read_backs_per_hop(ops, temporal):
         assert n_sync <= 1 + hops * (1 + len(RELS)), n_sync
     else:
         assert n_sync <= 1 + 2 * hops, n_sync
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_random_graphs_against_the_sequential_restatement(ops, seed):
+    """Deterministic draws (every neighbour, or more draws than neighbours) on random heterogeneous graphs against
+    oracle/np_oracle.py: hetero_neighbor_sample_det -- the statement-by-statement restatement of hetero_sample that
+    tests/test_oracle.py pins to the compiled reference: input nodes listed twice or three times (first position keeps
+    the node), empty relations, a type without times, directed / undirected / temporal, 1..3 hops."""
+    from oracle import np_oracle as npo
+    rng = np.random.default_rng(100 + seed)
+    sizes = {'paper': int(rng.integers(50, 3000)), 'author': int(rng.integers(20, 1000)), 'venue': int(rng.integers(2, 40))}
+    colptr, row = {}, {}
+    for (s, r, d) in EDGE_TYPES:
+        deg = rng.integers(0, 9, sizes[d])
+        deg[::3] = 0
+        cp = np.zeros(sizes[d] + 1, np.int64)
+        np.cumsum(deg, out=cp[1:])
+        colptr['__'.join((s, r, d))] = cp
+        row['__'.join((s, r, d))] = rng.integers(0, sizes[s], int(cp[-1]))
+    if seed % 2:
+        colptr['venue__hosts__paper'] = np.zeros_like(colptr['venue__hosts__paper'])
+        row['venue__hosts__paper'] = row['venue__hosts__paper'][:0]
+    times = {t: rng.integers(0, 30, sizes[t]) for t in NODE_TYPES}
+    seeds = rng.integers(0, sizes['paper'], 40)
+    seeds[7], seeds[21] = seeds[3], seeds[3]
+    inp = {'paper': seeds, 'author': rng.integers(0, sizes['author'], 5)}
+    D = lambda d: {k: dev(v) for k, v in d.items()}  # noqa: E731
+    for hops in (1, 2, 3):
+        for fanv in (-1, 20):
+            fan = {r: [fanv] * hops for r in RELS}
+            for directed in (True, False):
+                got = ops.hetero_neighbor_sample(NODE_TYPES, EDGE_TYPES, D(colptr), D(row), D(inp), fan, hops, False, directed)
+                want = npo.hetero_neighbor_sample_det(NODE_TYPES, EDGE_TYPES, colptr, row, inp, fan, hops, directed)
+                for t in NODE_TYPES:
+                    np.testing.assert_array_equal(got[0][t].cpu().numpy(), want[0][t], err_msg='node ' + t)
+                for r in RELS:
+                    for k in (1, 2, 3):
+                        np.testing.assert_array_equal(got[k][r].cpu().numpy(), want[k][r], err_msg='%s %d %s %d' % (r, k, directed, hops))
+            tm = {t: v for t, v in times.items() if t != 'venue'} if seed % 2 else times
+            got = ops.hetero_temporal_neighbor_sample(NODE_TYPES, EDGE_TYPES, D(colptr), D(row), D(inp), fan, D(tm), hops, False, True)
+            want = npo.hetero_neighbor_sample_det(NODE_TYPES, EDGE_TYPES, colptr, row, inp, fan, hops, True, tm)
+            for t in NODE_TYPES:
+                np.testing.assert_array_equal(got[0][t].cpu().numpy(), want[0][t], err_msg='temporal node ' + t)
+            for r in RELS:
+                for k in (1, 2, 3):
+                    np.testing.assert_array_equal(got[k][r].cpu().numpy(), want[k][r], err_msg='temporal %s %d %d' % (r, k, hops))
+
+
+def test_homogeneous_neighbor_sample_with_repeated_seeds():
+    """neighbor_sample with a seed listed twice: the first position keeps the node (neighbor_sample_cpu.cpp:31)."""
+    import pytorch_sparse_amd  # noqa: F401
+    from oracle import np_oracle as npo
+    rng = np.random.default_rng(5)
+    n = 400
+    key = np.unique(rng.integers(0, n * n, 3000))
+    order = np.lexsort((key // n, key % n))
+    row, col = (key // n)[order], (key % n)[order]
+    colptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(col, minlength=n), out=colptr[1:])
+    inp = rng.permutation(n)[:30]
+    inp[11], inp[20] = inp[4], inp[4]
+    types, etypes = ['n'], [('n', 'e', 'n')]
+    for hops in (1, 3):
+        for directed in (True, False):
+            got = torch.ops.torch_sparse.neighbor_sample(dev(colptr), dev(row), dev(inp), [-1] * hops, False, directed)
+            want = npo.hetero_neighbor_sample_det(types, etypes, {'n__e__n': colptr}, {'n__e__n': row}, {'n': inp},
+                                                  {'n__e__n': [-1] * hops}, hops, directed)
+            np.testing.assert_array_equal(got[0].cpu().numpy(), want[0]['n'])
+            for k in (1, 2, 3):
+                np.testing.assert_array_equal(got[k].cpu().numpy(), want[k]['n__e__n'], err_msg='%d %s %d' % (k, directed, hops))

@@ -308,3 +308,81 @@ def test_np_neighbor_sample_matches_fixtures_and_compiled_reference():
                                          [-1] * hops, False, directed)
                 for g, w in zip(npo.neighbor_sample_all(colptr, row, inp, hops, directed), want):
                     np.testing.assert_array_equal(g, w.numpy())
+
+
+HET_NODE_TYPES = ['paper', 'author', 'venue']
+HET_EDGE_TYPES = [('author', 'writes', 'paper'), ('paper', 'cites', 'paper'), ('paper', 'in', 'venue'),
+                  ('venue', 'hosts', 'paper'), ('paper', 'by', 'author')]
+HET_RELS = ['__'.join(e) for e in HET_EDGE_TYPES]
+
+
+def _random_hetero(rng, sizes, max_deg):
+    colptr, row = {}, {}
+    for (s, r, d) in HET_EDGE_TYPES:
+        deg = rng.integers(0, max_deg + 1, sizes[d])
+        deg[::4] = 0
+        cp = np.zeros(sizes[d] + 1, np.int64)
+        np.cumsum(deg, out=cp[1:])
+        colptr['__'.join((s, r, d))] = cp
+        row['__'.join((s, r, d))] = rng.integers(0, sizes[s], int(cp[-1]))
+    times = {t: rng.integers(0, 50, sizes[t]) for t in HET_NODE_TYPES}
+    return colptr, row, times
+
+
+def test_np_hetero_sampler_matches_fixtures_and_compiled_reference():
+    """The sequential restatement of hetero_sample (csrc/cpu/neighbor_sample_cpu.cpp:135-430) against the 88 fixtures
+    the compiled reference wrote (make_golden.py part 8) and against the live compiled reference on random graphs --
+    with input nodes listed TWICE (the map insert keeps the first position), relations without entries, a node type
+    without a time tensor."""
+    from oracle import np_oracle as npo
+    paths = sorted(glob.glob(os.path.join(GOLDEN, 'py8_hetero_*.npz')))
+    assert len(paths) == 88
+    for path in paths:
+        z = np.load(path)
+        colptr = {r: z['colptr__' + r] for r in HET_RELS}
+        row = {r: z['row__' + r] for r in HET_RELS}
+        inp = {t: z['input__' + t] for t in HET_NODE_TYPES if 'input__' + t in z.files}
+        times = {t: z['time__' + t] for t in HET_NODE_TYPES if 'time__' + t in z.files}
+        mode, hops, fanv = str(z['mode']), int(z['hops']), int(z['fan'])
+        fan = {r: [fanv] * hops for r in HET_RELS}
+        node, orow, ocol, oedge = npo.hetero_neighbor_sample_det(
+            HET_NODE_TYPES, HET_EDGE_TYPES, colptr, row, inp, fan, hops, mode != 'undirected',
+            times if mode.startswith('temporal') else None)
+        name = os.path.basename(path)
+        for t in HET_NODE_TYPES:
+            np.testing.assert_array_equal(node[t], z['node__' + t], err_msg=name + ':node ' + t)
+        for r in HET_RELS:
+            for got, key in ((orow, 'orow__'), (ocol, 'ocol__'), (oedge, 'oedge__')):
+                np.testing.assert_array_equal(got[r], z[key + r], err_msg=name + ':' + key + r)
+    if not ref.available() or not hasattr(ref.ops(), 'hetero_neighbor_sample'):
+        return
+    r_ops = ref.ops()
+    rng = np.random.default_rng(11)
+    T = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}  # noqa: E731
+    for trial in range(6):
+        sizes = {'paper': 300, 'author': 120, 'venue': 7}
+        colptr, row, times = _random_hetero(rng, sizes, 6)
+        if trial % 2:
+            row['paper__in__venue'] = row['paper__in__venue'][:0]
+            colptr['paper__in__venue'] = np.zeros_like(colptr['paper__in__venue'])
+        seeds = rng.integers(0, sizes['paper'], 25)
+        seeds[5], seeds[9] = seeds[2], seeds[2]  # listed three times
+        inp = {'paper': seeds, 'venue': np.array([3, 3, 1])}
+        for hops in (1, 3):
+            fan = {r: [-1 if trial % 3 else 50] * hops for r in HET_RELS}
+            for directed in (True, False):
+                want = r_ops.hetero_neighbor_sample(HET_NODE_TYPES, HET_EDGE_TYPES, T(colptr), T(row), T(inp), fan, hops, False, directed)
+                got = npo.hetero_neighbor_sample_det(HET_NODE_TYPES, HET_EDGE_TYPES, colptr, row, inp, fan, hops, directed)
+                for t in HET_NODE_TYPES:
+                    np.testing.assert_array_equal(got[0][t], want[0][t].numpy())
+                for rel in HET_RELS:
+                    for k in (1, 2, 3):
+                        np.testing.assert_array_equal(got[k][rel], want[k][rel].numpy(), err_msg='%s %d %s' % (rel, k, directed))
+            tm = {t: v for t, v in times.items() if t != 'author'} if trial % 2 else times
+            want = r_ops.hetero_temporal_neighbor_sample(HET_NODE_TYPES, HET_EDGE_TYPES, T(colptr), T(row), T(inp), fan, T(tm), hops, False, True)
+            got = npo.hetero_neighbor_sample_det(HET_NODE_TYPES, HET_EDGE_TYPES, colptr, row, inp, fan, hops, True, tm)
+            for t in HET_NODE_TYPES:
+                np.testing.assert_array_equal(got[0][t], want[0][t].numpy())
+            for rel in HET_RELS:
+                for k in (1, 2, 3):
+                    np.testing.assert_array_equal(got[k][rel], want[k][rel].numpy())

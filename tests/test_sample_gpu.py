@@ -424,7 +424,7 @@ def test_relabel_seed_extend_cabi_matches_a_sequential_map():
     st = nat.stream_ptr(buf.device)
     P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     I = lambda x: ctypes.c_int64(int(x))  # noqa: E731
-    nat.check(L.tsamd_relabel_seed(P(buf), I(seeds.numel()), I(M), P(slot), P(count), P(err), st), 'seed')
+    nat.check(L.tsamd_relabel_seed(P(buf), I(seeds.numel()), I(M), P(slot), P(count), P(err), ctypes.c_int(1), st), 'seed')
     got_local = []
     for d in draws:
         dd = d.to(DEV)
