@@ -70,15 +70,15 @@ _PMC = None
 
 def pmc_traffic(workload, kernel_substr):
     """Counter-measured fabric bytes per call of one kernel (FETCH_SIZE x 2 + WRITE_SIZE, calibrated in
-    profiles/traffic_ns.json) from the committed builder-run profiles -- the newest of profiles/r05_pmc.json / r04_pmc.json /
-    r03_pmc.json that holds the workload AND a kernel of that name -- NOT measured in this run (PMC passes need
+    profiles/traffic_ns.json) from the committed builder-run profiles -- the newest of profiles/r06_pmc.json / r05_pmc.json /
+    r04_pmc.json / r03_pmc.json that holds the workload AND a kernel of that name -- NOT measured in this run (PMC passes need
     rocprofv3).  kernel_substr '*' = every kernel of the workload summed (a sort is build + passes).
     -> dict for a roofline's `traffic` fields, or {} when no file has it."""
     global _PMC
     if _PMC is None:
         import json
         _PMC = []
-        for name in ('r05_pmc.json', 'r04_pmc.json', 'r03_pmc.json'):
+        for name in ('r06_pmc.json', 'r05_pmc.json', 'r04_pmc.json', 'r03_pmc.json'):
             path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', name)
             try:
                 _PMC.append((name, json.load(open(path))))
@@ -801,7 +801,9 @@ def run_construct(dev, cpu=True, iters=5):
                roofline={k: _roof(nbytes[k], ms[k], 'whole call incl. host syncs; bytes = E(16+s) in + E\'(16+s) out '
                                   '(SURVEY 8d; the radix passes are implementation cost)') for k in ms})
     res['ms_total'] = round(sum(ms.values()), 4)
-    res['roofline']['construct'].update(pmc_traffic('sort_coo_7m5', '*'))
+    res['roofline']['construct'].update(pmc_traffic('construct_7m5', '*') or pmc_traffic('sort_coo_7m5', '*'))
+    for k, w in (('coalesce', 'coalesce_7m5'), ('transpose', 'transpose_7m5')):
+        res['roofline'][k].update(pmc_traffic(w, '*'))
     # ---- parity: every index output bit-exact against the numpy restatement, on the host ----
     rn, cn, vn = row.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
     rs, cs, perm = npo.sort_coo(rn, cn, m, n)
