@@ -454,6 +454,18 @@ int tsamd_sort_coalesce(const int64_t *row, const int64_t *col, int64_t E, int64
                         int64_t *col_tmp, int64_t *row_u, int64_t *col_u, int64_t *seg_ptr, int64_t *counts,
                         const void *value, void *value_out, int64_t value_bytes, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* tsamd_sort_coalesce with the reduction of the duplicates' values fused into the bucket sort (round 6) -- the whole
+ * of torch_sparse/coalesce.py:5-25 (storage.py:431-466: `segment_csr(value, ptr, reduce)`) behind ONE read of the
+ * input: `value` is an [E] array of dtype TSAMD_F32 or TSAMD_I32, `reduce` one of TSAMD_SUM .. TSAMD_MAX.  When the
+ * bucket path sorts the input, value_u[p] (capacity E) = REDUCE over the p-th run of equal pairs, taken in sorted
+ * (= stable input) order in the accumulator type of tsamd_segment_reduce -- the same bits -- counts[3] (DEVICE) = 1,
+ * and NEITHER seg_ptr NOR value_out is written.  Otherwise counts[3] = 0 and the call leaves exactly what
+ * tsamd_sort_coalesce leaves (seg_ptr, value_out = the values in sorted order): the caller reduces them with
+ * tsamd_segment_reduce once it has read counts.  counts has FOUR entries here.  Workspace: tsamd_sort_coalesce's. */
+int tsamd_sort_coalesce_reduce(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                               int64_t *row_tmp, int64_t *col_tmp, int64_t *row_u, int64_t *col_u, int64_t *seg_ptr,
+                               int64_t *counts, int dtype, int reduce, const void *value, void *value_out,
+                               void *value_u, void *workspace, size_t workspace_bytes, void *stream);
 size_t tsamd_coalesce_workspace_bytes(int64_t E);
 int tsamd_coalesce_index(const int64_t *row, const int64_t *col, int64_t E,
                          int64_t *row_out, int64_t *col_out, int64_t *seg_ptr,

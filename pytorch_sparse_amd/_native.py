@@ -27,7 +27,7 @@ SYMBOLS = [
     'tsamd_spmm_minmax_bw_workspace_bytes', 'tsamd_spmm_minmax_bw',
     'tsamd_spmm_minmax_bw_csc_workspace_bytes', 'tsamd_spmm_minmax_bw_csc',
     'tsamd_ind2ptr', 'tsamd_ptr2ind',
-    'tsamd_coo_order', 'tsamd_coo_check', 'tsamd_sort_rank_mode', 'tsamd_sort_coalesce_workspace_bytes', 'tsamd_sort_coalesce', 'tsamd_sort_coo_workspace_bytes', 'tsamd_sort_coo', 'tsamd_sort_coo_auto', 'tsamd_sort_coo_probed', 'tsamd_sort_coo_values',
+    'tsamd_coo_order', 'tsamd_coo_check', 'tsamd_sort_rank_mode', 'tsamd_sort_coalesce_workspace_bytes', 'tsamd_sort_coalesce', 'tsamd_sort_coalesce_reduce', 'tsamd_sort_coo_workspace_bytes', 'tsamd_sort_coo', 'tsamd_sort_coo_auto', 'tsamd_sort_coo_probed', 'tsamd_sort_coo_values',
     'tsamd_coalesce_workspace_bytes', 'tsamd_coalesce_index', 'tsamd_segment_reduce',
     'tsamd_segment_reduce_balanced_workspace_bytes', 'tsamd_segment_reduce_balanced',
     'tsamd_exclusive_scan_workspace_bytes', 'tsamd_exclusive_scan_i64',

@@ -13,6 +13,8 @@ from torch import Tensor
 from .segment import segment_reduce
 
 _OPS = ('add', 'sum', 'mean', 'min', 'max')
+_OPCODE = {'add': 0, 'sum': 0, 'mean': 1, 'min': 2, 'max': 3}  # TSAMD_SUM .. TSAMD_MAX (include/tsamd.h)
+_FUSE_REDUCE = True  # (A/B scripts set it to False: tsamd::sort_coalesce + tsamd::segment_reduce, the round-6 mid route)
 
 
 def _rides(value: Optional[Tensor], nnz: int) -> bool:
@@ -63,6 +65,24 @@ def coalesce_rows_cols(row: Tensor, col: Tensor, value: Optional[Tensor], m: int
     if op not in _OPS:
         raise ValueError(op)
     nnz = col.numel()
+    if (_FUSE_REDUCE and nnz > 1 and col.is_cuda and value is not None and _rides(value, nnz) and
+            value.dtype in (torch.float32, torch.int32)):
+        # sort + duplicate compaction + reduction of the duplicates' values in one op (tsamd_sort_coalesce_reduce):
+        # when the bucket sort takes the input, the distinct pairs AND their reduced values are written straight from
+        # its last kernel (no run starts, no sorted copy of the values, no reduction pass); ONE transfer brings back
+        # (#descents, #duplicates, #distinct, reduced-on-the-device flag)
+        index_u, seg_ptr, counts, value_s, value_u = torch.ops.tsamd.sort_coalesce_reduce(row, col, m, n, value,
+                                                                                        _OPCODE[op])
+        descents, _, n_u, fused = counts.tolist()  # the one host sync
+        if n_u == nnz:
+            if descents == 0:  # in order, no duplicates: the caller's own data (as the reference hands it back)
+                return torch.stack([row, col], dim=0), value
+            return index_u, (value_u if fused else value_s)
+        if fused:  # (a prefix of the capacity-nnz buffer; its own storage once half of it would be idle)
+            value = value_u[:n_u] if 2 * n_u >= nnz else value_u[:n_u].clone()
+        else:  # the values came out of the sort in order: a streamed reduction, no gather
+            value = segment_reduce(value_s, None, seg_ptr, n_u, op, balanced=nnz > 8 * max(n_u, 1))
+        return index_u[:, :n_u].contiguous(), value
     if nnz > 1 and col.is_cuda and (value is None or _rides(value, nnz)):
         # sort + duplicate compaction in one op (tsamd_sort_coalesce): when the bucket sort takes the input the distinct
         # pairs are written straight from its last kernel; ONE transfer brings back (#descents, #duplicates, #distinct)

@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void coalesce_compact_kernel(
     const int64_t *__restrict__ row, const int64_t *__restrict__ col, int64_t n, int64_t *__restrict__ row_out,
     int64_t *__restrict__ col_out, int64_t *__restrict__ seg_ptr, int64_t *__restrict__ nnz_out,
     unsigned long long *__restrict__ state /* [1] error, [8 + tile] status */,
-    const unsigned long long *__restrict__ skip /* nullable: non-zero = the outputs are there already (compacting sort) */) {
+    const unsigned long long *__restrict__ skip /* nullable: non-zero = the outputs are there already (compacting sort) */,
+    int64_t *__restrict__ fused_out = nullptr /* nullable: tsamd_sort_coalesce_reduce's counts[3], 0 on this route */) {
   if (skip != nullptr && *skip != 0) return;
+  if (fused_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *fused_out = 0;
   __shared__ unsigned long long s_base;
   __shared__ unsigned int s_cnt[kCompactItems][4];
   const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -623,27 +625,33 @@ extern "C" size_t tsamd_sort_coalesce_workspace_bytes(int64_t E) {
          tsamd_coalesce_workspace_bytes(E);
 }
 
-extern "C" int tsamd_sort_coalesce(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
-                                   int64_t *row_tmp, int64_t *col_tmp, int64_t *row_u, int64_t *col_u, int64_t *seg_ptr,
-                                   int64_t *counts, const void *value, void *value_out, int64_t value_bytes,
-                                   void *workspace, size_t workspace_bytes, void *stream_) {
+namespace {
+// reduce < 0: tsamd_sort_coalesce (counts has 3 entries); else tsamd_sort_coalesce_reduce (4 entries, value_u)
+int sort_coalesce_impl(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                       int64_t *row_tmp, int64_t *col_tmp, int64_t *row_u, int64_t *col_u, int64_t *seg_ptr,
+                       int64_t *counts, const void *value, void *value_out, int64_t value_bytes, void *value_u,
+                       int reduce, int is_float, void *workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (E < 0 || M < 0 || N < 0 || !counts || !seg_ptr) return TSAMD_ERR_INVALID;
   if ((value == nullptr) != (value_out == nullptr)) return TSAMD_ERR_INVALID;
   if (value != nullptr && value_bytes != 4 && value_bytes != 8) return TSAMD_ERR_UNSUPPORTED;
+  const int ncounts = reduce >= 0 ? 4 : 3;
   if (E == 0) {
-    TSAMD_HIP_TRY(hipMemsetAsync(counts, 0, 3 * sizeof(int64_t), stream));
+    TSAMD_HIP_TRY(hipMemsetAsync(counts, 0, ncounts * sizeof(int64_t), stream));
     TSAMD_HIP_TRY(hipMemsetAsync(seg_ptr, 0, sizeof(int64_t), stream));
     return TSAMD_OK;
   }
   if (!row || !col || !row_tmp || !col_tmp || !row_u || !col_u) return TSAMD_ERR_INVALID;
   if (!sort_coo_supported(E, M, N)) return TSAMD_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < tsamd_sort_coalesce_workspace_bytes(E)) return TSAMD_ERR_WORKSPACE;
+  // [status words of the compacting bucket sort | state of the compaction kernel | the sort's workspace]: the two
+  // zero-initialised pieces sit directly in front of the sort's own, so that ONE fill covers all three
   char *wsp = reinterpret_cast<char *>(workspace);
-  void *sort_ws = wsp;
-  unsigned long long *status = reinterpret_cast<unsigned long long *>(wsp + align_up(sort_coo_workspace_bytes(E), 256));
-  void *co_ws = reinterpret_cast<char *>(status) + align_up(sizeof(unsigned long long) * kSortCoalesceStatusWords, 256);
+  unsigned long long *status = reinterpret_cast<unsigned long long *>(wsp);
+  void *co_ws = wsp + align_up(sizeof(unsigned long long) * kSortCoalesceStatusWords, 256);
   const size_t co_bytes = tsamd_coalesce_workspace_bytes(E);
+  const size_t pre_zero = align_up(sizeof(unsigned long long) * kSortCoalesceStatusWords, 256) + co_bytes;
+  void *sort_ws = wsp + pre_zero;
   const unsigned long long *skip = nullptr;
   if (E <= kSmallSortMax && small_sort_coo(row, col, E, M, N, row_tmp, col_tmp, seg_ptr /* perm: scratch, rewritten below */,
                                            counts, true, stream)) {
@@ -652,8 +660,20 @@ extern "C" int tsamd_sort_coalesce(const int64_t *row, const int64_t *col, int64
       int st = tsamd_gather_rows(value, seg_ptr, value_out, E, E, value_bytes, stream_);
       if (st != TSAMD_OK) return st;
     }
+    TSAMD_HIP_TRY(hipMemsetAsync(co_ws, 0, co_bytes, stream));
   } else {
     SortCoalesce co{row_u, col_u, seg_ptr, counts + 2, status};
+    co.pre_zero_bytes = pre_zero;
+#if defined(TSAMD_EXP_COAL_SEPARATE_FILLS)  // A/B builds (scripts/variants.py): a fill per piece, as before
+    co.pre_zero_bytes = 0;
+    TSAMD_HIP_TRY(hipMemsetAsync(co_ws, 0, co_bytes, stream));
+#endif
+    if (reduce >= 0) co.fused_out = counts + 3;
+    if (reduce >= 0 && value != nullptr && value_bytes == 4 && value_u != nullptr) {
+      co.value_u = value_u;
+      co.reduce = reduce;
+      co.is_float = is_float;
+    }
     int st = sort_coo_onesweep(row, col, E, M, N, row_tmp, col_tmp, nullptr, nullptr, true, counts, sort_ws, stream, value,
                                value_out, (int)value_bytes, false, &co);
     if (st != TSAMD_OK) return st;
@@ -661,11 +681,32 @@ extern "C" int tsamd_sort_coalesce(const int64_t *row, const int64_t *col, int64
   }
   // the one-sweep passes (or the one-launch sort) left sorted pairs in row_tmp / col_tmp: compact them -- returns at
   // once when the bucket path wrote the compacted outputs itself
-  TSAMD_HIP_TRY(hipMemsetAsync(co_ws, 0, co_bytes, stream));
   hipLaunchKernelGGL(coalesce_compact_kernel, dim3((unsigned int)ceil_div(E, kCompactTile)), dim3(256), 0, stream, row_tmp,
-                     col_tmp, E, row_u, col_u, seg_ptr, counts + 2, reinterpret_cast<unsigned long long *>(co_ws), skip);
+                     col_tmp, E, row_u, col_u, seg_ptr, counts + 2, reinterpret_cast<unsigned long long *>(co_ws), skip,
+                     reduce >= 0 ? counts + 3 : (int64_t *)nullptr);
   TSAMD_LAUNCH_CHECK();
   return TSAMD_OK;
+}
+}  // namespace
+
+extern "C" int tsamd_sort_coalesce(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                                   int64_t *row_tmp, int64_t *col_tmp, int64_t *row_u, int64_t *col_u, int64_t *seg_ptr,
+                                   int64_t *counts, const void *value, void *value_out, int64_t value_bytes,
+                                   void *workspace, size_t workspace_bytes, void *stream_) {
+  return sort_coalesce_impl(row, col, E, M, N, row_tmp, col_tmp, row_u, col_u, seg_ptr, counts, value, value_out,
+                            value_bytes, nullptr, -1, 1, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int tsamd_sort_coalesce_reduce(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
+                                          int64_t *row_tmp, int64_t *col_tmp, int64_t *row_u, int64_t *col_u,
+                                          int64_t *seg_ptr, int64_t *counts, int dtype, int reduce, const void *value,
+                                          void *value_out, void *value_u, void *workspace, size_t workspace_bytes,
+                                          void *stream_) {
+  if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
+  if (dtype != TSAMD_F32 && dtype != TSAMD_I32) return TSAMD_ERR_UNSUPPORTED;
+  if (value == nullptr || value_out == nullptr || value_u == nullptr) return TSAMD_ERR_INVALID;
+  return sort_coalesce_impl(row, col, E, M, N, row_tmp, col_tmp, row_u, col_u, seg_ptr, counts, value, value_out, 4,
+                            value_u, reduce, dtype == TSAMD_F32 ? 1 : 0, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int tsamd_segment_reduce(int dtype, int reduce, const void *value, const int64_t *perm,

@@ -228,6 +228,46 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sort_coalesce(Tensor row, Tensor col,
   return std::make_tuple(index_u, seg, counts, value_s);
 }
 
+// tsamd_sort_coalesce_reduce: the same with the reduction of the duplicates' values (float32 / int32, 1-D, no
+// gradient; reduce = 0 sum, 1 mean, 2 min, 3 max) fused into the bucket sort -> (index_u[2, E], seg_ptr[E+1],
+// counts[4] = (#descents, #adjacent duplicates, #distinct pairs, 1 = value_u holds the reduced values) on the device,
+// value in sorted order (valid when counts[3] == 0), value_u[E] (valid when counts[3] == 1)).
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sort_coalesce_reduce(Tensor row, Tensor col, int64_t M, int64_t N,
+                                                                      Tensor value, int64_t reduce) {
+  check_index(row, "row");
+  check_index(col, "col");
+  check_gpu(value, "value");
+  TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
+  c10::hip::HIPGuard guard(row.get_device());
+  row = row.contiguous();
+  col = col.contiguous();
+  const int64_t E = row.numel();
+  TORCH_CHECK(value.dim() == 1 && value.size(0) == E &&
+                  (value.scalar_type() == at::kFloat || value.scalar_type() == at::kInt) && !needs_grad(value),
+              "sort_coalesce_reduce: the value must be a 1-D float32 / int32 tensor that needs no gradient");
+  TORCH_CHECK(reduce >= 0 && reduce <= 3, "sort_coalesce_reduce: reduce must be 0 (sum), 1 (mean), 2 (min) or 3 (max)");
+  value = value.contiguous();
+  Tensor index_u = torch::empty({2, E}, row.options());
+  Tensor row_u = index_u.select(0, 0), col_u = index_u.select(0, 1);
+  Tensor row_t = torch::empty({E}, row.options()), col_t = torch::empty({E}, row.options());
+  Tensor seg = torch::empty({E + 1}, row.options()), counts = torch::empty({4}, row.options());
+  Tensor value_s = torch::empty_like(value), value_u = torch::empty_like(value);
+  if (E == 0) {
+    counts.zero_();
+    seg.zero_();
+    return std::make_tuple(index_u, seg, counts, value_s, value_u);
+  }
+  Tensor ws = workspace(tsamd_sort_coalesce_workspace_bytes(E), row);
+  check_status(tsamd_sort_coalesce_reduce(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N,
+                                          row_t.data_ptr<int64_t>(), col_t.data_ptr<int64_t>(), row_u.data_ptr<int64_t>(),
+                                          col_u.data_ptr<int64_t>(), seg.data_ptr<int64_t>(), counts.data_ptr<int64_t>(),
+                                          value.scalar_type() == at::kFloat ? TSAMD_F32 : TSAMD_I32, (int)reduce,
+                                          value.data_ptr(), value_s.data_ptr(), value_u.data_ptr(), ws.data_ptr(),
+                                          (size_t)ws.numel(), current_stream(row)),
+               "tsamd_sort_coalesce_reduce");
+  return std::make_tuple(index_u, seg, counts, value_s, value_u);
+}
+
 // sorted (row, col) -> (row_u[E], col_u[E], seg_ptr[E+1], nnz[1]); only the first nnz (+1)
 // entries are meaningful, nnz lives on the device.
 std::tuple<Tensor, Tensor, Tensor, Tensor> coalesce_index(Tensor row, Tensor col) {
@@ -580,6 +620,7 @@ static auto registry_storage = torch::RegisterOperators()
                            .op("tsamd::sort_rank_mode", &sort_rank_mode)
                            .op("tsamd::coalesce_index", &coalesce_index)
                            .op("tsamd::sort_coalesce", &sort_coalesce)
+                           .op("tsamd::sort_coalesce_reduce", &sort_coalesce_reduce)
                            .op("tsamd::segment_reduce", &segment_reduce)
                            .op("tsamd::spspmm", &spspmm)
                            .op("tsamd::select_segments", &select_segments)

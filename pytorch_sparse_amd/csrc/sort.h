@@ -24,9 +24,21 @@ bool sort_coo_supported(int64_t E, int64_t M, int64_t N);
 //   and their number to co->nnz_out, and row_out / col_out / perm_out stay untouched; otherwise the one-sweep passes
 //   write row_out / col_out (/ perm_out, nullable) as usual and the CALLER compacts them (it can tell on the device:
 //   *sort_fast_flag(workspace, E) != 0 means the compacted outputs are already there).  co->status: nb words of scratch.
+//   Fused reduction (round 6): with a riding 4-byte value (gather_bytes == 4) and co->reduce >= 0 the bucket path also
+//   REDUCES the values of every run -- sequentially in sorted order, in the accumulator type of
+//   segment_reduce_kernel, i.e. the same bits -- into co->value_u (capacity E, entry p = the p-th distinct pair),
+//   writes neither seg_ptr nor the sorted values, and sets *co->fused_out = 1 (the caller zeroes it beforehand).
 struct SortCoalesce {
   int64_t *row_u, *col_u, *seg_ptr, *nnz_out;
   unsigned long long *status;  // [kSortCoalesceStatusWords]
+  void *value_u = nullptr;     // [E] 4-byte elements, or null
+  int64_t *fused_out = nullptr;
+  int reduce = -1;             // -1: no fused reduction; 0 sum, 1 mean, 2 min, 3 max (TSAMD_SUM .. TSAMD_MAX)
+  int is_float = 1;            // 4-byte value type: 1 float32, 0 int32
+  // the caller's zero-initialised state (the status words above, the state of its compaction kernel) lies in the
+  // pre_zero_bytes bytes directly IN FRONT of `workspace`: the sort's first fill covers them too (one fill kernel
+  // instead of three, ~4.5 us each); 0 = the sort zeroes co->status itself
+  size_t pre_zero_bytes = 0;
 };
 constexpr int kSortCoalesceStatusWords = 1 << 14;
 const unsigned long long *sort_fast_flag(void *workspace, int64_t E);

@@ -29,6 +29,8 @@
 #include "common.h"
 #include "sort.h"
 
+#include <type_traits>
+
 #include <atomic>
 #include <mutex>
 
@@ -989,7 +991,41 @@ struct CoalesceOut {
   int64_t *nnz_out;            // [1]
   unsigned long long *status;  // [#buckets], zeroed: [63:62] 1 = own count, 2 = inclusive prefix
   int64_t n_total;
+  // fused reduction of the riding values (VAL launches, reduce >= 0): value_u[p] = REDUCE over the p-th run, in sorted
+  // order, in the accumulator type of segment_reduce_kernel (coalesce.hip) -- neither seg_ptr nor the sorted values
+  // are written then
+  void *value_u;
+  int64_t *fused_out;
+  int reduce;    // -1 none, 0 sum, 1 mean, 2 min, 3 max
+  int is_float;
 };
+
+// REDUCE over sval[j .. j + r) (r >= 1), the bits of segment_reduce_kernel<float / int32_t>
+template <typename A>
+__device__ __forceinline__ unsigned int bk_reduce_run(const unsigned int *sval, int j, int r, int reduce) {
+  A acc;
+  unsigned int bits = sval[j];
+  __builtin_memcpy(&acc, &bits, 4);
+  for (int q = 1; q < r; ++q) {
+    A v;
+    bits = sval[j + q];
+    __builtin_memcpy(&v, &bits, 4);
+    if (reduce == 2) acc = v < acc ? v : acc;
+    else if (reduce == 3) acc = v > acc ? v : acc;
+    else acc += v;
+  }
+  if (reduce == 1) {
+    if constexpr (std::is_integral<A>::value) {  // floor division, as torch_scatter does
+      A q = acc / (A)r;
+      if ((acc % (A)r != 0) && (acc < 0)) --q;
+      acc = q;
+    } else {
+      acc = acc / (A)r;
+    }
+  }
+  __builtin_memcpy(&bits, &acc, 4);
+  return bits;
+}
 
 template <int THREADS, int ITEMS, bool VAL, bool BALLOT, bool COAL = false>
 __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kernel(
@@ -1166,8 +1202,13 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
       B.strip ? (unsigned long long)(blockIdx.x >> (B.bits - B.bits1)) << (L.key_bits - B.bits1) : 0ull;
   if constexpr (COAL) {
     __shared__ unsigned int s_heads[ITEMS][kW];
+    __shared__ unsigned long long s_hbits[VAL ? ITEMS * kW + 1 : 1];  // head flags, bit j = entry j (fused reduction)
     __shared__ unsigned long long s_base;
+    const bool fuse = VAL && Co.reduce >= 0;
     // 1. the exact order in LDS (the finish step moves what it otherwise only re-addresses)
+#if defined(TSAMD_EXP_COAL_NO_EXACT)  // timing experiments (scripts/variants.py): wrong result
+    exact = true;
+#endif
     if (!exact) {
       unsigned long long fw[ITEMS];
       unsigned int fv[VAL ? ITEMS : 1];
@@ -1217,8 +1258,13 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
       if (k * THREADS < n && j < n) h = j == 0 || (sword[j] >> L.idx_bits) != (sword[j - 1] >> L.idx_bits);
       hmask[k] = __ballot(h);
       heads |= (h ? 1u : 0u) << k;
-      if (lane == 0) s_heads[k][w] = (unsigned int)__popcll(hmask[k]);
+      if (lane == 0) {
+        s_heads[k][w] = (unsigned int)__popcll(hmask[k]);
+        if constexpr (VAL) s_hbits[k * kW + w] = hmask[k];  // (entry j = k * THREADS + w * 64 + lane: word j >> 6)
+      }
     }
+    if constexpr (VAL)
+      if (tid == 0) s_hbits[ITEMS * kW] = 0ull;
     __syncthreads();
     unsigned int before_step[ITEMS], total = 0;
 #pragma unroll
@@ -1229,21 +1275,51 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
         total += s_heads[k][ww];
       }
     }
-    // 3. distinct pairs in the buckets before this one: publish, look back (wave 0, 64 buckets per step)
+    // 3. distinct pairs in the buckets before this one: publish, look back
     constexpr unsigned long long kLocal = 1ull << 62, kPrefix = 2ull << 62, kMask = (1ull << 62) - 1ull;
     const int64_t bucket = (int64_t)blockIdx.x;
-    if (w == 0) {
-      unsigned long long *mine = Co.status + bucket;
-      if (lane == 0)
-        __hip_atomic_store(mine, (bucket == 0 ? kPrefix : kLocal) | (unsigned long long)total, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    if (w == 0 && lane == 0)
+      __hip_atomic_store(Co.status + bucket, (bucket == 0 ? kPrefix : kLocal) | (unsigned long long)total, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    // the sorted values do not depend on the look-back: their stores are in flight while wave 0 waits for the
+    // buckets before this one (and the own count is out before them)
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int j = k * THREADS + tid;
+      if (k * THREADS >= n || j >= n) continue;
+      if constexpr (VAL) {
+        if (!fuse) reinterpret_cast<uint32_t *>(gather_dst)[(size_t)start + j] = sval[j];
+      } else if (gather_dst != nullptr) {
+        const unsigned long long e = sword[j] & imask;
+        if (gather_bytes == 4) reinterpret_cast<uint32_t *>(gather_dst)[(size_t)start + j] = reinterpret_cast<const uint32_t *>(gather_src)[e];
+        else reinterpret_cast<uint64_t *>(gather_dst)[(size_t)start + j] = reinterpret_cast<const uint64_t *>(gather_src)[e];
+      }
+    }
+    // look-back over kLbWaves x 64 status words per round trip (wave w reads the 64 buckets behind the 64 * w nearer
+    // ones; shipped: wave 0 alone).  The ~512 workgroups in flight finish their sorts together, so none of them finds
+    // an inclusive prefix nearby: bucket b of a batch spends ~b / 64 dependent round trips here.
+    {
+      // (measured and rejected, profiles/r06_ab_coalesce_fused.md: every wave of the workgroup reading its own 64 words per
+      // round trip -- 146 against 133 us for this kernel at 7.5 M entries: the words are device-scope loads, i.e. fabric
+      // round trips, and eight times as many of them queue behind the stores of the other workgroups)
+#if defined(TSAMD_EXP_COAL_WIDE_LOOKBACK)
+      constexpr int kLbWaves = kW;
+#else
+      constexpr int kLbWaves = 1;
+#endif
+      __shared__ unsigned long long s_lb_sum[kW];
+      __shared__ int s_lb_state[kW];  // 0: the wave's 64 buckets are all "own count"; 1: an inclusive prefix ends the sum here; 2: a bucket is not ready
       unsigned long long before = 0;
       int64_t t = bucket - 1;
+#if defined(TSAMD_EXP_COAL_NO_LOOKBACK)
+      t = -1;
+      before = start;
+#endif
       unsigned int spins = 0;
       while (t >= 0) {
-        const int64_t mt = t - lane;
-        unsigned long long sv = kPrefix;  // lanes past bucket 0 read as "prefix 0"
-        if (mt >= 0) sv = __hip_atomic_load(Co.status + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t mt = t - tid;
+        unsigned long long sv = kPrefix;  // threads past bucket 0 read as "prefix 0"
+        if (mt >= 0 && w < kLbWaves) sv = __hip_atomic_load(Co.status + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long ready = __ballot((sv >> 62) != 0);
         const unsigned long long pref = __ballot((sv >> 62) == 2);
         const int first_gap = ~ready ? __builtin_ctzll(~ready) : 64;
@@ -1251,46 +1327,81 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
         const int take = first_pref < first_gap ? first_pref + 1 : first_gap;
         unsigned long long v = lane < take ? (sv & kMask) : 0ull;
         for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)lane_xor((int64_t)v, off);
-        before += v;
-        if (first_pref < first_gap) break;  // reached an inclusive prefix
-        t -= take;
-        if (take == 0) {
+        if (lane == 0) {
+          s_lb_sum[w] = v;
+          s_lb_state[w] = first_pref < first_gap ? 1 : (first_gap < 64 ? 2 : 0);
+        }
+        __syncthreads();
+        // every thread folds the waves' pieces in order (nearest buckets first) and reaches the same verdict
+        unsigned long long acc = 0;
+        int verdict = 0;
+#pragma unroll
+        for (int ww = 0; ww < kLbWaves; ++ww) {
+          if (verdict == 0) {
+            const int stt = s_lb_state[ww];
+            if (stt != 2) acc += s_lb_sum[ww];
+            verdict = stt;
+          }
+        }
+        __syncthreads();  // (the pieces are rewritten by the next round)
+        if (verdict == 1) {
+          before += acc;
+          break;
+        }
+        if (verdict == 0) {  // THREADS buckets of own counts: further back
+          before += acc;
+          t -= 64 * kLbWaves;
+        } else {  // a bucket in the window has not published yet: read the window again
           if (++spins > kSpinLimit) {  // (see the pass kernel: the dispatch-order assumption does not hold here)
             __builtin_trap();
           }
           __builtin_amdgcn_s_sleep(1);
         }
       }
-      if (lane == 0) {
+      if (tid == 0) {
+        unsigned long long *mine = Co.status + bucket;
         if (bucket > 0)
           __hip_atomic_store(mine, kPrefix | (before + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_base = before;
         if (bucket == (int64_t)gridDim.x - 1) {
           Co.nnz_out[0] = (int64_t)(before + total);
-          Co.seg_ptr[before + total] = Co.n_total;
+          if (Co.fused_out != nullptr) Co.fused_out[0] = fuse ? 1 : 0;
+          if (!fuse) Co.seg_ptr[before + total] = Co.n_total;
         }
       }
     }
     __syncthreads();
-    // 4. the distinct pairs, where their runs start in the sorted order, and the sorted values
+    // 4. the distinct pairs and where their runs start in the sorted order
     const int64_t base = (int64_t)s_base;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       const int j = k * THREADS + tid;
       if (k * THREADS >= n || j >= n) continue;
-      const unsigned long long wd = sword[j];
-      if constexpr (VAL) reinterpret_cast<uint32_t *>(gather_dst)[(size_t)start + j] = sval[j];
-      else if (gather_dst != nullptr) {
-        const unsigned long long e = wd & imask;
-        if (gather_bytes == 4) reinterpret_cast<uint32_t *>(gather_dst)[(size_t)start + j] = reinterpret_cast<const uint32_t *>(gather_src)[e];
-        else reinterpret_cast<uint64_t *>(gather_dst)[(size_t)start + j] = reinterpret_cast<const uint64_t *>(gather_src)[e];
-      }
+#if defined(TSAMD_EXP_COAL_NO_HEAD_STORES)
+      if (((heads >> k) & 1u) && sword[j] == 0x123456789ull) {
+#else
       if ((heads >> k) & 1u) {
+#endif
+        const unsigned long long wd = sword[j];
         const int64_t p = base + before_step[k] + (unsigned int)__popcll(hmask[k] & lt_mask);
         const unsigned long long key = keybase | (wd >> L.idx_bits);
         row_out[p] = (int64_t)(key >> L.col_bits);
         col_out[p] = (int64_t)(key & cmask);
+        if constexpr (VAL) {
+          if (fuse) {
+            // the run ends at the next head (or at the end of the bucket: other buckets hold other keys)
+            int wi = (j + 1) >> 6;
+            unsigned long long bits = s_hbits[wi] & (~0ull << ((j + 1) & 63));
+            while (bits == 0ull && (wi + 1) * 64 < n) bits = s_hbits[++wi];
+            int next = bits ? wi * 64 + __builtin_ctzll(bits) : n;
+            next = next < n ? next : n;
+            const int r = next - j;
+            reinterpret_cast<uint32_t *>(Co.value_u)[p] =
+                Co.is_float ? bk_reduce_run<float>(sval, j, r, Co.reduce) : bk_reduce_run<int32_t>(sval, j, r, Co.reduce);
+            continue;
+          }
+        }
         Co.seg_ptr[p] = (int64_t)start + j;
       }
     }
@@ -1555,8 +1666,10 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
   if (gather_dst != nullptr && (gather_src == nullptr || (gather_bytes != 4 && gather_bytes != 8))) return TSAMD_ERR_INVALID;
   SortWs ws;
   carve_sort(workspace, E, &ws);
+  const size_t pre_zero = co != nullptr ? co->pre_zero_bytes : 0;
+  char *const zero_from = reinterpret_cast<char *>(ws.hdr) - pre_zero;
   if (L.passes == 0 || E == 1) {  // nothing to order (a 1 x 1 matrix: every key is equal)
-    TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, sizeof(unsigned long long) * kHdrWords, stream));  // (kHdrFast = 0 for a caller that asks)
+    TSAMD_HIP_TRY(hipMemsetAsync(zero_from, 0, pre_zero + sizeof(unsigned long long) * kHdrWords, stream));  // (kHdrFast = 0 for a caller that asks)
     if (probe && counts_out != nullptr) {
       const int64_t c[2] = {0, E - 1};  // no descent, every adjacent pair a duplicate
       TSAMD_HIP_TRY(hipMemcpyAsync(counts_out, c, sizeof(c), hipMemcpyHostToDevice, stream));
@@ -1576,7 +1689,7 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
   // a compacting sort needs buckets that end where keys end (the bucket id inside the key bits)
   if (co != nullptr && B.on && !B.strip && B.shift < L.idx_bits) B.on = 0;
   const bool ballot = sort_rank_mode(stream) == 1;
-  TSAMD_HIP_TRY(hipMemsetAsync(ws.hdr, 0, ws.zero_bytes + (B.on ? sizeof(unsigned int) * (size_t)B.nb * kBkHistCopies : 0), stream));
+  TSAMD_HIP_TRY(hipMemsetAsync(zero_from, 0, pre_zero + ws.zero_bytes + (B.on ? sizeof(unsigned int) * (size_t)B.nb * kBkHistCopies : 0), stream));
   int build_wgs = 1;
   {
     const int64_t nb = ceil_div(E, kBuildThreads * 4);
@@ -1617,12 +1730,18 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
       sorted_in = ws.a;
     }
 #undef TSAMD_BK_SCATTER
-    CoalesceOut Co{nullptr, nullptr, nullptr, E};
+    CoalesceOut Co{nullptr, nullptr, nullptr, E, nullptr, nullptr, -1, 1};
     if (co != nullptr) {
-      TSAMD_HIP_TRY(hipMemsetAsync(co->status, 0, sizeof(unsigned long long) * (size_t)B.nb, stream));
+      if (pre_zero == 0) TSAMD_HIP_TRY(hipMemsetAsync(co->status, 0, sizeof(unsigned long long) * (size_t)B.nb, stream));
       Co.seg_ptr = co->seg_ptr;
       Co.nnz_out = co->nnz_out;
       Co.status = co->status;
+      Co.fused_out = co->fused_out;  // (written by the bucket path in any case: 1 = value_u holds the reduced values)
+      if (want4 && co->reduce >= 0 && co->value_u != nullptr && co->fused_out != nullptr) {
+        Co.value_u = co->value_u;
+        Co.reduce = co->reduce;
+        Co.is_float = co->is_float;
+      }
     }
 #define TSAMD_BK_SORT(ITEMS, V, BAL)                                                                                     \
   do {                                                                                                                   \

@@ -14,6 +14,9 @@ from tests.baseline_configs import gpu_ms, wall_ms  # noqa: E402
 
 dev = torch.device('cuda:0')
 ops = torch.ops.tsamd
+if os.environ.get('TSAMD_COALESCE_UNFUSED'):  # A/B: the unfused functional coalesce / transpose
+    import pytorch_sparse_amd.coalesce as _co
+    _co._FUSE_REDUCE = False
 tag = next((a for a in sys.argv[1:] if not a.startswith('--')), 'base')
 cases = [('c4', 500000, 500000, 7500000)]
 if '--big' in sys.argv:

@@ -200,6 +200,64 @@ def test_sort_coalesce_bit_exact(dev, ops, E, m, n, kind, with_value):
         assert np.array_equal(vs8.cpu().numpy(), v8.numpy()[ep])
 
 
+@pytest.mark.parametrize('E,m,n,kind,fused_expected', [
+    (5000, 300, 200, 'uniform', False),          # the one-launch sort
+    (400003, 500000, 500000, 'uniform', True),   # bucket path, runs of 1-2
+    (400003, 700, 900, 'uniform', True),         # bucket path, runs of a few entries (runs across the finish step's groups)
+    (400003, 150, 100, 'uniform', True),         # ... of ~27 entries: the bucket sorts by full LSD passes first
+    (1 << 20, 16, 16, 'uniform', True),          # one bucket per key: runs of 4096 entries
+    (1 << 20, 8, 16, 'uniform', False),          # the bucket id would reach into the position bits: one-sweep + compaction kernel
+    (500000, 1 << 20, 1 << 20, 'hub', False),    # a bucket overflows
+    (3000000, (1 << 21) + 5, (1 << 21) - 3, 'uniform', True),   # stripped keys
+    (300000, 1000, 1000, 'sorted', False),       # already in order
+])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.int32])
+def test_sort_coalesce_reduce_bit_exact(dev, ops, E, m, n, kind, fused_expected, dtype):
+    """tsamd::sort_coalesce_reduce (the duplicates' values reduced inside the bucket sort): the same distinct pairs and
+    counts as tsamd::sort_coalesce, and -- when the device reports the fused route -- reduced values that equal, bit
+    for bit, tsamd::segment_reduce over the sorted values of the unfused op (torch_sparse/storage.py:431-466); both
+    routes against numpy's sequential reduceat."""
+    from pytorch_sparse_amd.segment import segment_reduce
+    g = torch.Generator().manual_seed(E % 977 + 3)
+    row = torch.randint(0, m, (E, ), generator=g)
+    col = torch.randint(0, n, (E, ), generator=g)
+    if kind == 'hub':
+        row[torch.randperm(E, generator=g)[:E // 3]] = 12345
+    q = E // 5
+    row[:q], col[:q] = row[q:2 * q].clone(), col[q:2 * q].clone()
+    if kind == 'sorted':
+        r_, c_, _ = no.sort_coo(row.numpy(), col.numpy(), m, n)
+        row, col = torch.from_numpy(r_.copy()), torch.from_numpy(c_.copy())
+    if dtype == torch.float32:
+        val = torch.randn(E, generator=g)
+    else:
+        val = torch.randint(-1000, 1000, (E, ), generator=g, dtype=torch.int32)
+    rd, cd, vd = row.to(dev), col.to(dev), val.to(dev)
+    index_0, seg_0, counts_0, vs_0 = ops.sort_coalesce(rd, cd, m, n, vd)
+    k = int(counts_0[2])
+    saw_fused = False
+    for code, op in enumerate(('sum', 'mean', 'min', 'max')):
+        index_u, seg, counts, vs, vu = ops.sort_coalesce_reduce(rd, cd, m, n, vd, code)
+        c = counts.tolist()
+        assert c[:3] == counts_0.tolist() and c[3] in (0, 1)
+        assert torch.equal(index_u[:, :k], index_0[:, :k])
+        want = segment_reduce(vs_0, None, seg_0, k, op)
+        if c[3] == 1:
+            saw_fused = True
+            got = vu[:k]
+        else:
+            assert torch.equal(seg[:k + 1], seg_0[:k + 1]) and torch.equal(vs, vs_0)
+            got = segment_reduce(vs, None, seg, k, op)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (op, c)
+        _, _, ev = no.coalesce(row.numpy(), col.numpy(), val.numpy(), m, n, 'add' if op == 'sum' else op)
+        if dtype == torch.int32 or op in ('min', 'max'):
+            assert np.array_equal(got.cpu().numpy(), ev)
+        else:  # fp32 sums in another association than numpy's: 1e-5 of the run's L1 mass
+            _, _, l1 = no.coalesce(row.numpy(), col.numpy(), np.abs(val.numpy()), m, n, 'add' if op == 'sum' else op)
+            assert np.all(np.abs(got.cpu().numpy() - ev) <= 1e-5 * l1 + 1e-30)
+    assert saw_fused == fused_expected, (saw_fused, fused_expected)
+
+
 def test_rank_self_test_and_forced_ballot_ranking(dev, ops):
     """The stable rank of the radix kernels is a returning LDS atomic when the device-side self-test finds the lanes of
     one instruction served in ascending order, ballot matching otherwise.  Both must give the SAME permutation on
