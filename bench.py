@@ -730,7 +730,8 @@ def _main():
             if traffic is None:
                 pmc_why, traffic_source = traffic_source, None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.workload)
-        if traffic is None and os.path.exists(tfile):
+        # (the committed figure is the WHOLE single-GPU workload's: a rank's shard of it at N > 1 moves other bytes)
+        if traffic is None and world == 1 and os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 traffic = tj.get('hbm_bytes_per_launch')
