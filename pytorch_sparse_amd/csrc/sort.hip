@@ -1201,9 +1201,11 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
   const unsigned long long keybase =
       B.strip ? (unsigned long long)(blockIdx.x >> (B.bits - B.bits1)) << (L.key_bits - B.bits1) : 0ull;
   if constexpr (COAL) {
-    __shared__ unsigned int s_heads[ITEMS][kW];
-    __shared__ unsigned long long s_hbits[VAL ? ITEMS * kW + 1 : 1];  // head flags, bit j = entry j (fused reduction)
+    __shared__ unsigned int s_heads[ITEMS * kW];              // heads of (step k, wave w) at [k * kW + w], then their exclusive prefix
+    __shared__ unsigned long long s_hbits[ITEMS * kW + 1];    // head flags, bit j = entry j (word j >> 6 = k * kW + w)
     __shared__ unsigned long long s_base;
+    __shared__ unsigned int s_total;
+    static_assert(ITEMS * kW <= 128, "one wave scans the per-(step, wave) head counts, two per lane");
     const bool fuse = VAL && Co.reduce >= 0;
     // 1. the exact order in LDS (the finish step moves what it otherwise only re-addresses)
 #if defined(TSAMD_EXP_COAL_NO_EXACT)  // timing experiments (scripts/variants.py): wrong result
@@ -1249,32 +1251,42 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
     }
     // 2. head flags (an entry whose key differs from its predecessor's; the bucket's first entry always: other
     //    buckets hold other keys) and their count per (step, wave)
-    unsigned long long hmask[ITEMS];
+    // (the flags and counts live in LDS, not in registers: as 12-16 ballot words + 12-16 prefixes per thread they pushed
+    // this instantiation past its 128 VGPRs -- 16-61 spilled -- and every thread summed the 96-128 counts by itself)
     unsigned int heads = 0;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
       const int j = k * THREADS + tid;
       bool h = false;
       if (k * THREADS < n && j < n) h = j == 0 || (sword[j] >> L.idx_bits) != (sword[j - 1] >> L.idx_bits);
-      hmask[k] = __ballot(h);
+      const unsigned long long hm = __ballot(h);
       heads |= (h ? 1u : 0u) << k;
       if (lane == 0) {
-        s_heads[k][w] = (unsigned int)__popcll(hmask[k]);
-        if constexpr (VAL) s_hbits[k * kW + w] = hmask[k];  // (entry j = k * THREADS + w * 64 + lane: word j >> 6)
+        s_heads[k * kW + w] = (unsigned int)__popcll(hm);
+        s_hbits[k * kW + w] = hm;
       }
     }
-    if constexpr (VAL)
-      if (tid == 0) s_hbits[ITEMS * kW] = 0ull;
+    if (tid == 0) s_hbits[ITEMS * kW] = 0ull;
     __syncthreads();
-    unsigned int before_step[ITEMS], total = 0;
+    if (w == 0) {  // exclusive prefix of the ITEMS * kW counts in (step, wave) order: two per lane
+      constexpr int kCnt = ITEMS * kW;
+      const unsigned int v0 = lane < kCnt ? s_heads[lane] : 0u, v1 = lane + 64 < kCnt ? s_heads[lane + 64] : 0u;
+      unsigned int i0 = v0, i1 = v1;
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-#pragma unroll
-      for (int ww = 0; ww < kW; ++ww) {
-        if (ww == w) before_step[k] = total;
-        total += s_heads[k][ww];
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o0 = lane_read(i0, lane >= off ? lane - off : lane), o1 = lane_read(i1, lane >= off ? lane - off : lane);
+        if (lane >= off) {
+          i0 += o0;
+          i1 += o1;
+        }
       }
+      const unsigned int t0 = lane_read(i0, 63);
+      if (lane < kCnt) s_heads[lane] = i0 - v0;
+      if (lane + 64 < kCnt) s_heads[lane + 64] = t0 + i1 - v1;
+      if (lane == 63) s_total = t0 + i1;
     }
+    __syncthreads();
+    const unsigned int total = s_total;
     // 3. distinct pairs in the buckets before this one: publish, look back
     constexpr unsigned long long kLocal = 1ull << 62, kPrefix = 2ull << 62, kMask = (1ull << 62) - 1ull;
     const int64_t bucket = (int64_t)blockIdx.x;
@@ -1295,17 +1307,25 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
         else reinterpret_cast<uint64_t *>(gather_dst)[(size_t)start + j] = reinterpret_cast<const uint64_t *>(gather_src)[e];
       }
     }
-    // look-back over kLbWaves x 64 status words per round trip (wave w reads the 64 buckets behind the 64 * w nearer
+    // look-back over lbw x 64 status words per round trip (wave w reads the 64 buckets behind the 64 * w nearer
     // ones; shipped: wave 0 alone).  The ~512 workgroups in flight finish their sorts together, so none of them finds
     // an inclusive prefix nearby: bucket b of a batch spends ~b / 64 dependent round trips here.
     {
       // (measured and rejected, profiles/r06_ab_coalesce_fused.md: every wave of the workgroup reading its own 64 words per
       // round trip -- 146 against 133 us for this kernel at 7.5 M entries: the words are device-scope loads, i.e. fabric
       // round trips, and eight times as many of them queue behind the stores of the other workgroups)
+      // (also rejected: 64 words in the first round trip and kW x 64 in every later one of the same bucket -- the ripple
+      // through the first ~512 buckets in 2 hops instead of 8 -- kernel 113.8 vs 112.3 us, coalesce 0.370 / 0.376 vs
+      // 0.369 / 0.361 ms: the chain is not what this kernel waits for either; -DTSAMD_EXP_COAL_WIDEN_LOOKBACK)
 #if defined(TSAMD_EXP_COAL_WIDE_LOOKBACK)
-      constexpr int kLbWaves = kW;
+      int lbw = kW;
 #else
-      constexpr int kLbWaves = 1;
+      int lbw = 1;
+#endif
+#if defined(TSAMD_EXP_COAL_WIDEN_LOOKBACK)
+      constexpr bool kWiden = true;
+#else
+      constexpr bool kWiden = false;
 #endif
       __shared__ unsigned long long s_lb_sum[kW];
       __shared__ int s_lb_state[kW];  // 0: the wave's 64 buckets are all "own count"; 1: an inclusive prefix ends the sum here; 2: a bucket is not ready
@@ -1319,7 +1339,7 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
       while (t >= 0) {
         const int64_t mt = t - tid;
         unsigned long long sv = kPrefix;  // threads past bucket 0 read as "prefix 0"
-        if (mt >= 0 && w < kLbWaves) sv = __hip_atomic_load(Co.status + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mt >= 0 && w < lbw) sv = __hip_atomic_load(Co.status + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long ready = __ballot((sv >> 62) != 0);
         const unsigned long long pref = __ballot((sv >> 62) == 2);
         const int first_gap = ~ready ? __builtin_ctzll(~ready) : 64;
@@ -1336,8 +1356,8 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
         unsigned long long acc = 0;
         int verdict = 0;
 #pragma unroll
-        for (int ww = 0; ww < kLbWaves; ++ww) {
-          if (verdict == 0) {
+        for (int ww = 0; ww < kW; ++ww) {
+          if (ww < lbw && verdict == 0) {
             const int stt = s_lb_state[ww];
             if (stt != 2) acc += s_lb_sum[ww];
             verdict = stt;
@@ -1350,7 +1370,8 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
         }
         if (verdict == 0) {  // THREADS buckets of own counts: further back
           before += acc;
-          t -= 64 * kLbWaves;
+          t -= 64 * lbw;
+          if (kWiden) lbw = kW;
         } else {  // a bucket in the window has not published yet: read the window again
           if (++spins > kSpinLimit) {  // (see the pass kernel: the dispatch-order assumption does not hold here)
             __builtin_trap();
@@ -1384,7 +1405,7 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
       if ((heads >> k) & 1u) {
 #endif
         const unsigned long long wd = sword[j];
-        const int64_t p = base + before_step[k] + (unsigned int)__popcll(hmask[k] & lt_mask);
+        const int64_t p = base + s_heads[k * kW + w] + (unsigned int)__popcll(s_hbits[k * kW + w] & lt_mask);
         const unsigned long long key = keybase | (wd >> L.idx_bits);
         row_out[p] = (int64_t)(key >> L.col_bits);
         col_out[p] = (int64_t)(key & cmask);
