@@ -31,6 +31,8 @@ for (name, m, n, E) in cases:
     r['sort'] = round(gpu_ms(lambda: ops.sort_coo(row, col, m, n, True), iters=20), 4)
     r['perm_only'] = round(gpu_ms(lambda: ops.sort_coo(col, row, n, m, False), iters=20), 4)
     r['sort_val'] = round(gpu_ms(lambda: ops.sort_coo_values(row, col, m, n, 3, None, val), iters=20), 4)
+    # the compacting chain alone (no host sync inside the op): differences between builds are kernel time
+    r['coalesce_op'] = round(gpu_ms(lambda: ops.sort_coalesce_reduce(row, col, m, n, val, 0), iters=20), 4)
 
     def ctor():
         A = ts.SparseTensor(row=row, col=col, value=val, sparse_sizes=(m, n))
