@@ -47,6 +47,8 @@ for (name, m, n, E) in cases:
         st._colptr = None
         st._colcount = None
         return A.t()
+    rs_ = A.storage.row()
+    r['ind2ptr'] = round(gpu_ms(lambda: torch.ops.torch_sparse.ind2ptr(rs_, m), iters=50), 4)
     r['construct'] = round(wall_ms(ctor, 9), 4)
     r['coalesce'] = round(wall_ms(lambda: ts.coalesce(index, val, m, n), 9), 4)
     r['transpose'] = round(wall_ms(lambda: ts.transpose(index, val, m, n), 9), 4)
