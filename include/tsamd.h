@@ -461,7 +461,9 @@ int tsamd_sort_coalesce(const int64_t *row, const int64_t *col, int64_t E, int64
  * (= stable input) order in the accumulator type of tsamd_segment_reduce -- the same bits -- counts[3] (DEVICE) = 1,
  * and NEITHER seg_ptr NOR value_out is written.  Otherwise counts[3] = 0 and the call leaves exactly what
  * tsamd_sort_coalesce leaves (seg_ptr, value_out = the values in sorted order): the caller reduces them with
- * tsamd_segment_reduce once it has read counts.  counts has FOUR entries here.  Workspace: tsamd_sort_coalesce's. */
+ * tsamd_segment_reduce once it has read counts.  counts has FOUR entries here.  value / value_out / value_u may be
+ * NULL together: index only (the common `coalesce(edge_index)` of a graph without edge attributes) -- counts[3] = 0
+ * and the bucket route writes NO seg_ptr (8 bytes per entry nobody would read).  Workspace: tsamd_sort_coalesce's. */
 int tsamd_sort_coalesce_reduce(const int64_t *row, const int64_t *col, int64_t E, int64_t M, int64_t N,
                                int64_t *row_tmp, int64_t *col_tmp, int64_t *row_u, int64_t *col_u, int64_t *seg_ptr,
                                int64_t *counts, int dtype, int reduce, const void *value, void *value_out,

@@ -65,8 +65,8 @@ def coalesce_rows_cols(row: Tensor, col: Tensor, value: Optional[Tensor], m: int
     if op not in _OPS:
         raise ValueError(op)
     nnz = col.numel()
-    if (_FUSE_REDUCE and nnz > 1 and col.is_cuda and value is not None and _rides(value, nnz) and
-            value.dtype in (torch.float32, torch.int32)):
+    if (_FUSE_REDUCE and nnz > 1 and col.is_cuda and
+            (value is None or (_rides(value, nnz) and value.dtype in (torch.float32, torch.int32)))):
         # sort + duplicate compaction + reduction of the duplicates' values in one op (tsamd_sort_coalesce_reduce):
         # when the bucket sort takes the input, the distinct pairs AND their reduced values are written straight from
         # its last kernel (no run starts, no sorted copy of the values, no reduction pass); ONE transfer brings back
@@ -77,7 +77,9 @@ def coalesce_rows_cols(row: Tensor, col: Tensor, value: Optional[Tensor], m: int
         if n_u == nnz:
             if descents == 0:  # in order, no duplicates: the caller's own data (as the reference hands it back)
                 return torch.stack([row, col], dim=0), value
-            return index_u, (value_u if fused else value_s)
+            return index_u, ((value_u if fused else value_s) if value is not None else None)
+        if value is None:  # index only (the bucket route then wrote no run starts either)
+            return index_u[:, :n_u].contiguous(), None
         if fused:  # (a prefix of the capacity-nnz buffer; its own storage once half of it would be idle)
             value = value_u[:n_u] if 2 * n_u >= nnz else value_u[:n_u].clone()
         else:  # the values came out of the sort in order: a streamed reduction, no gather

@@ -669,6 +669,7 @@ int sort_coalesce_impl(const int64_t *row, const int64_t *col, int64_t E, int64_
     TSAMD_HIP_TRY(hipMemsetAsync(co_ws, 0, co_bytes, stream));
 #endif
     if (reduce >= 0) co.fused_out = counts + 3;
+    co.no_seg = reduce >= 0 && value == nullptr;  // tsamd_sort_coalesce_reduce without a value: index only
     if (reduce >= 0 && value != nullptr && value_bytes == 4 && value_u != nullptr) {
       co.value_u = value_u;
       co.reduce = reduce;
@@ -704,7 +705,9 @@ extern "C" int tsamd_sort_coalesce_reduce(const int64_t *row, const int64_t *col
                                           void *stream_) {
   if (reduce < TSAMD_SUM || reduce > TSAMD_MAX) return TSAMD_ERR_UNSUPPORTED;
   if (dtype != TSAMD_F32 && dtype != TSAMD_I32) return TSAMD_ERR_UNSUPPORTED;
-  if (value == nullptr || value_out == nullptr || value_u == nullptr) return TSAMD_ERR_INVALID;
+  // value, value_out, value_u: all three or none (none = index only: dtype / reduce are not looked at beyond the checks
+  // above, and the bucket route writes no seg_ptr -- nobody is going to reduce values by the run starts)
+  if ((value == nullptr) != (value_out == nullptr) || (value == nullptr) != (value_u == nullptr)) return TSAMD_ERR_INVALID;
   return sort_coalesce_impl(row, col, E, M, N, row_tmp, col_tmp, row_u, col_u, seg_ptr, counts, value, value_out, 4,
                             value_u, reduce, dtype == TSAMD_F32 ? 1 : 0, workspace, workspace_bytes, stream_);
 }

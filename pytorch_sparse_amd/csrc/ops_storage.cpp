@@ -229,29 +229,38 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sort_coalesce(Tensor row, Tensor col,
 }
 
 // tsamd_sort_coalesce_reduce: the same with the reduction of the duplicates' values (float32 / int32, 1-D, no
-// gradient; reduce = 0 sum, 1 mean, 2 min, 3 max) fused into the bucket sort -> (index_u[2, E], seg_ptr[E+1],
+// gradient; reduce = 0 sum, 1 mean, 2 min, 3 max; or no value: index only) fused into the bucket sort -> (index_u[2, E], seg_ptr[E+1],
 // counts[4] = (#descents, #adjacent duplicates, #distinct pairs, 1 = value_u holds the reduced values) on the device,
 // value in sorted order (valid when counts[3] == 0), value_u[E] (valid when counts[3] == 1)).
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sort_coalesce_reduce(Tensor row, Tensor col, int64_t M, int64_t N,
-                                                                      Tensor value, int64_t reduce) {
+                                                                      OptTensor opt_value, int64_t reduce) {
   check_index(row, "row");
   check_index(col, "col");
-  check_gpu(value, "value");
   TORCH_CHECK(row.numel() == col.numel(), "row and col differ in length");
   c10::hip::HIPGuard guard(row.get_device());
   row = row.contiguous();
   col = col.contiguous();
   const int64_t E = row.numel();
-  TORCH_CHECK(value.dim() == 1 && value.size(0) == E &&
-                  (value.scalar_type() == at::kFloat || value.scalar_type() == at::kInt) && !needs_grad(value),
-              "sort_coalesce_reduce: the value must be a 1-D float32 / int32 tensor that needs no gradient");
   TORCH_CHECK(reduce >= 0 && reduce <= 3, "sort_coalesce_reduce: reduce must be 0 (sum), 1 (mean), 2 (min) or 3 (max)");
-  value = value.contiguous();
+  // without a value: index only (seg_ptr is then meaningful on the one-sweep route only -- nobody needs it)
+  const bool with_value = opt_value.has_value();
+  Tensor value, value_s = torch::empty({0}, row.options()), value_u = torch::empty({0}, row.options());
+  bool is_float = true;
+  if (with_value) {
+    value = opt_value.value();
+    check_gpu(value, "value");
+    TORCH_CHECK(value.dim() == 1 && value.size(0) == E &&
+                    (value.scalar_type() == at::kFloat || value.scalar_type() == at::kInt) && !needs_grad(value),
+                "sort_coalesce_reduce: the value must be a 1-D float32 / int32 tensor that needs no gradient");
+    is_float = value.scalar_type() == at::kFloat;
+    value = value.contiguous();
+    value_s = torch::empty_like(value);
+    value_u = torch::empty_like(value);
+  }
   Tensor index_u = torch::empty({2, E}, row.options());
   Tensor row_u = index_u.select(0, 0), col_u = index_u.select(0, 1);
   Tensor row_t = torch::empty({E}, row.options()), col_t = torch::empty({E}, row.options());
   Tensor seg = torch::empty({E + 1}, row.options()), counts = torch::empty({4}, row.options());
-  Tensor value_s = torch::empty_like(value), value_u = torch::empty_like(value);
   if (E == 0) {
     counts.zero_();
     seg.zero_();
@@ -261,9 +270,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sort_coalesce_reduce(Tensor r
   check_status(tsamd_sort_coalesce_reduce(row.data_ptr<int64_t>(), col.data_ptr<int64_t>(), E, M, N,
                                           row_t.data_ptr<int64_t>(), col_t.data_ptr<int64_t>(), row_u.data_ptr<int64_t>(),
                                           col_u.data_ptr<int64_t>(), seg.data_ptr<int64_t>(), counts.data_ptr<int64_t>(),
-                                          value.scalar_type() == at::kFloat ? TSAMD_F32 : TSAMD_I32, (int)reduce,
-                                          value.data_ptr(), value_s.data_ptr(), value_u.data_ptr(), ws.data_ptr(),
-                                          (size_t)ws.numel(), current_stream(row)),
+                                          is_float ? TSAMD_F32 : TSAMD_I32, (int)reduce,
+                                          with_value ? value.data_ptr() : nullptr, with_value ? value_s.data_ptr() : nullptr,
+                                          with_value ? value_u.data_ptr() : nullptr, ws.data_ptr(), (size_t)ws.numel(),
+                                          current_stream(row)),
                "tsamd_sort_coalesce_reduce");
   return std::make_tuple(index_u, seg, counts, value_s, value_u);
 }

@@ -35,6 +35,7 @@ struct SortCoalesce {
   int64_t *fused_out = nullptr;
   int reduce = -1;             // -1: no fused reduction; 0 sum, 1 mean, 2 min, 3 max (TSAMD_SUM .. TSAMD_MAX)
   int is_float = 1;            // 4-byte value type: 1 float32, 0 int32
+  bool no_seg = false;         // index only (no value to reduce afterwards): the bucket route does not write seg_ptr
   // the caller's zero-initialised state (the status words above, the state of its compaction kernel) lies in the
   // pre_zero_bytes bytes directly IN FRONT of `workspace`: the sort's first fill covers them too (one fill kernel
   // instead of three, ~4.5 us each); 0 = the sort zeroes co->status itself

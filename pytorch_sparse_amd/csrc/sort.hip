@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
         if (bucket == (int64_t)gridDim.x - 1) {
           Co.nnz_out[0] = (int64_t)(before + total);
           if (Co.fused_out != nullptr) Co.fused_out[0] = fuse ? 1 : 0;
-          if (!fuse) Co.seg_ptr[before + total] = Co.n_total;
+          if (!fuse && Co.seg_ptr != nullptr) Co.seg_ptr[before + total] = Co.n_total;
         }
       }
     }
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(THREADS, (2 * THREADS / 256)) void bucket_sort_kern
             continue;
           }
         }
-        Co.seg_ptr[p] = (int64_t)start + j;
+        if (Co.seg_ptr != nullptr) Co.seg_ptr[p] = (int64_t)start + j;
       }
     }
     return;
@@ -1754,7 +1754,7 @@ int sort_coo_onesweep(const int64_t *row, const int64_t *col, int64_t E, int64_t
     CoalesceOut Co{nullptr, nullptr, nullptr, E, nullptr, nullptr, -1, 1};
     if (co != nullptr) {
       if (pre_zero == 0) TSAMD_HIP_TRY(hipMemsetAsync(co->status, 0, sizeof(unsigned long long) * (size_t)B.nb, stream));
-      Co.seg_ptr = co->seg_ptr;
+      Co.seg_ptr = co->no_seg ? nullptr : co->seg_ptr;  // (null: nobody will reduce values by these run starts)
       Co.nnz_out = co->nnz_out;
       Co.status = co->status;
       Co.fused_out = co->fused_out;  // (written by the bucket path in any case: 1 = value_u holds the reduced values)

@@ -52,6 +52,7 @@ for (name, m, n, E) in cases:
     r['construct'] = round(wall_ms(ctor, 9), 4)
     r['coalesce'] = round(wall_ms(lambda: ts.coalesce(index, val, m, n), 9), 4)
     r['transpose'] = round(wall_ms(lambda: ts.transpose(index, val, m, n), 9), 4)
+    r['coalesce_index'] = round(wall_ms(lambda: ts.coalesce(index, None, m, n), 9), 4)
     r['t'] = round(wall_ms(t_fresh, 9), 4)
     print(json.dumps(r), flush=True)
     del row, col, val, index, A

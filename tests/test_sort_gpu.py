@@ -256,6 +256,10 @@ def test_sort_coalesce_reduce_bit_exact(dev, ops, E, m, n, kind, fused_expected,
             _, _, l1 = no.coalesce(row.numpy(), col.numpy(), np.abs(val.numpy()), m, n, 'add' if op == 'sum' else op)
             assert np.all(np.abs(got.cpu().numpy() - ev) <= 1e-5 * l1 + 1e-30)
     assert saw_fused == fused_expected, (saw_fused, fused_expected)
+    # index only (no value): the same pairs and counts, nothing reduced
+    index_u, seg, counts, _, _ = ops.sort_coalesce_reduce(rd, cd, m, n, None, 0)
+    assert counts.tolist() == counts_0.tolist() + [0]
+    assert torch.equal(index_u[:, :k], index_0[:, :k])
 
 
 def test_rank_self_test_and_forced_ballot_ranking(dev, ops):
