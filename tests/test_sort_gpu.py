@@ -291,6 +291,45 @@ def test_rank_self_test_and_forced_ballot_ranking(dev, ops):
     assert ops.sort_rank_mode(-1) == decided
 
 
+def test_fused_coalesce_under_both_rankings(dev, ops):
+    """The compacting bucket sort with the fused reduction has a ballot-ranking instantiation too: distinct pairs,
+    counts and reduced values must not depend on the ranking in force (fp32 and int32, every reduction, index only)."""
+    decided = ops.sort_rank_mode(-1)
+    g = torch.Generator().manual_seed(23)
+    cases = []
+    for (E, m, n) in ((400003, 700, 900), (600000, 300000, 300000), (1 << 20, 16, 16)):
+        row = torch.randint(0, m, (E, ), generator=g)
+        col = torch.randint(0, n, (E, ), generator=g)
+        q = E // 4
+        row[:q], col[:q] = row[q:2 * q].clone(), col[q:2 * q].clone()
+        cases.append((row.to(dev), col.to(dev), m, n, torch.randn(E, generator=g).to(dev),
+                      torch.randint(-50, 50, (E, ), generator=g, dtype=torch.int32).to(dev)))
+    try:
+        outs = {}
+        for mode in (0, 1):
+            assert ops.sort_rank_mode(mode) == mode
+            res = []
+            for (r, c, m, n, vf, vi) in cases:
+                for v in (vf, vi, None):
+                    for code in ((0, 1, 2, 3) if v is not None else (0, )):
+                        index_u, seg, counts, vs, vu = ops.sort_coalesce_reduce(r, c, m, n, v, code)
+                        cl = counts.tolist()
+                        k = cl[2]
+                        res.append((cl, index_u[:, :k].clone(), vu[:k].clone() if (v is not None and cl[3] & 1) else None))
+            outs[mode] = res
+        saw_fused = False
+        for a, b in zip(outs[0], outs[1]):
+            assert a[0] == b[0] and torch.equal(a[1], b[1])
+            assert (a[2] is None) == (b[2] is None)
+            if a[2] is not None:
+                saw_fused = True
+                assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+        assert saw_fused
+    finally:
+        ops.sort_rank_mode(2)
+    assert ops.sort_rank_mode(-1) == decided
+
+
 def test_device_decided_sort_and_probe(dev, ops):
     E, m, n = 300000, 4000, 5000
     g = torch.Generator().manual_seed(2)
